@@ -1,0 +1,12 @@
+"""MI355X-native GSC shadow-removal generator forward (drop-in for the reference's ``Generator`` /
+``FSRNet.test*`` inference path).  See DESIGN.md."""
+from .weights import generator_variable_shapes, init_weights  # noqa: F401
+
+__all__ = ["Generator", "generator_variable_shapes", "init_weights"]
+
+
+def __getattr__(name):
+    if name == "Generator":
+        from .model import Generator
+        return Generator
+    raise AttributeError(name)

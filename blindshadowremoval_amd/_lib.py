@@ -1,0 +1,63 @@
+"""ctypes binding of libbsr_hip.so (C ABI: include/bsr_hip.h).  There is NO CPU fallback: if the
+library is missing the import of the HIP path fails loudly."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+from .build import LIB_PATH
+
+ABI_VERSION = 1
+NUM_CLASSES = 6
+CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue")
+
+_lib: Optional[ctypes.CDLL] = None
+
+# every symbol include/bsr_hip.h declares
+EXPORTS = ("bsr_create", "bsr_forward", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
+           "bsr_get_timing", "bsr_destroy", "bsr_last_error", "bsr_abi_version")
+
+
+def load() -> ctypes.CDLL:
+    """Load the in-tree library (after torch, so both share one HIP runtime) and declare signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError("libbsr_hip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "— the HIP path has no fallback" % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 first; our DT_NEEDED then resolves to the same runtime)
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    c_f, c_i, c_v, c_sz = ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    lib.bsr_abi_version.restype = c_i
+    lib.bsr_last_error.restype = ctypes.c_char_p
+    lib.bsr_create.argtypes = [ctypes.POINTER(c_v), c_i, c_v, c_sz, c_i]
+    lib.bsr_create.restype = c_i
+    lib.bsr_forward.argtypes = [c_v, c_v, c_v, c_i, c_i, c_i, c_v, c_v, c_v, c_v, c_v]
+    lib.bsr_forward.restype = c_i
+    lib.bsr_workspace_bytes.argtypes = [c_i, c_i, c_i]
+    lib.bsr_workspace_bytes.restype = c_sz
+    lib.bsr_reserve.argtypes = [c_v, c_i, c_i, c_i]
+    lib.bsr_reserve.restype = c_i
+    lib.bsr_probe.argtypes = [c_v, ctypes.c_char_p, c_v, c_sz, ctypes.POINTER(c_i * 4), c_v]
+    lib.bsr_probe.restype = c_i
+    lib.bsr_set_timing.argtypes = [c_v, c_i]
+    lib.bsr_set_timing.restype = c_i
+    lib.bsr_get_timing.argtypes = [c_v, ctypes.POINTER(ctypes.c_float * NUM_CLASSES), ctypes.POINTER(c_i * NUM_CLASSES)]
+    lib.bsr_get_timing.restype = c_i
+    lib.bsr_destroy.argtypes = [c_v]
+    lib.bsr_destroy.restype = None
+    if lib.bsr_abi_version() != ABI_VERSION:
+        raise RuntimeError("libbsr_hip.so ABI %d != binding ABI %d: rebuild" % (lib.bsr_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().bsr_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

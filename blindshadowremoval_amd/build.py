@@ -1,0 +1,41 @@
+"""Build libbsr_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the repo)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libbsr_hip.so")
+SOURCES = ["csrc/bsr_api.hip"]
+HEADERS = ["csrc/igemm_conv.h", "csrc/attention.h", "csrc/glue_kernels.h", "../include/bsr_hip.h"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.isfile(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def is_stale() -> bool:
+    if not os.path.isfile(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(PKG_DIR, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source into blindshadowremoval_amd/libbsr_hip.so; returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", LIB_PATH + ".tmp"] + [os.path.join(PKG_DIR, s) for s in SOURCES]
+    res = subprocess.run(cmd, cwd=PKG_DIR, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout + res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed building libbsr_hip.so:\n" + res.stderr[-4000:])
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH

@@ -1,0 +1,153 @@
+// Fused single-head attention for NonLocalBlock (/root/reference/model.py:51-53):
+//   f = theta . phi^T  [HW x HW]   (NO 1/sqrt(d) scaling),  P = softmax(f, -1),  y = P . g
+// on the fp32 matrix cores, flash-style (online softmax) so the 4 MB/image score matrix never leaves
+// the CU.  Layout of the qkv buffer: [B][HW][3*D] rows = tokens (t = h*W + w, A.8), channels
+// [0,D) = theta, [D,2D) = phi, [2D,3D) = g.  Output y: [B][HW][D].
+//
+// One workgroup = 4 waves = 128 query tokens of one image; each wave owns 32 queries.  Per 32-key tile:
+//   S^T[key][q]  = sum_c phi[key][c] * theta[q][c]      A = phi tile (LDS, ds_read_b128), B = theta (registers)
+//   -> the accumulator puts the QUERY on the lane (column) and 16 keys in the registers, so the row
+//      max / sum is in-lane plus one exchange with lane^32, and exp(S^T) is already the B operand of
+//   O^T[d][q]   += sum_key g[key][d] * P^T[key][q]      A = g tile (LDS), B = P (registers), no LDS round trip.
+// The d index of the four O^T tiles is interleaved (tile dt, row i  <->  d = 4*i + dt) so one ds_read_b128
+// of g[key][4i..4i+3] feeds four MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "igemm_conv.h"
+
+namespace bsr {
+
+constexpr int kAttD = 128;        // C/2 of the 257-channel NonLocalBlock (/root/reference/model.py:10-12)
+constexpr int kAttKT = 32;        // keys per LDS stage
+constexpr int kAttLdK = kAttD + 4;
+constexpr int kAttStageFloats = kAttKT * kAttLdK + kAttKT * kAttD;
+constexpr int kAttSmemBytes = 2 * kAttStageFloats * 4;
+
+__global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int qblocks = tokens / 128;
+  const int img = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+  const float* base = qkv + (size_t)img * tokens * (3 * kAttD);
+  const int q = qb * 128 + wave * 32 + r;
+
+  // theta fragment of this lane's query: element j of group g is channel 8g + 4h + j
+  f32x4 qf[kAttD / 8];
+#pragma unroll
+  for (int g = 0; g < kAttD / 8; ++g)
+    qf[g] = *reinterpret_cast<const f32x4*>(base + (size_t)q * (3 * kAttD) + g * 8 + 4 * h);
+
+  f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  constexpr int V4_PER_STAGE = kAttKT * kAttD / 4;      // 1024 float4 per operand -> 4 per thread
+  f32x4 kreg[V4_PER_STAGE / 256], vreg[V4_PER_STAGE / 256];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < V4_PER_STAGE / 256; ++i) {
+      const int idx = tid + i * 256;
+      const int key = idx / (kAttD / 4), c4 = idx % (kAttD / 4);
+      const float* row = base + (size_t)(kt * kAttKT + key) * (3 * kAttD);
+      kreg[i] = *reinterpret_cast<const f32x4*>(row + kAttD + c4 * 4);
+      vreg[i] = *reinterpret_cast<const f32x4*>(row + 2 * kAttD + c4 * 4);
+    }
+  };
+  auto publish = [&](int buf) {
+    float* sk = smem + buf * kAttStageFloats;
+    float* sv = sk + kAttKT * kAttLdK;
+#pragma unroll
+    for (int i = 0; i < V4_PER_STAGE / 256; ++i) {
+      const int idx = tid + i * 256;
+      const int key = idx / (kAttD / 4), c4 = idx % (kAttD / 4);
+      *reinterpret_cast<f32x4*>(sk + key * kAttLdK + c4 * 4) = kreg[i];
+      *reinterpret_cast<f32x4*>(sv + key * kAttD + c4 * 4) = vreg[i];
+    }
+  };
+
+  const int nkt = tokens / kAttKT;
+  fetch(0);
+  publish(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) fetch(kt + 1);
+    const float* sk = smem + buf * kAttStageFloats;
+    const float* sv = sk + kAttKT * kAttLdK;
+
+    // S^T tile: rows = keys (A from LDS), cols = queries (B from registers)
+    f32x16 s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < kAttD / 8; ++g) {
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(sk + r * kAttLdK + g * 8 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[g][j], s, 0, 0, 0);
+    }
+
+    // online softmax for this lane's query: 16 keys here + 16 in lane^32
+    float mx = s[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float scale = __expf(m_run - m_new);      // exp(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i] = __expf(s[i] - m_new);
+      psum += s[i];
+    }
+    l_run = l_run * scale + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] *= scale;
+
+    // O^T += g^T . P^T : register i of s holds key (i&3) + 8*(i>>2) + 4h
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+      const f32x4 vf = *reinterpret_cast<const f32x4*>(sv + key * kAttD + 4 * r);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[dt], s[i], o[dt], 0, 0, 0);
+    }
+
+    if (kt + 1 < nkt) {
+      publish(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // combine the two key halves' partial sums, normalise, store y[q][d], d = 4*row + dt
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  float* orow = out + ((size_t)img * tokens + q) * kAttD;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+    f32x4 v = {o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv};
+    *reinterpret_cast<f32x4*>(orow + 4 * row) = v;
+  }
+}
+
+inline hipError_t launch_nonlocal_attention(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nonlocal_attention_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kAttSmemBytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nonlocal_attention_kernel, dim3(batch * (tokens / 128)), dim3(256), kAttSmemBytes, stream, qkv, out, tokens);
+  return hipGetLastError();
+}
+
+}  // namespace bsr

@@ -1,0 +1,471 @@
+// libbsr_hip.so — host side of the MI355X-native GSC generator forward (C ABI in include/bsr_hip.h).
+// Orchestrates Generator.call (/root/reference/model.py:228-290) as a fixed sequence of hand-written
+// gfx950 kernels over one pre-planned NHWC workspace; concatenations are channel slices of shared buffers.
+#include "../../include/bsr_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "attention.h"
+#include "glue_kernels.h"
+#include "igemm_conv.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail(BSR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                \
+  } while (0)
+
+// ---- packed-weight blob (written by blindshadowremoval_amd/pack.py) ----
+constexpr uint32_t kBlobMagic = 0x57525342u;  // "BSRW"
+constexpr uint32_t kBlobVersion = 1;
+struct BlobHeader {
+  uint32_t magic, version, n_entries, reserved;
+};
+struct BlobEntry {
+  char name[40];
+  uint64_t offset;   // bytes from blob start, 16-byte aligned
+  uint64_t nfloats;
+  int32_t dims[4];   // conv weights: {nchunk, taps, n_pad, CC+4}; bias: {n_pad,0,0,0}
+};
+
+struct LayerW {
+  const float* w = nullptr;
+  const float* b = nullptr;
+  int nchunk = 0, taps = 0, n_pad = 0, ldp = 0;
+};
+
+enum KClass { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2, K_ATT = 3, K_CONV7 = 4, K_GLUE = 5 };
+
+constexpr int C_RES = 257;   // ResBottleneck width (/root/reference/model.py:226)
+constexpr int CS_RES = 264;  // its channel stride (multiple of the 24-wide K chunk)
+constexpr int CS_XA = 120;   // cat[x(96), uv(3)] stride (model.py:238)
+constexpr int CS_CF = 72;    // cat[f(64), gs(1)] stride (model.py:267; gs moved to the tail, weights permuted)
+
+struct Plan {  // float offsets into the workspace for a (B,H,W) problem
+  size_t xr, x1, c3, c2, xa, t1, t2, y3[6], qkv, att[6], r[6], xh, ybuf, qh, f1, f2, cf, c1, probe, total;
+};
+
+Plan make_plan(size_t B, size_t H, size_t W) {
+  Plan p;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    size_t o = off;
+    off += (floats + 63) & ~size_t(63);
+    return o;
+  };
+  const size_t px = B * H * W, cells = px / 64;
+  p.xr = take(px * 24);
+  p.x1 = take(px * 32);
+  p.c3 = take(px / 4 * 128);
+  p.c2 = take(px / 16 * 160);
+  p.xa = take(cells * CS_XA);
+  p.t1 = take(cells * 128);
+  p.t2 = take(cells * 128);
+  for (int i = 0; i < 6; ++i) p.y3[i] = take(cells * CS_RES);
+  p.qkv = take(cells * 384);
+  for (int i = 0; i < 6; ++i) p.att[i] = take(cells * 128);
+  for (int i = 0; i < 6; ++i) p.r[i] = take(cells * CS_RES);
+  p.xh = take(cells * CS_RES);
+  p.ybuf = take(px * 64);
+  p.qh = take(px * 16);
+  p.f1 = take(px / 16 * 128);
+  p.f2 = take(px / 4 * 96);
+  p.cf = take(px * CS_CF);
+  p.c1 = take(px * 16);
+  p.probe = take(cells * 2);
+  p.total = off;
+  return p;
+}
+
+}  // namespace
+
+struct bsr_handle {
+  int device = 0;
+  float* d_blob = nullptr;
+  std::unordered_map<std::string, LayerW> layers;
+  float head_bias[2] = {0.f, 0.f};
+  const float* tail_w = nullptr;
+  float* ws = nullptr;
+  size_t ws_floats = 0;
+  Plan plan{};
+  int B = 0, H = 0, W = 0;       // shape of the last forward
+  bool ran = false;
+  bool timing = false;
+  std::vector<hipEvent_t> ev;    // event pool, pairs
+  std::vector<int> ev_class;
+  size_t ev_used = 0;
+};
+
+namespace {
+
+int find_layer(bsr_handle* h, const char* name, int nchunk, int taps, int ldp, int n_min, LayerW* out) {
+  auto it = h->layers.find(name);
+  if (it == h->layers.end()) return fail(BSR_ERR_BLOB, std::string("blob has no layer '") + name + "'");
+  const LayerW& l = it->second;
+  if (l.w == nullptr || l.b == nullptr || l.nchunk != nchunk || l.taps != taps || l.ldp != ldp || l.n_pad < n_min) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "layer '%s': blob has {chunks %d, taps %d, n_pad %d, ldp %d}, kernel needs {%d, %d, >=%d, %d}", name,
+             l.nchunk, l.taps, l.n_pad, l.ldp, nchunk, taps, n_min, ldp);
+    return fail(BSR_ERR_BLOB, buf);
+  }
+  *out = l;
+  return BSR_OK;
+}
+
+struct Launcher {
+  bsr_handle* h;
+  hipStream_t s;
+  int rc = BSR_OK;
+
+  void begin(int cls) {
+    if (!h->timing) return;
+    if (h->ev_used + 2 > h->ev.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        h->ev.push_back(e);
+      }
+      h->ev_class.push_back(cls);
+    }
+    h->ev_class[h->ev_used / 2] = cls;
+    hipEventRecord(h->ev[h->ev_used], s);
+  }
+  void end() {
+    if (!h->timing) return;
+    hipEventRecord(h->ev[h->ev_used + 1], s);
+    h->ev_used += 2;
+  }
+  void check(hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == BSR_OK) rc = fail(BSR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  }
+
+  // KH,KW,S,TR,TH,TW,WM,WN,MI,NI,CC,PF_IN
+  template <int KH, int KW, int S, bool TR, int NI, int CC, bool PF_IN>
+  void conv(int cls, const char* name, const float* in, int in_cs, int in_coff, int k_pad, int H, int W, float* out, int out_cs,
+            int out_coff, int n_store, int act, const float* res1 = nullptr, int res1_cs = 0, int res1_c = 0,
+            const float* res2 = nullptr, int res2_cs = 0, int res2_c = 0) {
+    if (rc != BSR_OK) return;
+    using C = bsr::ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, PF_IN>;
+    LayerW l;
+    const int nb = (n_store + C::BN - 1) / C::BN;
+    rc = find_layer(h, name, k_pad / CC, KH * KW, CC + 4, nb * C::BN, &l);
+    if (rc != BSR_OK) return;
+    bsr::ConvArgs a{};
+    a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.H = H; a.W = W;
+    a.out = out; a.out_cs = out_cs; a.out_coff = out_coff;
+    a.Ho = TR ? 2 * H : (H + S - 1) / S;
+    a.Wo = TR ? 2 * W : (W + S - 1) / S;
+    a.w = l.w; a.bias = l.b; a.nchunk = l.nchunk; a.n_pad = l.n_pad; a.n_store = n_store;
+    // TF SAME pad-before: total = max((out-1)*s + k - in, 0), before = total / 2
+    auto pad_before = [](int in, int k, int s) {
+      int o = (in + s - 1) / s, tot = (o - 1) * s + k - in;
+      return tot > 0 ? tot / 2 : 0;
+    };
+    a.pad_t = pad_before(H, KH, S);
+    a.pad_l = pad_before(W, KW, S);
+    a.act = act;
+    a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c;
+    a.res2 = res2; a.res2_cs = res2_cs; a.res2_c = res2_c;
+    const int mh = TR ? H : a.Ho, mw = TR ? W : a.Wo;
+    if (mh % 4 != 0 || mw % 32 != 0) {
+      rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': feature map is not a multiple of the 4x32 tile");
+      return;
+    }
+    begin(cls);
+    check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, PF_IN>(a, h->B, s), name);
+    end();
+  }
+};
+
+int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
+  Plan p = make_plan(B, H, W);
+  if (p.total > h->ws_floats) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h->ws) HIP_TRY(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_floats = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ws), p.total * sizeof(float)));
+    h->ws_floats = p.total;
+    h->B = 0;  // force re-zero below
+  }
+  if (B != h->B || H != h->H || W != h->W) {
+    // channel-pad lanes of the concat buffers must read as 0: clear once per shape
+    HIP_TRY(hipMemsetAsync(h->ws, 0, p.total * sizeof(float), s));
+    h->ran = false;
+  }
+  h->plan = p;
+  h->B = B; h->H = H; h->W = W;
+  return BSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsr_abi_version(void) { return 1; }
+
+const char* bsr_last_error(void) { return g_last_error.c_str(); }
+
+size_t bsr_workspace_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return make_plan(B, H, W).total * sizeof(float);
+}
+
+int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t nbytes, int dtype) {
+  if (out == nullptr || packed_weights == nullptr) return fail(BSR_ERR_ARG, "bsr_create: null argument");
+  *out = nullptr;
+  if (dtype != BSR_DTYPE_F32) return fail(BSR_ERR_ARG, "bsr_create: only BSR_DTYPE_F32 is implemented");
+  if (nbytes < sizeof(BlobHeader)) return fail(BSR_ERR_BLOB, "bsr_create: blob shorter than its header");
+  const uint8_t* blob = static_cast<const uint8_t*>(packed_weights);
+  BlobHeader hd;
+  memcpy(&hd, blob, sizeof hd);
+  if (hd.magic != kBlobMagic || hd.version != kBlobVersion) return fail(BSR_ERR_BLOB, "bsr_create: bad blob magic/version");
+  const size_t table_end = sizeof(BlobHeader) + (size_t)hd.n_entries * sizeof(BlobEntry);
+  if (table_end > nbytes) return fail(BSR_ERR_BLOB, "bsr_create: blob entry table exceeds blob size");
+  HIP_TRY(hipSetDevice(device));
+  bsr_handle* h = new bsr_handle();
+  h->device = device;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
+  if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (h->d_blob) hipFree(h->d_blob);
+    delete h;
+    return fail(BSR_ERR_HIP, std::string("bsr_create: weight upload: ") + hipGetErrorString(e));
+  }
+  for (uint32_t i = 0; i < hd.n_entries; ++i) {
+    BlobEntry en;
+    memcpy(&en, blob + sizeof(BlobHeader) + (size_t)i * sizeof(BlobEntry), sizeof en);
+    en.name[sizeof(en.name) - 1] = 0;
+    if (en.offset % 16 != 0 || en.offset + en.nfloats * 4 > nbytes) {
+      bsr_destroy(h);
+      return fail(BSR_ERR_BLOB, std::string("bsr_create: entry '") + en.name + "' is out of bounds or misaligned");
+    }
+    std::string nm(en.name);
+    const float* dptr = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(h->d_blob) + en.offset);
+    if (nm == "heads.bias") {
+      if (en.nfloats != 2) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: heads.bias must hold 2 floats"); }
+      memcpy(h->head_bias, blob + en.offset, 8);
+    } else if (nm == "tail.w") {
+      if (en.nfloats != 16 * 16 + 16 + 48 + 3) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: tail.w has the wrong size"); }
+      h->tail_w = dptr;
+    } else if (nm.size() > 2 && nm.compare(nm.size() - 2, 2, ".w") == 0) {
+      LayerW& l = h->layers[nm.substr(0, nm.size() - 2)];
+      l.w = dptr;
+      l.nchunk = en.dims[0]; l.taps = en.dims[1]; l.n_pad = en.dims[2]; l.ldp = en.dims[3];
+      if ((uint64_t)l.nchunk * l.taps * l.n_pad * l.ldp != en.nfloats) {
+        bsr_destroy(h);
+        return fail(BSR_ERR_BLOB, std::string("bsr_create: entry '") + en.name + "' dims do not match its size");
+      }
+    } else if (nm.size() > 2 && nm.compare(nm.size() - 2, 2, ".b") == 0) {
+      h->layers[nm.substr(0, nm.size() - 2)].b = dptr;
+    }
+  }
+  if (h->tail_w == nullptr) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob has no 'tail.w'"); }
+  *out = h;
+  return BSR_OK;
+}
+
+void bsr_destroy(bsr_handle* h) {
+  if (h == nullptr) return;
+  hipSetDevice(h->device);
+  for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  if (h->ws) hipFree(h->ws);
+  if (h->d_blob) hipFree(h->d_blob);
+  delete h;
+}
+
+int bsr_reserve(bsr_handle* h, int B, int H, int W) {
+  if (h == nullptr || B <= 0 || H <= 0 || W <= 0) return fail(BSR_ERR_ARG, "bsr_reserve: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  Plan p = make_plan(B, H, W);
+  if (p.total > h->ws_floats) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->ws) HIP_TRY(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_floats = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ws), p.total * sizeof(float)));
+    h->ws_floats = p.total;
+    h->B = 0;
+  }
+  return BSR_OK;
+}
+
+int bsr_set_timing(bsr_handle* h, int enable) {
+  if (h == nullptr) return fail(BSR_ERR_ARG, "bsr_set_timing: null handle");
+  h->timing = enable != 0;
+  h->ev_used = 0;
+  return BSR_OK;
+}
+
+int bsr_get_timing(bsr_handle* h, float ms[BSR_NUM_CLASSES], int launches[BSR_NUM_CLASSES]) {
+  if (h == nullptr || ms == nullptr || launches == nullptr) return fail(BSR_ERR_ARG, "bsr_get_timing: null argument");
+  for (int i = 0; i < BSR_NUM_CLASSES; ++i) { ms[i] = 0.f; launches[i] = 0; }
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+    const int c = h->ev_class[i / 2];
+    ms[c] += t;
+    launches[c] += 1;
+  }
+  return BSR_OK;
+}
+
+int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W, float* gs, float* con_rgb, float* mask22,
+                float* dif, void* stream) {
+  if (h == nullptr || inputs == nullptr || uv == nullptr || gs == nullptr || con_rgb == nullptr || mask22 == nullptr || dif == nullptr)
+    return fail(BSR_ERR_ARG, "bsr_forward: null argument");
+  if (B <= 0) return fail(BSR_ERR_ARG, "bsr_forward: B must be positive");
+  if (H <= 0 || W <= 0 || H % 32 != 0 || W % 256 != 0)
+    return fail(BSR_ERR_ARG, "bsr_forward: H must be a multiple of 32 and W a multiple of 256 (reference: 256x256)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_workspace(h, B, H, W, s);
+  if (rc != BSR_OK) return rc;
+  h->ev_used = 0;
+  const Plan& p = h->plan;
+  float* ws = h->ws;
+  const size_t npix = (size_t)B * H * W, ncell = npix / 64;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  Launcher L{h, s};
+  auto glue_begin = [&]() { L.begin(K_GLUE); };
+  auto glue_end = [&](const char* what) { L.check(hipGetLastError(), what); L.end(); };
+
+  // conv1 = Conv(32, 7x7) (model.py:203,230): im2row over kx, then a 7x1 MFMA conv with K = 7 x 24
+  glue_begin();
+  hipLaunchKernelGGL(bsr::im2row7_kernel, dim3((unsigned)((npix * 6 + 255) / 256)), dim3(256), 0, s, inputs, ws + p.xr, W, npix);
+  glue_end("im2row7");
+  L.conv<7, 1, 1, false, 1, 24, true>(K_CONV7, "conv1", ws + p.xr, 24, 0, 24, H, W, ws + p.x1, 32, 0, 32, 1);
+  // down1..3 = Conv(stride 2) (model.py:207-209,231-233); x2 / x3 land in their skip-concat slots (model.py:244-245)
+  L.conv<3, 3, 2, false, 2, 16, false>(K_CONV3, "down1", ws + p.x1, 32, 0, 32, H, W, ws + p.c3, 128, 64, 64, 1);
+  L.conv<3, 3, 2, false, 2, 16, false>(K_CONV3, "down2", ws + p.c3, 128, 64, 64, H2, W2, ws + p.c2, 160, 96, 64, 1);
+  L.conv<3, 3, 2, false, 3, 16, false>(K_CONV3, "down3", ws + p.c2, 160, 96, 64, H4, W4, ws + p.xa, CS_XA, 0, 96, 1);
+  // uv = resize(uv, [h,w]); x = cat[x, uv] (model.py:237-238) and the uv slot of cat[x_hole, bmask, uv] (model.py:259)
+  glue_begin();
+  hipLaunchKernelGGL(bsr::uv_resize8_kernel, dim3((unsigned)((ncell * 3 + 255) / 256)), dim3(256), 0, s, uv, H, W, ws + p.xa, CS_XA, 96,
+                     ws + p.xh, CS_RES, C_RES + 1, ncell);
+  glue_end("uv_resize8");
+
+  // ResBottleneck + NonLocalBlock (model.py:98-113, 23-61)
+  auto res_block = [&](int i, const float* x, int x_cs) {
+    char nm[32];
+    float* y3 = ws + p.y3[i];
+    snprintf(nm, sizeof nm, "res%d.conv1", i);
+    L.conv<1, 1, 1, false, 2, 24, true>(K_CONV1, nm, x, x_cs, 0, x_cs, H8, W8, ws + p.t1, 128, 0, 128, 1);
+    snprintf(nm, sizeof nm, "res%d.conv2", i);
+    L.conv<3, 3, 1, false, 2, 32, true>(K_CONV3, nm, ws + p.t1, 128, 0, 128, H8, W8, ws + p.t2, 128, 0, 128, 1);
+    snprintf(nm, sizeof nm, "res%d.conv3", i);
+    L.conv<1, 1, 1, false, 3, 32, true>(K_CONV1, nm, ws + p.t2, 128, 0, 128, H8, W8, y3, CS_RES, 0, CS_RES, 0);
+    snprintf(nm, sizeof nm, "res%d.qkv", i);
+    L.conv<1, 1, 1, false, 4, 24, true>(K_CONV1, nm, y3, CS_RES, 0, CS_RES, H8, W8, ws + p.qkv, 384, 0, 384, 0);
+    if (L.rc == BSR_OK) {
+      L.begin(K_ATT);
+      L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
+      L.end();
+    }
+    // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113)
+    snprintf(nm, sizeof nm, "res%d.w", i);
+    L.conv<1, 1, 1, false, 3, 32, true>(K_CONV1, nm, ws + p.att[i], 128, 0, 128, H8, W8, ws + p.r[i], CS_RES, 0, CS_RES, 1, x, x_cs, x_cs,
+                                         y3, CS_RES, CS_RES);
+  };
+  if ((H8 * W8) % 128 != 0) return fail(BSR_ERR_ARG, "bsr_forward: (H/8)*(W/8) must be a multiple of 128");
+  res_block(0, ws + p.xa, CS_XA);
+  res_block(1, ws + p.r[0], CS_RES);
+  res_block(2, ws + p.r[1], CS_RES);
+
+  // greyscale decoder: up1..3 = ConvT (model.py:243-245)
+  L.conv<3, 3, 1, true, 1, 24, true>(K_CONVT, "up1", ws + p.r[2], CS_RES, 0, CS_RES, H8, W8, ws + p.c2, 160, 0, 96, 1);
+  L.conv<3, 3, 1, true, 2, 32, true>(K_CONVT, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
+  L.conv<3, 3, 1, true, 2, 32, true>(K_CONVT, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
+  // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
+  L.conv<7, 1, 1, false, 1, 32, true>(K_CONV7, "heads", ws + p.ybuf, 64, 0, 64, H, W, ws + p.qh, 16, 0, 14, 0);
+  glue_begin();
+  hipLaunchKernelGGL(bsr::heads_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.qh, inputs, h->head_bias[0],
+                     h->head_bias[1], gs, mask22, ws + p.cf, CS_CF, 64, W, npix);
+  glue_end("heads_post");
+  // bmask / x_hole (model.py:256-259)
+  glue_begin();
+  hipLaunchKernelGGL(bsr::bmask_xhole_kernel, dim3((unsigned)ncell), dim3(64), 0, s, gs, inputs, H, W, ws + p.r[2], CS_RES, C_RES, ws + p.xh,
+                     CS_RES, ws + p.probe);
+  glue_end("bmask_xhole");
+
+  res_block(3, ws + p.xh, CS_RES);
+  res_block(4, ws + p.r[3], CS_RES);
+  res_block(5, ws + p.r[4], CS_RES);
+
+  // colour decoder (model.py:264-269)
+  L.conv<3, 3, 1, true, 2, 24, true>(K_CONVT, "clr_up1", ws + p.r[5], CS_RES, 0, CS_RES, H8, W8, ws + p.f1, 128, 0, 128, 1);
+  L.conv<3, 3, 1, true, 1, 32, true>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1);
+  L.conv<3, 3, 1, true, 2, 32, true>(K_CONVT, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
+  L.conv<3, 3, 1, false, 1, 24, true>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, 0, CS_CF, H, W, ws + p.c1, 16, 0, 16, 1);
+  if (L.rc == BSR_OK) {
+    glue_begin();
+    hipLaunchKernelGGL(bsr::color_tail_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.c1, h->tail_w, inputs, con_rgb, dif,
+                       npix);
+    glue_end("color_tail");
+  }
+  if (L.rc == BSR_OK) h->ran = true;
+  return L.rc;
+}
+
+int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream) {
+  if (h == nullptr || name == nullptr || dst == nullptr || shape4 == nullptr) return fail(BSR_ERR_ARG, "bsr_probe: null argument");
+  if (!h->ran) return fail(BSR_ERR_STATE, "bsr_probe: no forward has run on this handle");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Plan& p = h->plan;
+  const int B = h->B, H = h->H, W = h->W;
+  struct Src { size_t off; int hh, ww, cs, coff, c; };
+  Src src{};
+  std::string nm(name);
+  auto res_idx = [&](const char* prefix) -> int {
+    size_t n = strlen(prefix);
+    if (nm.size() == n + 1 && nm.compare(0, n, prefix) == 0 && nm[n] >= '0' && nm[n] <= '5') return nm[n] - '0';
+    return -1;
+  };
+  int i;
+  if (nm == "x1") src = {p.x1, H, W, 32, 0, 32};
+  else if (nm == "x2") src = {p.c3, H / 2, W / 2, 128, 64, 64};
+  else if (nm == "x3") src = {p.c2, H / 4, W / 4, 160, 96, 64};
+  else if (nm == "x0") src = {p.xa, H / 8, W / 8, CS_XA, 0, 99};
+  else if ((i = res_idx("res")) >= 0) src = {p.r[i], H / 8, W / 8, CS_RES, 0, i < 3 ? C_RES : C_RES + 4};
+  else if ((i = res_idx("att")) >= 0) src = {p.att[i], H / 8, W / 8, 128, 0, 128};
+  else if ((i = res_idx("y3_")) >= 0) src = {p.y3[i], H / 8, W / 8, CS_RES, 0, C_RES};
+  else if (nm == "up1") src = {p.c2, H / 4, W / 4, 160, 0, 96};
+  else if (nm == "up2") src = {p.c3, H / 2, W / 2, 128, 0, 64};
+  else if (nm == "y") src = {p.ybuf, H, W, 64, 0, 64};
+  else if (nm == "d32") src = {p.probe, H / 8, W / 8, 2, 0, 1};
+  else if (nm == "bmask") src = {p.probe, H / 8, W / 8, 2, 1, 1};
+  else if (nm == "xh") src = {p.xh, H / 8, W / 8, CS_RES, 0, C_RES + 4};
+  else if (nm == "f1") src = {p.f1, H / 4, W / 4, 128, 0, 128};
+  else if (nm == "f2") src = {p.f2, H / 2, W / 2, 96, 0, 96};
+  else if (nm == "f") src = {p.cf, H, W, CS_CF, 0, 64};
+  else if (nm == "c1") src = {p.c1, H, W, 16, 0, 16};
+  else return fail(BSR_ERR_STATE, std::string("bsr_probe: unknown probe '") + name + "'");
+  const size_t npix = (size_t)B * src.hh * src.ww;
+  shape4[0] = B; shape4[1] = src.hh; shape4[2] = src.ww; shape4[3] = src.c;
+  if (npix * src.c > cap_floats) return fail(BSR_ERR_ARG, "bsr_probe: destination too small");
+  hipLaunchKernelGGL(bsr::slice_copy_kernel, dim3((unsigned)((npix * src.c + 255) / 256)), dim3(256), 0, s, h->ws + src.off, src.cs, src.coff,
+                     src.c, dst, npix);
+  HIP_TRY(hipGetLastError());
+  return BSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+// Small HBM-bound kernels around the MFMA convolutions: the glue of Generator.call
+// (/root/reference/model.py:237,238,246-252,256-259,267-269,288).  fp contraction is disabled so the
+// grayscale / gs / dif arithmetic rounds like the reference's separate TF ops (matters at the hard
+// 0.1 threshold of model.py:256).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "igemm_conv.h"
+
+#pragma clang fp contract(off)
+
+namespace bsr {
+
+__device__ __forceinline__ float gray3(float r, float g, float b) {
+  // tf.image.rgb_to_grayscale: sum(x * [0.2989, 0.5870, 0.1140]) (/root/reference/model.py:250)
+  return (r * 0.2989f + g * 0.5870f) + b * 0.1140f;
+}
+
+// inputs [B,H,W,3] -> xr [B,H,W,24]: xr[y][x][kx*3+c] = in[y][x+kx-3][c] (zero outside), ch 21..23 = 0.
+// Turns the 7x7x3 stem conv (model.py:203,230) into a 7x1 conv over 24 channels for the MFMA kernel.
+__global__ void im2row7_kernel(const float* __restrict__ in, float* __restrict__ xr, int W, size_t npix) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (pixel, float4 of 24 ch)
+  const size_t pix = gid / 6;
+  const int q = (int)(gid % 6);
+  if (pix >= npix) return;
+  const int x = (int)(pix % W);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = q * 4 + e;           // kx*3 + c
+    const int kx = k / 3, c = k % 3;
+    const int sx = x + kx - 3;
+    float val = 0.f;
+    if (k < 21 && sx >= 0 && sx < W) val = in[(pix + (size_t)(kx - 3)) * 3 + c];
+    v[e] = val;
+  }
+  *reinterpret_cast<f32x4*>(xr + pix * 24 + q * 4) = v;
+}
+
+// tf.image.resize(uv, [H/8, W/8]) bilinear, half-pixel centres (model.py:237): for an exact 8x reduction
+// the sample point is 8o+3.5, i.e. the mean of the centre 2x2 block.  Writes the 3 channels into two
+// concat slots: dst_a[..., coff_a..] (model.py:238) and dst_b[..., coff_b..] (model.py:259).
+__global__ void uv_resize8_kernel(const float* __restrict__ uv, int H, int W, float* __restrict__ dst_a, int cs_a, int coff_a,
+                                  float* __restrict__ dst_b, int cs_b, int coff_b, size_t ncell) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncell * 3) return;
+  const size_t cell = gid / 3;
+  const int c = (int)(gid % 3);
+  const int h8 = H / 8, w8 = W / 8;
+  const int p = (int)(cell % w8), o = (int)((cell / w8) % h8);
+  const size_t img = cell / ((size_t)w8 * h8);
+  const float* src = uv + ((img * H + 8 * o + 3) * W + 8 * p + 3) * 3 + c;
+  const float a = src[0], b = src[3], cc = src[(size_t)W * 3], d = src[(size_t)W * 3 + 3];
+  const float v = 0.5f * (0.5f * a + 0.5f * b) + 0.5f * (0.5f * cc + 0.5f * d);
+  dst_a[cell * cs_a + coff_a + c] = v;
+  dst_b[cell * cs_b + coff_b + c] = v;
+}
+
+// Heads epilogue (model.py:246-252).  q [B,H,W,16]: q[y][x'][kx*2+o] = sum_{ky,c} y[y+ky-3][x'][c] * w_o[ky][kx][c]
+// (the 7x1 MFMA conv); here the 7 horizontal taps are summed, then
+//   mask = tanh(. + b2), con = . + b3, gs = gray(inputs)*(1+mask)+con, mask22 = [relu(mask), 0, relu(-mask)].
+// gs is also written into channel gs_coff of the clr_conv1 concat buffer (model.py:267).
+__global__ void heads_post_kernel(const float* __restrict__ q, const float* __restrict__ inputs, float b_mask, float b_con,
+                                  float* __restrict__ gs, float* __restrict__ mask22, float* __restrict__ cat, int cat_cs,
+                                  int gs_coff, int W, size_t npix) {
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int x = (int)(pix % W);
+  float m = 0.f, cn = 0.f;
+#pragma unroll
+  for (int kx = 0; kx < 7; ++kx) {
+    const int sx = x + kx - 3;
+    if (sx >= 0 && sx < W) {
+      const float2 v = *reinterpret_cast<const float2*>(q + (pix + (size_t)(kx - 3)) * 16 + kx * 2);
+      m += v.x;
+      cn += v.y;
+    }
+  }
+  const float mask = tanhf(m + b_mask);
+  const float con = cn + b_con;
+  const float g0 = gray3(inputs[pix * 3], inputs[pix * 3 + 1], inputs[pix * 3 + 2]);
+  const float g = g0 * (1.f + mask) + con;
+  gs[pix] = g;
+  cat[pix * cat_cs + gs_coff] = g;
+  mask22[pix * 3 + 0] = fmaxf(mask, 0.f);
+  mask22[pix * 3 + 1] = mask * 0.f;
+  mask22[pix * 3 + 2] = fmaxf(-mask, 0.f);
+}
+
+// model.py:251,256-259: dif = gs - gray(inputs); d32 = resize(dif, /8) (centre 2x2 mean);
+// bmask = d32 > 0.1 (strict); x_hole = x*(1-bmask); xh = cat[x_hole, bmask, uv] (uv slot filled by uv_resize8).
+// One workgroup of 64 threads per 32x32 cell; r [B,cells,r_cs] -> xh [B,cells,xh_cs]; probe [cells][2] = {d32, bmask}.
+__global__ void bmask_xhole_kernel(const float* __restrict__ gs, const float* __restrict__ inputs, int H, int W,
+                                   const float* __restrict__ r, int r_cs, int r_c, float* __restrict__ xh, int xh_cs,
+                                   float* __restrict__ probe) {
+  const size_t cell = blockIdx.x;
+  const int h8 = H / 8, w8 = W / 8;
+  const int p = (int)(cell % w8), o = (int)((cell / w8) % h8);
+  const size_t img = cell / ((size_t)w8 * h8);
+  const size_t p00 = (img * H + 8 * o + 3) * W + 8 * p + 3;
+  float d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t px = p00 + (size_t)(k >> 1) * W + (k & 1);
+    const float g0 = gray3(inputs[px * 3], inputs[px * 3 + 1], inputs[px * 3 + 2]);
+    d[k] = gs[px] - g0;
+  }
+  const float d32 = 0.5f * (0.5f * d[0] + 0.5f * d[1]) + 0.5f * (0.5f * d[2] + 0.5f * d[3]);
+  const float bm = d32 > 0.1f ? 1.f : 0.f;
+  const float keep = 1.f - bm;
+  for (int c = threadIdx.x; c < r_c; c += blockDim.x) xh[cell * xh_cs + c] = r[cell * r_cs + c] * keep;
+  if (threadIdx.x == 0) {
+    xh[cell * xh_cs + r_c] = bm;
+    probe[cell * 2] = d32;
+    probe[cell * 2 + 1] = bm;
+  }
+}
+
+// clr_conv2 (1x1 16->16 + BN + LeakyReLU) and clr_conv3 (1x1 16->3), then
+// dif = gray(con_rgb) - gray(inputs)  (model.py:268-269,288).  wt: [16*16 w2 (k-major: w2[k*16+n])][16 b2][16*3 w3 (w3[k*3+n])][3 b3].
+__global__ void color_tail_kernel(const float* __restrict__ c1, const float* __restrict__ wt, const float* __restrict__ inputs,
+                                  float* __restrict__ con_rgb, float* __restrict__ dif, size_t npix) {
+  __shared__ float sw[16 * 16 + 16 + 48 + 3];
+  for (int i = threadIdx.x; i < 16 * 16 + 16 + 48 + 3; i += blockDim.x) sw[i] = wt[i];
+  __syncthreads();
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  float x[16];
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(c1 + pix * 16 + k4 * 4);
+    x[k4 * 4 + 0] = v[0];
+    x[k4 * 4 + 1] = v[1];
+    x[k4 * 4 + 2] = v[2];
+    x[k4 * 4 + 3] = v[3];
+  }
+  float y[16];
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a = fmaf(x[k], sw[k * 16 + n], a);
+    a += sw[256 + n];
+    y[n] = a >= 0.f ? a : a * kLeakyAlpha;
+  }
+  float o[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a = fmaf(y[k], sw[272 + k * 3 + n], a);
+    o[n] = a + sw[272 + 48 + n];
+    con_rgb[pix * 3 + n] = o[n];
+  }
+  dif[pix] = gray3(o[0], o[1], o[2]) - gray3(inputs[pix * 3], inputs[pix * 3 + 1], inputs[pix * 3 + 2]);
+}
+
+// dense copy of a channel slice of an NHWC buffer (debug probes only)
+__global__ void slice_copy_kernel(const float* __restrict__ src, int cs, int coff, int c, float* __restrict__ dst, size_t npix) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= npix * c) return;
+  const size_t pix = gid / c;
+  const int ch = (int)(gid % c);
+  dst[gid] = src[pix * cs + coff + ch];
+}
+
+}  // namespace bsr

@@ -1,0 +1,135 @@
+"""Drop-in counterpart of the reference's ``Generator`` (/root/reference/model.py:198-290) for
+inference on MI355X: same constructor, same call signature and return order, NHWC float32 tensors —
+backed by libbsr_hip (hand-written gfx950 kernels) through the C ABI of include/bsr_hip.h.
+
+    gen = Generator()
+    gen.load_weights(weights)                    # dict: reference checkpoint names -> numpy arrays
+    gs, con_rgb, mask22, dif = gen(inputs, uv, reg, chuck=1, training=False)
+
+``reg`` and ``chuck`` are accepted and unused, exactly as in the reference's GSC forward
+(``ShareLayer`` is constructed but never called there: model.py:221 vs :228-290).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .pack import pack_generator
+from .tf_bundle import latest_checkpoint, load_generator_weights
+
+
+class Generator:
+    def __init__(self, downsize: int = 1, n_res: int = 6, device: Optional[int] = None):
+        if n_res != 6:
+            raise ValueError("the GSC generator has n_res=6 (/root/reference/model.py:199)")
+        self.n_res = n_res
+        self.n_ch = [32, 64, 64, 96, 128, 256, 256]
+        self._device = device
+        self._handle: Optional[ctypes.c_void_p] = None
+        self._lib = None
+        self._shape: Optional[Tuple[int, int, int]] = None
+
+    # -- weights ----------------------------------------------------------------------------
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> "Generator":
+        """``weights``: the reference's ``generator/...`` variables by checkpoint name
+        (``conv1/conv/kernel`` HWIO, ConvT kernels ``[kh,kw,out,in]``, BN gamma/beta/moving_*)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("blindshadowremoval_amd.Generator needs a ROCm GPU: there is no CPU path")
+        lib = _lib.load()
+        dev = torch.cuda.current_device() if self._device is None else int(self._device)
+        blob = pack_generator(weights)
+        handle = ctypes.c_void_p()
+        buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
+        _lib.check(lib.bsr_create(ctypes.byref(handle), dev, ctypes.cast(buf, ctypes.c_void_p), len(blob), 0), "bsr_create")
+        self.close()
+        self._lib, self._handle, self._device = lib, handle, dev
+        return self
+
+    def restore(self, checkpoint_dir: str) -> int:
+        """Counterpart of ``tf.train.latest_checkpoint`` + ``checkpoint.restore(...).expect_partial()``
+        (/root/reference/train_test_GSC.py:362-367).  Returns the epoch parsed from the file name, 0 if none."""
+        prefix = latest_checkpoint(checkpoint_dir)
+        if not prefix:
+            return 0
+        self.load_weights(load_generator_weights(prefix))
+        return int(prefix.split("-")[-1])
+
+    def close(self) -> None:
+        if self._handle is not None and self._lib is not None:
+            self._lib.bsr_destroy(self._handle)
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- forward ----------------------------------------------------------------------------
+    def _check_input(self, t: torch.Tensor, name: str, dev: int) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        if t.dim() != 4 or t.shape[-1] != 3:
+            raise ValueError("%s must be [B,H,W,3] NHWC, got %s" % (name, tuple(t.shape)))
+        if t.dtype != torch.float32:
+            raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+        if t.device.type != "cuda" or t.device.index != dev:
+            t = t.to("cuda:%d" % dev)
+        return t.contiguous()
+
+    def __call__(self, inputs, uv, reg=None, chuck: int = 1, training: bool = False,
+                 out: Optional[Tuple[torch.Tensor, ...]] = None):
+        if training:
+            raise NotImplementedError("only the inference path (training=False) is implemented "
+                                      "(/root/reference/train_test_GSC.py:404,856)")
+        if self._handle is None:
+            raise RuntimeError("Generator has no weights: call load_weights() or restore() first")
+        dev = self._device
+        inputs = self._check_input(inputs, "inputs", dev)
+        uv = self._check_input(uv, "uv", dev)
+        if uv.shape != inputs.shape:
+            raise ValueError("inputs %s and uv %s must have the same shape" % (tuple(inputs.shape), tuple(uv.shape)))
+        B, H, W, _ = inputs.shape
+        if H % 32 or W % 256:
+            raise ValueError("H must be a multiple of 32 and W of 256 (reference IMG_SIZE = 256), got %dx%d" % (H, W))
+        with torch.cuda.device(dev):
+            if out is None:
+                gs = torch.empty((B, H, W, 1), dtype=torch.float32, device=inputs.device)
+                con_rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=inputs.device)
+                mask22 = torch.empty((B, H, W, 3), dtype=torch.float32, device=inputs.device)
+                dif = torch.empty((B, H, W, 1), dtype=torch.float32, device=inputs.device)
+            else:
+                gs, con_rgb, mask22, dif = out
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = self._lib.bsr_forward(self._handle, inputs.data_ptr(), uv.data_ptr(), B, H, W, gs.data_ptr(), con_rgb.data_ptr(),
+                                       mask22.data_ptr(), dif.data_ptr(), stream)
+        _lib.check(rc, "bsr_forward")
+        self._shape = (B, H, W)
+        return gs, con_rgb, mask22, dif
+
+    # -- test / measurement hooks -----------------------------------------------------------
+    def probe(self, name: str) -> torch.Tensor:
+        """Intermediate of the last forward as a dense NHWC tensor (see bsr_probe in include/bsr_hip.h)."""
+        if self._shape is None:
+            raise RuntimeError("probe() needs a forward first")
+        B, H, W = self._shape
+        shape = (ctypes.c_int * 4)()
+        with torch.cuda.device(self._device):
+            stream = torch.cuda.current_stream().cuda_stream
+            dst = torch.empty(B * H * W * 64, dtype=torch.float32, device="cuda:%d" % self._device)   # largest probe: 64 ch at full res
+            _lib.check(self._lib.bsr_probe(self._handle, name.encode(), dst.data_ptr(), dst.numel(), ctypes.byref(shape), stream), "bsr_probe")
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        return dst[:n].reshape(shape[0], shape[1], shape[2], shape[3]).clone()
+
+    def set_timing(self, enable: bool) -> None:
+        _lib.check(self._lib.bsr_set_timing(self._handle, 1 if enable else 0), "bsr_set_timing")
+
+    def get_timing(self) -> Dict[str, Tuple[float, int]]:
+        ms = (ctypes.c_float * _lib.NUM_CLASSES)()
+        n = (ctypes.c_int * _lib.NUM_CLASSES)()
+        _lib.check(self._lib.bsr_get_timing(self._handle, ctypes.byref(ms), ctypes.byref(n)), "bsr_get_timing")
+        return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.CLASS_NAMES)}

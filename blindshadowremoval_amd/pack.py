@@ -1,0 +1,141 @@
+"""Offline weight preparation for libbsr_hip: BatchNorm folding + MFMA-friendly packing.
+
+Input: the reference's generator variables by their checkpoint names (HWIO ``Conv2D`` kernels,
+``[kh,kw,Cout,Cin]`` ``Conv2DTranspose`` kernels, BatchNormalization gamma/beta/moving stats —
+/root/reference/model.py:115-177, 81-113, 6-61; names per blindshadowremoval_amd/weights.py).
+
+Output: one blob (bytes) that ``bsr_create`` uploads as is.  Per MFMA conv layer the weights become
+``[chunk][tap][n_pad][CC+4]`` float32 — the exact LDS image the kernel stages per (chunk, tap) step,
+including the 4-float bank pad — and a ``[n_pad]`` bias.  Every BatchNormalization on the path
+follows a conv and runs with ``training=False`` (/root/reference/train_test_GSC.py:404,856), so it
+folds exactly:  s = gamma * rsqrt(var + 1e-3);  W' = W * s;  b' = (b - mean) * s + beta.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .weights import BN_EPS, N_RES, check_weights
+
+BLOB_MAGIC = 0x57525342   # "BSRW"
+BLOB_VERSION = 1
+_ENTRY = struct.Struct("<40sQQ4i")
+_HEADER = struct.Struct("<4I")
+
+TRANSPOSED = ("up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3")
+
+# name -> (CC, k_pad, n_pad): must match the launch table in csrc/bsr_api.hip
+GEOMETRY: Dict[str, Tuple[int, int, int]] = {
+    "conv1": (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),
+    "up1": (24, 264, 96), "up2": (32, 160, 64), "up3": (32, 128, 64), "heads": (32, 64, 32),
+    "clr_up1": (24, 264, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (24, 72, 32),
+}
+for _i in range(N_RES):
+    _cin_pad = 120 if _i == 0 else 264
+    GEOMETRY["res%d.conv1" % _i] = (24, _cin_pad, 128)
+    GEOMETRY["res%d.conv2" % _i] = (32, 128, 128)
+    GEOMETRY["res%d.conv3" % _i] = (32, 128, 288)
+    GEOMETRY["res%d.qkv" % _i] = (24, 264, 384)
+    GEOMETRY["res%d.w" % _i] = (32, 128, 288)
+
+
+def fold_bn(kernel_tkn: np.ndarray, bias: np.ndarray, bn: Dict[str, np.ndarray] | None):
+    """kernel_tkn: [taps, K, N] float64.  Returns folded (kernel, bias) in float64."""
+    k = kernel_tkn.astype(np.float64)
+    b = bias.astype(np.float64)
+    if bn is None:
+        return k, b
+    s = bn["gamma"].astype(np.float64) / np.sqrt(bn["moving_variance"].astype(np.float64) + BN_EPS)
+    return k * s[None, None, :], (b - bn["moving_mean"].astype(np.float64)) * s + bn["beta"].astype(np.float64)
+
+
+def _bn(w: Dict[str, np.ndarray], stem: str) -> Dict[str, np.ndarray]:
+    return {p: w[stem + "/" + p] for p in ("gamma", "beta", "moving_mean", "moving_variance")}
+
+
+def pack_taps(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int, n_pad: int):
+    """[taps, K, N] -> ([k_pad/cc, taps, n_pad, cc+4] float32, [n_pad] float32), zero padded."""
+    taps, k, n = kernel_tkn.shape
+    assert k <= k_pad and n <= n_pad and k_pad % cc == 0
+    full = np.zeros((taps, k_pad, n_pad), np.float64)
+    full[:, :k, :n] = kernel_tkn
+    arr = np.zeros((k_pad // cc, taps, n_pad, cc + 4), np.float32)
+    arr[..., :cc] = full.reshape(taps, k_pad // cc, cc, n_pad).transpose(1, 0, 3, 2)
+    b = np.zeros(n_pad, np.float32)
+    b[:n] = bias
+    return arr, b
+
+
+def layer_matrices(w: Dict[str, np.ndarray]) -> "Dict[str, Tuple[np.ndarray, np.ndarray]]":
+    """Folded [taps, K, N] kernels + biases (float64) of every MFMA layer, in kernel K/N order."""
+    out: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
+
+    def hwio(stem):            # Conv2D kernel [kh,kw,ci,co] -> [kh*kw, ci, co]
+        k = w[stem + "/kernel"]
+        return k.reshape(k.shape[0] * k.shape[1], k.shape[2], k.shape[3])
+
+    # stem 7x7x3: taps = ky, K = kx*3 + c   (im2row7_kernel layout)
+    k = w["conv1/conv/kernel"]                                    # [7,7,3,32]
+    out["conv1"] = fold_bn(k.reshape(7, 21, 32), w["conv1/conv/bias"], _bn(w, "conv1/bnorm"))
+    for nm in ("down1", "down2", "down3"):
+        out[nm] = fold_bn(hwio(nm + "/conv"), w[nm + "/conv/bias"], _bn(w, nm + "/bnorm"))
+    for nm in TRANSPOSED:                                         # [3,3,co,ci] -> [9, ci, co]
+        k = w[nm + "/conv/kernel"]
+        out[nm] = fold_bn(k.reshape(9, k.shape[2], k.shape[3]).transpose(0, 2, 1), w[nm + "/conv/bias"], _bn(w, nm + "/bnorm"))
+    # heads: taps = ky, K = c, N = kx*2 + head (head 0 = conv2/mask, 1 = conv3/con); bias applied in heads_post
+    k2, k3 = w["conv2/conv/kernel"][..., 0], w["conv3/conv/kernel"][..., 0]      # [7,7,64]
+    hk = np.stack([k2, k3], axis=-1)                              # [ky,kx,c,head]
+    out["heads"] = (hk.transpose(0, 2, 1, 3).reshape(7, 64, 14).astype(np.float64), np.zeros(14))
+    # clr_conv1: reference input cat[gs, f] (model.py:267); our buffer is [f(64), gs] -> rotate K
+    k = hwio("clr_conv1/conv")                                    # [9,65,16]
+    k = np.concatenate([k[:, 1:, :], k[:, :1, :]], axis=1)
+    out["clr_conv1"] = fold_bn(k, w["clr_conv1/conv/bias"], _bn(w, "clr_conv1/bnorm"))
+    for i in range(N_RES):
+        st = "res_stack/%d/" % i
+        out["res%d.conv1" % i] = fold_bn(hwio(st + "conv1"), w[st + "conv1/bias"], _bn(w, st + "bnorm1"))
+        out["res%d.conv2" % i] = fold_bn(hwio(st + "conv2"), w[st + "conv2/bias"], _bn(w, st + "bnorm2"))
+        out["res%d.conv3" % i] = fold_bn(hwio(st + "conv3"), w[st + "conv3/bias"], _bn(w, st + "bnorm3"))
+        # theta | phi | g share their input: one GEMM with N = 3 x 128 (query, key, value order of the attention kernel)
+        qkv = np.concatenate([hwio(st + "non_local/" + n) for n in ("theta", "phi", "g")], axis=2)
+        qb = np.concatenate([w[st + "non_local/%s/bias" % n] for n in ("theta", "phi", "g")])
+        out["res%d.qkv" % i] = (qkv.astype(np.float64), qb.astype(np.float64))
+        out["res%d.w" % i] = fold_bn(hwio(st + "non_local/w"), w[st + "non_local/w/bias"], _bn(w, st + "non_local/bnorm"))
+    return out
+
+
+def tail_weights(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """clr_conv2 (folded, k-major [16][16]) | bias[16] | clr_conv3 [16][3] | bias[3] for color_tail_kernel."""
+    k2, b2 = fold_bn(w["clr_conv2/conv/kernel"].reshape(1, 16, 16), w["clr_conv2/conv/bias"], _bn(w, "clr_conv2/bnorm"))
+    k3 = w["clr_conv3/conv/kernel"].reshape(16, 3).astype(np.float64)
+    return np.concatenate([k2.reshape(-1), b2, k3.reshape(-1), w["clr_conv3/conv/bias"].astype(np.float64)]).astype(np.float32)
+
+
+def pack_generator(weights: Dict[str, np.ndarray]) -> bytes:
+    """reference-named variables -> blob for ``bsr_create``."""
+    check_weights(weights)
+    entries: List[Tuple[str, np.ndarray, Tuple[int, int, int, int]]] = []
+    for name, (k, b) in layer_matrices(weights).items():
+        cc, k_pad, n_pad = GEOMETRY[name]
+        arr, bias = pack_taps(k, b, cc, k_pad, n_pad)
+        entries.append((name + ".w", arr, tuple(arr.shape)))
+        entries.append((name + ".b", bias, (n_pad, 0, 0, 0)))
+    entries.append(("heads.bias", np.array([weights["conv2/conv/bias"][0], weights["conv3/conv/bias"][0]], np.float32), (2, 0, 0, 0)))
+    entries.append(("tail.w", tail_weights(weights), (323, 0, 0, 0)))
+
+    off = _HEADER.size + _ENTRY.size * len(entries)
+    off = (off + 255) & ~255
+    table = bytearray()
+    chunks = []
+    for name, arr, dims in entries:
+        raw = np.ascontiguousarray(arr, dtype="<f4").tobytes()
+        table += _ENTRY.pack(name.encode(), off, arr.size, *dims)
+        chunks.append((off, raw))
+        off = (off + len(raw) + 255) & ~255
+    blob = bytearray(off)
+    blob[:_HEADER.size] = _HEADER.pack(BLOB_MAGIC, BLOB_VERSION, len(entries), 0)
+    blob[_HEADER.size:_HEADER.size + len(table)] = table
+    for o, raw in chunks:
+        blob[o:o + len(raw)] = raw
+    return bytes(blob)

@@ -1,0 +1,78 @@
+/* libbsr_hip — C ABI of the MI355X-native GSC generator forward pass.
+ *
+ * The reference has no FFI / plugin boundary: the hot path is entered through a Python call on a
+ * tf.keras.Model,
+ *     deshadow_img_gs, deshadow_img_c, _, mask_pred = self.gen(img, uv, reg, chuck=1, training=False)
+ * (/root/reference/train_test_GSC.py:422, :871; Generator.call at /root/reference/model.py:228-290).
+ * This header is what a binding for that call site binds instead (INTEGRATION.md shows the ctypes stub):
+ * plain pointers and sizes, no framework types.  All tensor pointers are DEVICE pointers owned by the
+ * caller (NHWC float32, dense); the library owns only its packed weights and its activation workspace.
+ *
+ * Threading: a handle is bound to one device and is not re-entrant; bsr_forward is asynchronous on the
+ * given hipStream_t and the caller synchronises.  Multi-GPU = one handle per device (one process per GPU).
+ * Every function returns 0 on success or a non-zero code; bsr_last_error() describes the last failure
+ * of the calling thread.
+ */
+#ifndef BSR_HIP_H_
+#define BSR_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bsr_handle bsr_handle;
+
+#define BSR_OK 0
+#define BSR_ERR_ARG 1      /* bad argument / shape */
+#define BSR_ERR_BLOB 2     /* malformed or mismatching packed-weight blob */
+#define BSR_ERR_HIP 3      /* a HIP runtime call failed */
+#define BSR_ERR_STATE 4    /* probe requested before any forward, unknown probe name, ... */
+
+#define BSR_DTYPE_F32 0
+
+/* Replaces Generator() construction + tf.train.Checkpoint(generator=...).restore(...)
+ * (/root/reference/train_test_GSC.py:120, :143-148, :365, :845).
+ * packed_weights: HOST pointer to the blob written by blindshadowremoval_amd.pack.pack_generator()
+ * (BatchNorm folded, MFMA-friendly layout); it is copied to the device, the caller may free it.
+ * dtype: BSR_DTYPE_F32 (the arithmetic type of the path). */
+int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t nbytes, int dtype);
+
+/* Replaces Generator.call(inputs, uv, reg, chuck, training=False) (/root/reference/model.py:228-290).
+ * inputs, uv : [B,H,W,3] float32 device pointers (reg / chuck are unused by the reference's GSC forward).
+ * gs [B,H,W,1], con_rgb [B,H,W,3], mask22 [B,H,W,3], dif [B,H,W,1] : caller-allocated outputs, in the order
+ * of the reference's return statement (model.py:290).  H % 32 == 0 and W % 256 == 0 (reference: 256 x 256).
+ * stream: a hipStream_t (NULL = default stream). */
+int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W,
+                float* gs, float* con_rgb, float* mask22, float* dif, void* stream);
+
+/* Bytes of activation workspace the library holds for a batch of B HxW images (grown lazily by
+ * bsr_forward; growth synchronises the stream — call bsr_reserve first to keep forwards allocation-free). */
+size_t bsr_workspace_bytes(int B, int H, int W);
+int bsr_reserve(bsr_handle* h, int B, int H, int W);
+
+/* Test hook: copy a named intermediate of the LAST forward (dense NHWC, real channel count) into dst
+ * (device pointer, capacity cap_floats).  shape4 receives [B,H,W,C].  Names: x1 x2 x3 x0 res0..res5 up1 up2
+ * y d32 bmask xh f1 f2 f c1 att<i> y3_<i>. */
+int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream);
+
+/* Per-kernel-class device time (ms) of the last forward run with timing enabled; classes are indexed
+ * 0: conv3x3 (+stride-2), 1: transposed 3x3, 2: conv1x1, 3: attention, 4: conv7 (stem + heads), 5: glue.
+ * bsr_set_timing(h, 1) makes every following forward record HIP events around each launch on the
+ * forward's stream (adds host overhead; off by default). */
+#define BSR_NUM_CLASSES 6
+int bsr_set_timing(bsr_handle* h, int enable);
+int bsr_get_timing(bsr_handle* h, float ms_per_class[BSR_NUM_CLASSES], int launches_per_class[BSR_NUM_CLASSES]);
+
+void bsr_destroy(bsr_handle* h);
+
+const char* bsr_last_error(void);
+
+/* ABI version of this header (bumped on any signature change). */
+int bsr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSR_HIP_H_ */
