@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the GSC generator batched forward at 256x256 on N MI355X (BASELINE.json).
+
+A step = one forward of the hot path over one synthetic batch of 32 images per GPU (BASELINE config 2:
+"Batch=32 synthetic 256x256x3, full GSC generator fp32"), inputs already resident in HBM.  For N > 1 the
+batch shards one-process-per-GPU (weak scaling: 32 images per rank) and each step ends with the RCCL
+all-gather that re-assembles the consumed outputs (con_rgb + dif) on every rank, overlapped with the next
+step's compute.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE = 18.104        # 9 052.06 MMAC per 256x256 image
+GFLOP_3X3_PER_IMAGE = 11.017    # 3x3 conv + transposed 3x3 ("3x3-conv path")
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
+
+
+def cpu_baseline(weights, seconds_budget=20.0):
+    """Oracle (torch-CPU restatement of the reference's TF graph; TF itself is not installable here) timed on
+    the host cores of this box, bounded sample of the same synthetic workload."""
+    import torch
+    from oracle.gsc_oracle import GeneratorOracle
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores // 2 if cores > 16 else cores, 128))      # physical cores on a 2-thread/core host
+    torch.set_num_threads(threads)
+    oracle = GeneratorOracle(weights)
+    torch.manual_seed(0)
+    b = 8
+    inp, uv = torch.rand(b, 256, 256, 3), torch.rand(b, 256, 256, 3)
+    oracle(inp[:2], uv[:2])                      # warm-up (oneDNN primitive creation)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
+        t0 = time.perf_counter()
+        oracle(inp, uv)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(b / med, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d forwards of %d synthetic 256x256 images, median (oracle-CPU torch/oneDNN fp32, proxy for the TF2-CPU path)" % (len(times), b)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the output all-gather (N>1)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from blindshadowremoval_amd import Generator, init_weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    weights = init_weights(1)
+    gen = Generator(device=local_rank).load_weights(weights)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    inp = torch.rand(B, 256, 256, 3, generator=g).to(dev)       # synthetic, resident in HBM before timing
+    uv = torch.rand(B, 256, 256, 3, generator=g).to(dev)
+    outs = [tuple(torch.empty((B, 256, 256, c), device=dev) for c in (1, 3, 3, 1)) for _ in range(2)]
+    packed = [torch.empty((B, 256, 256, 4), device=dev) for _ in range(2)]          # con_rgb | dif: what callers consume
+    gathered = [torch.empty((world * B, 256, 256, 4), device=dev) for _ in range(2)] if distributed else None
+    pending = [None, None]
+
+    def step(i):
+        slot = i & 1
+        if pending[slot] is not None:           # buffers of step i-2 are free once its gather completed
+            pending[slot].wait()
+            pending[slot] = None
+        o = gen(inp, uv, out=outs[slot])
+        if distributed and not args.no_gather:
+            torch.cat((o[1], o[3]), dim=3, out=packed[slot])
+            pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
+
+    def drain():
+        for s in (0, 1):
+            if pending[s] is not None:
+                pending[s].wait()
+                pending[s] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        # roofline of the dominant kernel (igemm_conv_kernel on the 3x3 / transposed-3x3 layers): HIP events around
+        # every launch of a few extra forwards on the same stream (event overhead stays out of `value`)
+        gen.set_timing(True)
+        acc, n_rep = {}, 3
+        for _ in range(n_rep):
+            gen(inp, uv, out=outs[0])
+            torch.cuda.synchronize()
+            for k, (ms, n) in gen.get_timing().items():
+                a = acc.setdefault(k, [0.0, 0])
+                a[0] += ms / n_rep
+                a[1] = n
+        gen.set_timing(False)
+        t33 = (acc["conv3x3"][0] + acc["convT3x3"][0]) * 1e-3
+        n33 = acc["conv3x3"][1] + acc["convT3x3"][1]
+        achieved = GFLOP_3X3_PER_IMAGE * B / t33 / 1e3            # TFLOP/s
+        t_all = sum(v[0] for v in acc.values()) * 1e-3
+        result = {
+            "metric": "images/sec at 256x256 batch inference (GSC generator forward)",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=32 synthetic 256x256x3 per GPU, full GSC generator fp32 "
+                                   "(seeded random-init weights in the ckpt-94 variable layout)",
+                       "images_per_gpu_per_step": B, "global_batch": world * B, "height": 256, "width": 256,
+                       "parallelism": "dp%d" % world,
+                       "collective": ("all_gather(con_rgb|dif) per step, async" if distributed and not args.no_gather else "none")},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "igemm_conv_kernel (3x3 + stride-2 3x3 + transposed 3x3 layers)",
+                         "launches_per_forward": n33, "avg_launch_ms": round(t33 * 1e3 / n33, 4),
+                         "algorithmic_gflop_per_forward": round(GFLOP_3X3_PER_IMAGE * B, 2),
+                         "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all / 1e3, 2),
+                         "class_ms": {k: round(v[0], 4) for k, v in acc.items()}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(weights)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

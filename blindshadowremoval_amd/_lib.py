@@ -16,7 +16,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_destroy", "bsr_last_error", "bsr_abi_version")
+           "bsr_get_timing", "bsr_debug_attention", "bsr_destroy", "bsr_last_error", "bsr_abi_version")
 
 
 def load() -> ctypes.CDLL:
@@ -49,6 +49,8 @@ def load() -> ctypes.CDLL:
     lib.bsr_set_timing.restype = c_i
     lib.bsr_get_timing.argtypes = [c_v, ctypes.POINTER(ctypes.c_float * NUM_CLASSES), ctypes.POINTER(c_i * NUM_CLASSES)]
     lib.bsr_get_timing.restype = c_i
+    lib.bsr_debug_attention.argtypes = [c_v, c_v, c_i, c_i, c_v]
+    lib.bsr_debug_attention.restype = c_i
     lib.bsr_destroy.argtypes = [c_v]
     lib.bsr_destroy.restype = None
     if lib.bsr_abi_version() != ABI_VERSION:

@@ -148,7 +148,7 @@ struct Launcher {
     hipEventRecord(h->ev[h->ev_used], s);
   }
   void end() {
-    if (!h->timing) return;
+    if (!h->timing || h->ev_used + 2 > h->ev.size()) return;
     hipEventRecord(h->ev[h->ev_used + 1], s);
     h->ev_used += 2;
   }
@@ -423,6 +423,13 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   }
   if (L.rc == BSR_OK) h->ran = true;
   return L.rc;
+}
+
+int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream) {
+  if (qkv == nullptr || y == nullptr) return fail(BSR_ERR_ARG, "bsr_debug_attention: null argument");
+  if (B <= 0 || tokens <= 0 || tokens % 128 != 0) return fail(BSR_ERR_ARG, "bsr_debug_attention: tokens must be a positive multiple of 128");
+  HIP_TRY(bsr::launch_nonlocal_attention(qkv, y, B, tokens, static_cast<hipStream_t>(stream)));
+  return BSR_OK;
 }
 
 int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream) {

@@ -65,6 +65,10 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
 int bsr_set_timing(bsr_handle* h, int enable);
 int bsr_get_timing(bsr_handle* h, float ms_per_class[BSR_NUM_CLASSES], int launches_per_class[BSR_NUM_CLASSES]);
 
+/* Test hook: the fused NonLocalBlock attention kernel alone (/root/reference/model.py:51-53).
+ * qkv [B,tokens,384] (theta | phi | g, 128 channels each) -> y [B,tokens,128]; tokens % 128 == 0. */
+int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream);
+
 void bsr_destroy(bsr_handle* h);
 
 const char* bsr_last_error(void);

@@ -1,0 +1,156 @@
+"""-m gpu parity tests: the HIP path, called through the C ABI (ctypes -> libbsr_hip.so), against the CPU
+oracle on the same seeded inputs.  Tolerance: 1e-3 absolute per pixel in fp32 (BASELINE.json north_star);
+measured agreement is ~1e-5."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from blindshadowremoval_amd.weights import init_weights
+
+pytestmark = pytest.mark.gpu
+
+PROBES = ("x1", "x2", "x3", "x0", "res0", "res1", "res2", "up1", "up2", "y", "res3", "res4", "res5", "f")
+
+
+@pytest.fixture(scope="module")
+def gen_w():
+    from blindshadowremoval_amd import Generator
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    w = init_weights(1)
+    return Generator().load_weights(w), w
+
+
+def test_library_is_the_in_tree_hip_extension():
+    from blindshadowremoval_amd import _lib
+    from blindshadowremoval_amd.build import LIB_PATH
+    lib = _lib.load()
+    assert lib._name == LIB_PATH and lib.bsr_abi_version() == 1
+
+
+@pytest.mark.parametrize("seed,B", [(0, 2), (7, 3)])
+def test_forward_matches_oracle_with_probes(gen_w, seed, B):
+    from parity_util import run_and_compare
+    gen, w = gen_w
+    torch.manual_seed(seed)
+    inp, uv = torch.rand(B, 256, 256, 3), torch.rand(B, 256, 256, 3)
+    uv[:, :, :30] = 0                      # real uv maps are ~60 % zeros outside the landmark hull
+    out, ref, errs, nflip = run_and_compare(gen, w, inp, uv, want_probes=PROBES)
+    assert max(errs.values()) <= 1e-3
+    assert out[0].shape == (B, 256, 256, 1) and out[1].shape == (B, 256, 256, 3)
+    assert out[2].shape == (B, 256, 256, 3) and out[3].shape == (B, 256, 256, 1)
+
+
+def test_other_weights_and_degenerate_masks(gen_w):
+    """bmask all-zero (no bias shift) and all-one (large shift): both branches of x*(1-bmask)."""
+    from blindshadowremoval_amd import Generator
+    from parity_util import run_and_compare
+    torch.manual_seed(11)
+    inp, uv = torch.rand(1, 256, 256, 3), torch.rand(1, 256, 256, 3)
+    for shift, want_mean in ((-1.0, 0.0), (2.0, 1.0)):
+        w = init_weights(4, con_bias_shift=shift)
+        gen = Generator().load_weights(w)
+        run_and_compare(gen, w, inp, uv)
+        assert float(gen.probe("bmask").mean()) == want_mean
+
+
+def test_rows_are_independent_and_deterministic(gen_w):
+    """no cross-sample op in GSC inference, so an image's outputs do not depend on what
+    else is in the batch — bit for bit — and repeated runs are bit-identical."""
+    gen, _ = gen_w
+    torch.manual_seed(5)
+    inp, uv = torch.rand(4, 256, 256, 3).cuda(), torch.rand(4, 256, 256, 3).cuda()
+    full = [t.clone() for t in gen(inp, uv)]
+    again = gen(inp, uv)
+    for a, b in zip(full, again):
+        assert torch.equal(a, b)
+    solo = gen(inp[2:3].contiguous(), uv[2:3].contiguous())
+    for a, b in zip(full, solo):
+        assert torch.equal(a[2:3], b)
+    # the reference feeds 10 copies/siblings and keeps row 0 (train_test_GSC.py:866-871, utils.py:231)
+    ten = gen(inp[:1].repeat(10, 1, 1, 1), uv[:1].repeat(10, 1, 1, 1))
+    for a, b in zip(full, ten):
+        assert torch.equal(a[0], b[0]) and torch.equal(b[0], b[9])
+
+
+def test_full_batch_properties(gen_w):
+    """BASELINE config 2 size (B=32): size-independent properties of the four outputs."""
+    gen, _ = gen_w
+    torch.manual_seed(6)
+    inp, uv = torch.rand(32, 256, 256, 3).cuda(), torch.rand(32, 256, 256, 3).cuda()
+    gs, con_rgb, mask22, dif = gen(inp, uv)
+    assert torch.isfinite(gs).all() and torch.isfinite(con_rgb).all()
+    assert float(mask22[..., 1].abs().max()) == 0.0                      # mask*0 (model.py:252)
+    assert float((mask22[..., 0] * mask22[..., 2]).abs().max()) == 0.0   # relu(m) * relu(-m) == 0
+    assert float(mask22.min()) >= 0.0 and float(mask22.max()) < 1.0      # tanh range
+    gw = torch.tensor([0.2989, 0.5870, 0.1140], device="cuda")
+    recomputed = (con_rgb * gw).sum(-1, keepdim=True) - (inp * gw).sum(-1, keepdim=True)   # model.py:288
+    assert float((dif - recomputed).abs().max()) < 1e-5
+    bm = gen.probe("bmask")
+    xh, r2 = gen.probe("xh"), gen.probe("res2")
+    assert set(bm.unique().tolist()) <= {0.0, 1.0}
+    assert torch.equal(xh[..., :257], r2 * (1 - bm)) and torch.equal(xh[..., 257:258], bm)   # model.py:258-259
+    # spot-check 2 of the 32 rows against the oracle
+    from oracle.gsc_oracle import GeneratorOracle
+    idx = [3, 29]
+    ref = GeneratorOracle(gen_w[1])(inp[idx].cpu(), uv[idx].cpu(), bmask_override=bm[idx].cpu())
+    for a, b in zip((gs, con_rgb, mask22, dif), ref):
+        assert float((a[idx].cpu() - b).abs().max()) <= 1e-3
+
+
+def test_attention_kernel_forced_rescale():
+    """Online-softmax rescale branch (cdna guide rule 26): spike late keys so the running max jumps in the
+    last tiles; compare with an fp64 softmax on the full tensor."""
+    from blindshadowremoval_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(2)
+    B, T, D = 2, 1024, 128
+    qkv = torch.randn(B, T, 3 * D) * 0.5
+    qkv[:, 1000, D:2 * D] = qkv[:, 17, :D] * 6.0        # key 1000 aligned with query 17: large late logit
+    qkv[:, 500:520, D:2 * D] *= 8.0                      # a mid-sequence burst of big keys
+    qkv[0, 3, :D] = 0.0                                  # a query with all-zero logits (uniform softmax)
+    x = qkv.cuda()
+    y = torch.empty(B, T, D, device="cuda")
+    _lib.check(lib.bsr_debug_attention(x.data_ptr(), y.data_ptr(), B, T, None), "bsr_debug_attention")
+    torch.cuda.synchronize()
+    q, k, v = (t.double() for t in qkv.split(D, dim=2))
+    ref = torch.softmax(q @ k.transpose(1, 2), -1) @ v
+    assert float((q @ k.transpose(1, 2)).max()) > 50.0          # the test really exercises large logits
+    assert float((y.cpu().double() - ref).abs().max()) < 2e-5
+    rc = lib.bsr_debug_attention(x.data_ptr(), y.data_ptr(), B, 1000, None)
+    assert rc == 1 and b"multiple of 128" in lib.bsr_last_error()
+
+
+def test_argument_errors(gen_w):
+    from blindshadowremoval_amd import Generator
+    gen, w = gen_w
+    ok = torch.rand(1, 256, 256, 3)
+    with pytest.raises(ValueError):
+        gen(torch.rand(1, 256, 256, 4), ok)
+    with pytest.raises(ValueError):
+        gen(torch.rand(1, 250, 256, 3), torch.rand(1, 250, 256, 3))
+    with pytest.raises(ValueError):
+        gen(ok, torch.rand(2, 256, 256, 3))
+    with pytest.raises(TypeError):
+        gen(ok.double(), ok)
+    with pytest.raises(NotImplementedError):
+        gen(ok, ok, training=True)
+    with pytest.raises(RuntimeError, match="no weights"):
+        Generator()(ok, ok)
+    with pytest.raises(RuntimeError, match="unknown probe"):
+        gen(ok, ok); gen.probe("nope")
+    # C ABI level: bad H/W are rejected with BSR_ERR_ARG
+    t = ok.cuda()
+    o = torch.empty(1, 256, 256, 3, device="cuda")
+    rc = gen._lib.bsr_forward(gen._handle, t.data_ptr(), t.data_ptr(), 1, 100, 256, o.data_ptr(), o.data_ptr(), o.data_ptr(), o.data_ptr(), None)
+    assert rc == 1
+
+
+def test_wider_input_512(gen_w):
+    """The kernels are size-generic (BASELINE config 5 runs 512x512 frames): one 256x512 image vs oracle."""
+    from parity_util import run_and_compare
+    gen, w = gen_w
+    torch.manual_seed(8)
+    inp, uv = torch.rand(1, 256, 512, 3), torch.rand(1, 256, 512, 3)
+    run_and_compare(gen, w, inp, uv)

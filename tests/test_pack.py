@@ -1,0 +1,138 @@
+"""Host-side weight preparation: BN folding and the MFMA packing are checked on CPU by emulating, in
+numpy, exactly what the kernels compute from the packed arrays, against the oracle's unfolded
+conv + BatchNorm on the same inputs."""
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from blindshadowremoval_amd import pack
+from blindshadowremoval_amd.weights import init_weights
+from oracle import gsc_oracle as O
+
+
+@pytest.fixture(scope="module")
+def w():
+    return init_weights(5)
+
+
+def unpack(arr):
+    """[chunk][tap][n_pad][cc+4] -> dense [tap][k_pad][n_pad] (what the kernel multiplies by)."""
+    nch, taps, n_pad, ldp = arr.shape
+    assert np.all(arr[..., ldp - 4:] == 0)
+    return arr[..., :ldp - 4].transpose(1, 0, 3, 2).reshape(taps, nch * (ldp - 4), n_pad)
+
+
+def packed(w, name):
+    k, b = pack.layer_matrices(w)[name]
+    cc, k_pad, n_pad = pack.GEOMETRY[name]
+    arr, bias = pack.pack_taps(k, b, cc, k_pad, n_pad)
+    return unpack(arr), bias
+
+
+def bn_args(w, stem):
+    return [w[stem + "/" + p] for p in ("gamma", "beta", "moving_mean", "moving_variance")]
+
+
+def test_bn_fold_matches_conv_then_bn(w):
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((1, 8, 8, 32)).astype(np.float32))
+    ref = O.batchnorm_infer(O.conv2d_same(x, w["down1/conv/kernel"], w["down1/conv/bias"], 2), *bn_args(w, "down1/bnorm"))
+    k, bias = packed(w, "down1")                                     # [9, 32, 64]
+    got = O.conv2d_same(x, k[:, :32, :].reshape(3, 3, 32, 64), bias[:64], 2)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5)
+
+
+def test_stem_im2row_equivalence(w):
+    """conv1 7x7x3 == 7x1 conv over the 24-channel row-expanded input (im2row7_kernel + igemm 7x1)."""
+    rng = np.random.default_rng(1)
+    x = rng.random((1, 12, 16, 3)).astype(np.float32)
+    ref = O.GeneratorOracle(w).conv_block(torch.from_numpy(x), "conv1").numpy()
+    xr = np.zeros((1, 12, 16, 24), np.float32)
+    for kx in range(7):
+        for c in range(3):
+            sx = np.arange(16) + kx - 3
+            ok = (sx >= 0) & (sx < 16)
+            xr[0, :, ok, kx * 3 + c] = x[0, :, sx[ok], c]
+    k, bias = packed(w, "conv1")                                     # [7, 24, 32]
+    got = O.leaky_relu(O.conv2d_same(torch.from_numpy(xr), k.reshape(7, 1, 24, 32), bias, 1)).numpy()
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+
+
+def test_heads_decomposition(w):
+    """conv2/conv3 (7x7, 64->1 each) == 7x1 conv to N=(kx,head) followed by a 7-tap horizontal sum."""
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal((1, 10, 12, 64)).astype(np.float32)
+    g = O.GeneratorOracle(w)
+    ref_m = g.conv_block(torch.from_numpy(y), "conv2", bn=False, act=False).numpy()[0, ..., 0]
+    ref_c = g.conv_block(torch.from_numpy(y), "conv3", bn=False, act=False).numpy()[0, ..., 0]
+    k, bias = packed(w, "heads")                                     # [7, 64, 32]
+    assert np.all(bias == 0)
+    q = O.conv2d_same(torch.from_numpy(y), k.reshape(7, 1, 64, 32), bias, 1).numpy()
+    m = np.zeros((10, 12)); c = np.zeros((10, 12))
+    for kx in range(7):
+        for x in range(12):
+            sx = x + kx - 3
+            if 0 <= sx < 12:
+                m[:, x] += q[0, :, sx, kx * 2]
+                c[:, x] += q[0, :, sx, kx * 2 + 1]
+    np.testing.assert_allclose(m + w["conv2/conv/bias"][0], ref_m, atol=2e-5)
+    np.testing.assert_allclose(c + w["conv3/conv/bias"][0], ref_c, atol=2e-5)
+
+
+def test_transposed_phase_decomposition(w):
+    """ConvT(3, s2) == 4 output-parity phases; tap (a,b) feeds phase (a==1, b==1) from x[i-(a==2), j-(b==2)]."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 4, 5, 96)).astype(np.float32)
+    ref = O.GeneratorOracle(w).convt_block(torch.from_numpy(x), "clr_up3").numpy()
+    k, bias = packed(w, "clr_up3")                                   # [9, 96, 64]
+    out = np.zeros((1, 8, 10, 64))
+    xp = np.pad(x, ((0, 0), (1, 0), (1, 0), (0, 0)))
+    for a in range(3):
+        for b in range(3):
+            di, dj = (0 if a == 2 else 1), (0 if b == 2 else 1)
+            out[0, (a == 1)::2, (b == 1)::2] += xp[0, di:di + 4, dj:dj + 5] @ k[a * 3 + b, :96, :64]
+    got = O.leaky_relu(torch.from_numpy(out + bias[:64])).numpy()
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+
+
+def test_clr_conv1_channel_rotation_and_qkv_order(w):
+    rng = np.random.default_rng(4)
+    gs = rng.standard_normal((1, 6, 6, 1)).astype(np.float32)
+    f = rng.standard_normal((1, 6, 6, 64)).astype(np.float32)
+    ref = O.GeneratorOracle(w).conv_block(torch.from_numpy(np.concatenate([gs, f], -1)), "clr_conv1").numpy()
+    k, bias = packed(w, "clr_conv1")                                 # [9, 72, 32]
+    buf = np.concatenate([f, gs, np.zeros((1, 6, 6, 7), np.float32)], -1)
+    got = O.leaky_relu(O.conv2d_same(torch.from_numpy(buf), k.reshape(3, 3, 72, 32), bias, 1)).numpy()
+    np.testing.assert_allclose(got[..., :16], ref, atol=2e-5)
+    assert np.all(got[..., 16:] == 0)
+    k, bias = packed(w, "res2.qkv")
+    st = "res_stack/2/non_local/"
+    for j, n in enumerate(("theta", "phi", "g")):
+        np.testing.assert_array_equal(k[0, :257, 128 * j:128 * (j + 1)], w[st + n + "/kernel"][0, 0])
+        np.testing.assert_array_equal(bias[128 * j:128 * (j + 1)], w[st + n + "/bias"])
+    assert np.all(k[0, 257:] == 0)
+
+
+def test_blob_layout(w):
+    blob = pack.pack_generator(w)
+    magic, ver, n, _ = struct.unpack_from("<4I", blob, 0)
+    assert magic == pack.BLOB_MAGIC and ver == pack.BLOB_VERSION
+    names = {}
+    for i in range(n):
+        name, off, nfl, d0, d1, d2, d3 = struct.unpack_from("<40sQQ4i", blob, 16 + 72 * i)
+        name = name.rstrip(b"\0").decode()
+        assert off % 16 == 0 and off + 4 * nfl <= len(blob)
+        names[name] = (off, nfl, (d0, d1, d2, d3))
+    assert len(names) == n == 2 * len(pack.GEOMETRY) + 2
+    off, nfl, dims = names["res0.conv1.w"]
+    assert dims == (5, 1, 128, 28) and nfl == 5 * 128 * 28
+    off, nfl, dims = names["up1.w"]
+    assert dims == (11, 9, 96, 28)
+    hb = np.frombuffer(blob, "<f4", 2, names["heads.bias"][0])
+    assert hb[0] == w["conv2/conv/bias"][0] and hb[1] == w["conv3/conv/bias"][0]
+    with pytest.raises(ValueError):
+        bad = dict(w); bad.pop("up1/conv/kernel"); pack.pack_generator(bad)
+    with pytest.raises(ValueError):
+        bad = dict(w); bad["up1/conv/kernel"] = bad["up1/conv/kernel"].transpose(0, 1, 3, 2); pack.pack_generator(bad)
