@@ -114,28 +114,32 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[ph][mi][ni][i] = 0.f;
 
-  // global -> register fetch of one input-tile chunk (zero outside the image: TF SAME zero padding)
-  auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
+  // global -> register fetch of one input-tile chunk.  Loads are UNCONDITIONAL (clamped address) so hipcc
+  // keeps them in flight across the MFMAs; out-of-image pixels (TF SAME zero padding) are zeroed at store time
+  // from a per-thread validity bitmask.
+  auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD], unsigned& okmask) {
+    okmask = 0u;
 #pragma unroll
     for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-      const int idx = tid + i * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < C::IN_V4) {
-        const int pix = idx / (CC / 4), q = idx % (CC / 4);
-        const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-          v = *reinterpret_cast<const f32x4*>(in_img + ((size_t)iy * p.W + ix) * p.in_cs + ch * CC + q * 4);
-      }
-      regs[i] = v;
+      int idx = tid + i * 256;
+      idx = idx < C::IN_V4 ? idx : C::IN_V4 - 1;
+      const int pix = idx / (CC / 4), q = idx % (CC / 4);
+      const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+      regs[i] = *reinterpret_cast<const f32x4*>(in_img + ((size_t)iyc * p.W + ixc) * p.in_cs + ch * CC + q * 4);
+      okmask |= (ok ? 1u : 0u) << i;
     }
   };
-  auto store_in = [&](const f32x4 (&regs)[C::IN_PER_THREAD]) {
+  auto store_in = [&](const f32x4 (&regs)[C::IN_PER_THREAD], unsigned okmask) {
 #pragma unroll
     for (int i = 0; i < C::IN_PER_THREAD; ++i) {
       const int idx = tid + i * 256;
       if (idx < C::IN_V4) {
         const int pix = idx / (CC / 4), q = idx % (CC / 4);
-        *reinterpret_cast<f32x4*>(s_in + pix * LDP + q * 4) = regs[i];
+        f32x4 v = regs[i];
+        if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(s_in + pix * LDP + q * 4) = v;
       }
     }
   };
@@ -143,8 +147,9 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
     const float* src = p.w + ((size_t)step * p.n_pad + n0) * LDP;
 #pragma unroll
     for (int i = 0; i < C::W_PER_THREAD; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < C::W_V4) regs[i] = *reinterpret_cast<const f32x4*>(src + idx * 4);
+      int idx = tid + i * 256;
+      idx = idx < C::W_V4 ? idx : C::W_V4 - 1;
+      regs[i] = *reinterpret_cast<const f32x4*>(src + idx * 4);
     }
   };
   auto store_w = [&](int buf, const f32x4 (&regs)[C::W_PER_THREAD]) {
@@ -158,11 +163,12 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 
   f32x4 in_regs[C::IN_PER_THREAD];
   f32x4 w_regs[C::W_PER_THREAD];
+  unsigned in_ok = 0u;
 
   // prologue: chunk 0 input tile + tap 0 weights
-  fetch_in(0, in_regs);
+  fetch_in(0, in_regs, in_ok);
   fetch_w(0, w_regs);
-  store_in(in_regs);
+  store_in(in_regs, in_ok);
   store_w(0, w_regs);
   __syncthreads();
 
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
         fetch_w(ch * T + t + 1, w_regs);
       } else if (more) {
         fetch_w((ch + 1) * T, w_regs);
-        if (PF_IN) fetch_in(ch + 1, in_regs);
+        if (PF_IN) fetch_in(ch + 1, in_regs, in_ok);
       }
 
       // ---- MFMAs of tap t ----
@@ -191,20 +197,30 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
         ph = 0;
       }
       const float* wb = s_w + buf * C::W_FLOATS;
+      // software-pipelined fragments: group g+1's ds_read_b128s are issued before group g's MFMAs
+      f32x4 af[2][MI], bf[2][NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[0][mi] = *reinterpret_cast<const f32x4*>(s_in + a_base[mi] + tap_off);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *reinterpret_cast<const f32x4*>(wb + b_base[ni]);
 #pragma unroll
       for (int g = 0; g < CC / 8; ++g) {
-        f32x4 af[MI], bf[NI];
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g + 1 < CC / 8) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(s_in + a_base[mi] + tap_off + g * 8);
+          for (int mi = 0; mi < MI; ++mi) af[nxt][mi] = *reinterpret_cast<const f32x4*>(s_in + a_base[mi] + tap_off + (g + 1) * 8);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(wb + b_base[ni] + g * 8);
+          for (int ni = 0; ni < NI; ++ni) bf[nxt][ni] = *reinterpret_cast<const f32x4*>(wb + b_base[ni] + (g + 1) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-              acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[ph][mi][ni], 0, 0, 0);
+              acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[ph][mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
 
       // ---- publish the prefetched data ----
@@ -213,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
         __syncthreads();
       } else if (more) {
         __syncthreads();                 // every wave is done reading s_in / both weight slots
-        if (!PF_IN) fetch_in(ch + 1, in_regs);
-        store_in(in_regs);
+        if (!PF_IN) fetch_in(ch + 1, in_regs, in_ok);
+        store_in(in_regs, in_ok);
         store_w(0, w_regs);
         __syncthreads();
       }
