@@ -157,12 +157,12 @@ struct Launcher {
   }
 
   // KH,KW,S,TR,TH,TW,WM,WN,MI,NI,CC,PF_IN
-  template <int KH, int KW, int S, bool TR, int NI, int CC, bool PF_IN>
+  template <int KH, int KW, int S, bool TR, int NI, int CC, int INB>
   void conv(int cls, const char* name, const float* in, int in_cs, int in_coff, int k_pad, int H, int W, float* out, int out_cs,
             int out_coff, int n_store, int act, const float* res1 = nullptr, int res1_cs = 0, int res1_c = 0,
             const float* res2 = nullptr, int res2_cs = 0, int res2_c = 0) {
     if (rc != BSR_OK) return;
-    using C = bsr::ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, PF_IN>;
+    using C = bsr::ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
     LayerW l;
     const int nb = (n_store + C::BN - 1) / C::BN;
     rc = find_layer(h, name, k_pad / CC, KH * KW, CC + 4, nb * C::BN, &l);
@@ -189,7 +189,7 @@ struct Launcher {
       return;
     }
     begin(cls);
-    check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, PF_IN>(a, h->B, s), name);
+    check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
     end();
   }
 };
@@ -352,11 +352,11 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   glue_begin();
   hipLaunchKernelGGL(bsr::im2row7_kernel, dim3((unsigned)((npix * 6 + 255) / 256)), dim3(256), 0, s, inputs, ws + p.xr, W, npix);
   glue_end("im2row7");
-  L.conv<7, 1, 1, false, 1, 24, true>(K_CONV7, "conv1", ws + p.xr, 24, 0, 24, H, W, ws + p.x1, 32, 0, 32, 1);
+  L.conv<7, 1, 1, false, 1, 24, 1>(K_CONV7, "conv1", ws + p.xr, 24, 0, 24, H, W, ws + p.x1, 32, 0, 32, 1);
   // down1..3 = Conv(stride 2) (model.py:207-209,231-233); x2 / x3 land in their skip-concat slots (model.py:244-245)
-  L.conv<3, 3, 2, false, 2, 16, false>(K_CONV3, "down1", ws + p.x1, 32, 0, 32, H, W, ws + p.c3, 128, 64, 64, 1);
-  L.conv<3, 3, 2, false, 2, 16, false>(K_CONV3, "down2", ws + p.c3, 128, 64, 64, H2, W2, ws + p.c2, 160, 96, 64, 1);
-  L.conv<3, 3, 2, false, 3, 16, false>(K_CONV3, "down3", ws + p.c2, 160, 96, 64, H4, W4, ws + p.xa, CS_XA, 0, 96, 1);
+  L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down1", ws + p.x1, 32, 0, 32, H, W, ws + p.c3, 128, 64, 64, 1);
+  L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down2", ws + p.c3, 128, 64, 64, H2, W2, ws + p.c2, 160, 96, 64, 1);
+  L.conv<3, 3, 2, false, 3, 16, 1>(K_CONV3, "down3", ws + p.c2, 160, 96, 64, H4, W4, ws + p.xa, CS_XA, 0, 96, 1);
   // uv = resize(uv, [h,w]); x = cat[x, uv] (model.py:237-238) and the uv slot of cat[x_hole, bmask, uv] (model.py:259)
   glue_begin();
   hipLaunchKernelGGL(bsr::uv_resize8_kernel, dim3((unsigned)((ncell * 3 + 255) / 256)), dim3(256), 0, s, uv, H, W, ws + p.xa, CS_XA, 96,
@@ -368,13 +368,13 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
     char nm[32];
     float* y3 = ws + p.y3[i];
     snprintf(nm, sizeof nm, "res%d.conv1", i);
-    L.conv<1, 1, 1, false, 2, 24, true>(K_CONV1, nm, x, x_cs, 0, x_cs, H8, W8, ws + p.t1, 128, 0, 128, 1);
+    L.conv<1, 1, 1, false, 2, 24, 3>(K_CONV1, nm, x, x_cs, 0, x_cs, H8, W8, ws + p.t1, 128, 0, 128, 1);
     snprintf(nm, sizeof nm, "res%d.conv2", i);
-    L.conv<3, 3, 1, false, 2, 32, true>(K_CONV3, nm, ws + p.t1, 128, 0, 128, H8, W8, ws + p.t2, 128, 0, 128, 1);
+    L.conv<3, 3, 1, false, 2, 32, 1>(K_CONV3, nm, ws + p.t1, 128, 0, 128, H8, W8, ws + p.t2, 128, 0, 128, 1);
     snprintf(nm, sizeof nm, "res%d.conv3", i);
-    L.conv<1, 1, 1, false, 3, 32, true>(K_CONV1, nm, ws + p.t2, 128, 0, 128, H8, W8, y3, CS_RES, 0, CS_RES, 0);
+    L.conv<1, 1, 1, false, 3, 32, 3>(K_CONV1, nm, ws + p.t2, 128, 0, 128, H8, W8, y3, CS_RES, 0, CS_RES, 0);
     snprintf(nm, sizeof nm, "res%d.qkv", i);
-    L.conv<1, 1, 1, false, 4, 24, true>(K_CONV1, nm, y3, CS_RES, 0, CS_RES, H8, W8, ws + p.qkv, 384, 0, 384, 0);
+    L.conv<1, 1, 1, false, 4, 24, 3>(K_CONV1, nm, y3, CS_RES, 0, CS_RES, H8, W8, ws + p.qkv, 384, 0, 384, 0);
     if (L.rc == BSR_OK) {
       L.begin(K_ATT);
       L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
@@ -382,7 +382,7 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
     }
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113)
     snprintf(nm, sizeof nm, "res%d.w", i);
-    L.conv<1, 1, 1, false, 3, 32, true>(K_CONV1, nm, ws + p.att[i], 128, 0, 128, H8, W8, ws + p.r[i], CS_RES, 0, CS_RES, 1, x, x_cs, x_cs,
+    L.conv<1, 1, 1, false, 3, 32, 3>(K_CONV1, nm, ws + p.att[i], 128, 0, 128, H8, W8, ws + p.r[i], CS_RES, 0, CS_RES, 1, x, x_cs, x_cs,
                                          y3, CS_RES, CS_RES);
   };
   if ((H8 * W8) % 128 != 0) return fail(BSR_ERR_ARG, "bsr_forward: (H/8)*(W/8) must be a multiple of 128");
@@ -391,11 +391,11 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   res_block(2, ws + p.r[1], CS_RES);
 
   // greyscale decoder: up1..3 = ConvT (model.py:243-245)
-  L.conv<3, 3, 1, true, 1, 24, true>(K_CONVT, "up1", ws + p.r[2], CS_RES, 0, CS_RES, H8, W8, ws + p.c2, 160, 0, 96, 1);
-  L.conv<3, 3, 1, true, 2, 32, true>(K_CONVT, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
-  L.conv<3, 3, 1, true, 2, 32, true>(K_CONVT, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
+  L.conv<3, 3, 1, true, 1, 24, 1>(K_CONVT, "up1", ws + p.r[2], CS_RES, 0, CS_RES, H8, W8, ws + p.c2, 160, 0, 96, 1);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
   // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
-  L.conv<7, 1, 1, false, 1, 32, true>(K_CONV7, "heads", ws + p.ybuf, 64, 0, 64, H, W, ws + p.qh, 16, 0, 14, 0);
+  L.conv<7, 1, 1, false, 1, 32, 1>(K_CONV7, "heads", ws + p.ybuf, 64, 0, 64, H, W, ws + p.qh, 16, 0, 14, 0);
   glue_begin();
   hipLaunchKernelGGL(bsr::heads_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.qh, inputs, h->head_bias[0],
                      h->head_bias[1], gs, mask22, ws + p.cf, CS_CF, 64, W, npix);
@@ -411,10 +411,10 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   res_block(5, ws + p.r[4], CS_RES);
 
   // colour decoder (model.py:264-269)
-  L.conv<3, 3, 1, true, 2, 24, true>(K_CONVT, "clr_up1", ws + p.r[5], CS_RES, 0, CS_RES, H8, W8, ws + p.f1, 128, 0, 128, 1);
-  L.conv<3, 3, 1, true, 1, 32, true>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1);
-  L.conv<3, 3, 1, true, 2, 32, true>(K_CONVT, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
-  L.conv<3, 3, 1, false, 1, 24, true>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, 0, CS_CF, H, W, ws + p.c1, 16, 0, 16, 1);
+  L.conv<3, 3, 1, true, 2, 24, 1>(K_CONVT, "clr_up1", ws + p.r[5], CS_RES, 0, CS_RES, H8, W8, ws + p.f1, 128, 0, 128, 1);
+  L.conv<3, 3, 1, true, 1, 32, 1>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
+  L.conv<3, 3, 1, false, 1, 24, 1>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, 0, CS_CF, H, W, ws + p.c1, 16, 0, 16, 1);
   if (L.rc == BSR_OK) {
     glue_begin();
     hipLaunchKernelGGL(bsr::color_tail_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.c1, h->tail_w, inputs, con_rgb, dif,

@@ -9,8 +9,11 @@
 // GEMM view: M = pixels of one spatial tile (TH x TW), N = output channels, K = taps x input channels.
 //  * the input tile + halo of one CC-channel chunk is staged once in LDS ([pixel][CC+4] floats) and every
 //    tap reads its A fragments from it at a shifted address — no im2col duplication;
-//  * weights are pre-packed [chunk][tap][N][CC+4] (the exact LDS image incl. the bank pad), copied per
-//    tap through registers into a double-buffered LDS slot while the previous tap's MFMAs run;
+//  * weights are pre-packed [chunk][tap][N][CC+4] (the exact LDS image incl. the bank pad) and flow through
+//    a 3-slot LDS ring: the global loads for step s+2 are issued at the start of step s, written to LDS late
+//    in step s and published by the barrier that ends it, so the first fragments of step s+1 are read BEFORE
+//    that barrier and the MFMA stream never waits on LDS latency behind a barrier (one barrier per step);
+//    the input tile is double-buffered the same way (ring of 3 for 1x1 convs, where every step is a new chunk);
 //  * a wave computes 32*MI pixels x 32*NI channels; lanes 0-31 / 32-63 read channels 8g+0..3 / 8g+4..7 of
 //    a K-group with one ds_read_b128 each and issue 4 MFMAs (the K order inside a group is permuted
 //    identically for A and B, which a sum over K does not care about);
@@ -48,18 +51,21 @@ struct ConvArgs {
   int tiles_x, tiles_y; // M tiles per image
 };
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, bool PF_IN>
+// INB = number of LDS input-tile buffers: 1 (reload synchronously at chunk boundaries), 2 (taps > 1: next chunk's
+// tile is staged one tap ahead) or 3 (1x1 convs: ring, like the weights).
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
 struct ConvCfg {
   static constexpr int T = KH * KW;
   static constexpr int IH = TR ? TH + 1 : (TH - 1) * S + KH;
   static constexpr int IW = TR ? TW + 1 : (TW - 1) * S + KW;
   static constexpr int LDP = CC + 4;
+  static constexpr int G = CC / 8;
   static constexpr int BN = WN * NI * 32;
   static constexpr int BM = WM * MI * 32;
   static constexpr int NPH = TR ? 4 : 1;
   static constexpr int IN_FLOATS = IH * IW * LDP;
   static constexpr int W_FLOATS = BN * LDP;
-  static constexpr int SMEM_BYTES = (IN_FLOATS + 2 * W_FLOATS) * 4;
+  static constexpr int SMEM_BYTES = (INB * IN_FLOATS + 3 * W_FLOATS) * 4;
   static constexpr int IN_V4 = IH * IW * (CC / 4);               // float4 loads per input-tile chunk
   static constexpr int IN_PER_THREAD = (IN_V4 + 255) / 256;
   static constexpr int W_V4 = W_FLOATS / 4;
@@ -68,15 +74,17 @@ struct ConvCfg {
   static_assert(BM == TH * TW, "M tile must equal the spatial tile");
   static_assert(CC % 8 == 0, "channel chunk must be a multiple of the 8-wide K group");
   static_assert(!TR || (KH == 3 && KW == 3 && S == 1), "transposed path is ConvT(3, stride 2)");
+  static_assert(INB == 1 || (T == 1 ? INB == 3 : INB == 2), "input buffers: 1, or 2 (taps > 1) / 3 (1x1)");
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, bool PF_IN>
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
 __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
-  using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, PF_IN>;
-  constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH;
+  using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
+  constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH, G = C::G;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
-  float* s_w = smem + C::IN_FLOATS;
+  float* s_w = smem + INB * C::IN_FLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       okmask |= (ok ? 1u : 0u) << i;
     }
   };
-  auto store_in = [&](const f32x4 (&regs)[C::IN_PER_THREAD], unsigned okmask) {
+  auto store_in = [&](int off, const f32x4 (&regs)[C::IN_PER_THREAD], unsigned okmask) {
 #pragma unroll
     for (int i = 0; i < C::IN_PER_THREAD; ++i) {
       const int idx = tid + i * 256;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
         const int pix = idx / (CC / 4), q = idx % (CC / 4);
         f32x4 v = regs[i];
         if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(s_in + pix * LDP + q * 4) = v;
+        *reinterpret_cast<f32x4*>(s_in + off + pix * LDP + q * 4) = v;
       }
     }
   };
@@ -152,8 +160,8 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       regs[i] = *reinterpret_cast<const f32x4*>(src + idx * 4);
     }
   };
-  auto store_w = [&](int buf, const f32x4 (&regs)[C::W_PER_THREAD]) {
-    float* dst = s_w + buf * C::W_FLOATS;
+  auto store_w = [&](int off, const f32x4 (&regs)[C::W_PER_THREAD]) {
+    float* dst = s_w + off;
 #pragma unroll
     for (int i = 0; i < C::W_PER_THREAD; ++i) {
       const int idx = tid + i * 256;
@@ -164,53 +172,73 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   f32x4 in_regs[C::IN_PER_THREAD];
   f32x4 w_regs[C::W_PER_THREAD];
   unsigned in_ok = 0u;
+  const int nsteps = p.nchunk * T;
 
-  // prologue: chunk 0 input tile + tap 0 weights
+  // LDS ring offsets (floats): weights of step s / s+1 / s+2; input tile of the current / next(+1) / next(+2) chunk
+  int w_cur = 0, w_n1 = C::W_FLOATS, w_n2 = 2 * C::W_FLOATS;
+  int in_cur = 0, in_n1 = (INB > 1) ? C::IN_FLOATS : 0, in_n2 = (INB > 2) ? 2 * C::IN_FLOATS : 0;
+
+  // prologue: steps 0 and 1 staged synchronously
   fetch_in(0, in_regs, in_ok);
   fetch_w(0, w_regs);
-  store_in(in_regs, in_ok);
+  store_in(0, in_regs, in_ok);
   store_w(0, w_regs);
+  if (nsteps > 1) {
+    fetch_w(1, w_regs);
+    store_w(w_n1, w_regs);
+    if (T == 1 && INB == 3) {
+      fetch_in(1, in_regs, in_ok);
+      store_in(in_n1, in_regs, in_ok);
+    }
+  }
   __syncthreads();
+
+  f32x4 af[2][MI], bf[2][NI];
+  auto read_frags = [&](int slot, int a_off, int b_off) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[slot][mi] = *reinterpret_cast<const f32x4*>(s_in + a_base[mi] + a_off);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_w + b_base[ni] + b_off);
+  };
+  auto tap_offset = [&](int t) -> int {
+    if (TR) {
+      const int a = t / 3, b = t % 3;
+      return (((a == 2) ? 0 : 1) * IW + ((b == 2) ? 0 : 1)) * LDP;
+    }
+    return ((t / KW) * IW + (t % KW)) * LDP;
+  };
+  read_frags(0, in_cur + tap_offset(0), w_cur);
 
   for (int ch = 0; ch < p.nchunk; ++ch) {
     const bool more = ch + 1 < p.nchunk;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int buf = t & 1;
-      const bool last_tap = (t == T - 1);
-      // prefetch what the next step needs while this step's MFMAs run
-      if (!last_tap) {
-        fetch_w(ch * T + t + 1, w_regs);
-      } else if (more) {
-        fetch_w((ch + 1) * T, w_regs);
-        if (PF_IN) fetch_in(ch + 1, in_regs, in_ok);
-      }
+      const int s = ch * T + t;
+      const bool has1 = s + 1 < nsteps, has2 = s + 2 < nsteps;
+      constexpr bool kRing1x1 = (T == 1 && INB == 3);
+      const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == T - 2 && more);
+      // (1) issue the global loads of step s+2 (and of the next input tile) — landed by the write point below
+      if (has2) fetch_w(s + 2, w_regs);
+      if (stage_in) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs, in_ok);
+      if (INB == 1 && t == T - 1 && more) fetch_in(ch + 1, in_regs, in_ok);     // single buffer: keep the loads in flight
+      __builtin_amdgcn_sched_barrier(0);
 
-      // ---- MFMAs of tap t ----
-      int tap_off, ph;
-      if (TR) {
-        const int a = t / 3, b = t % 3;
-        tap_off = (((a == 2) ? 0 : 1) * IW + ((b == 2) ? 0 : 1)) * LDP;
-        ph = ((a == 1) ? 2 : 0) + ((b == 1) ? 1 : 0);
-      } else {
-        tap_off = ((t / KW) * IW + (t % KW)) * LDP;
-        ph = 0;
-      }
-      const float* wb = s_w + buf * C::W_FLOATS;
-      // software-pipelined fragments: group g+1's ds_read_b128s are issued before group g's MFMAs
-      f32x4 af[2][MI], bf[2][NI];
+      // (2) MFMAs of tap t; group g+1's fragments (or step s+1's first group) are read before group g's MFMAs
+      const int ph = TR ? (((t / 3 == 1) ? 2 : 0) + ((t % 3 == 1) ? 1 : 0)) : 0;
+      const int tap_off = tap_offset(t);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[0][mi] = *reinterpret_cast<const f32x4*>(s_in + a_base[mi] + tap_off);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *reinterpret_cast<const f32x4*>(wb + b_base[ni]);
-#pragma unroll
-      for (int g = 0; g < CC / 8; ++g) {
-        const int cur = g & 1, nxt = cur ^ 1;
-        if (g + 1 < CC / 8) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) af[nxt][mi] = *reinterpret_cast<const f32x4*>(s_in + a_base[mi] + tap_off + (g + 1) * 8);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bf[nxt][ni] = *reinterpret_cast<const f32x4*>(wb + b_base[ni] + (g + 1) * 8);
+      for (int g = 0; g < G; ++g) {
+        const int cur = (t * G + g) & 1, nxt = cur ^ 1;
+        if (g + 1 < G) {
+          read_frags(nxt, in_cur + tap_off + (g + 1) * 8, w_cur + (g + 1) * 8);
+        } else if (t + 1 < T) {
+          read_frags(nxt, in_cur + tap_offset(t + 1 < T ? t + 1 : 0), w_n1);        // same chunk, next tap (published one barrier ago)
+        } else if (INB > 1) {
+          if (has1) read_frags(nxt, in_n1 + tap_offset(0), w_n1);                   // next chunk's tile is already staged
+        }
+        if (g == G - 1) {                                                           // write point: stage step s+2
+          if (has2) store_w(w_n2, w_regs);
+          if (stage_in) store_in(kRing1x1 ? in_n2 : in_n1, in_regs, in_ok);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -223,22 +251,39 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
 
-      // ---- publish the prefetched data ----
-      if (!last_tap) {
-        store_w(buf ^ 1, w_regs);
+      // (3) one barrier per step publishes what was staged and frees the slot read in this step
+      __syncthreads();
+      if (INB == 1 && t == T - 1 && more) {          // single input buffer: swap it between chunks (2 barriers)
+        store_in(0, in_regs, in_ok);
         __syncthreads();
-      } else if (more) {
-        __syncthreads();                 // every wave is done reading s_in / both weight slots
-        if (!PF_IN) fetch_in(ch + 1, in_regs, in_ok);
-        store_in(in_regs, in_ok);
-        store_w(0, w_regs);
-        __syncthreads();
+        read_frags(((T * G) & 1), tap_offset(0), w_n1);
       }
+      {                                               // rotate the rings
+        const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = tw;
+        if (T == 1 && INB == 3) { const int ti = in_cur; in_cur = in_n1; in_n1 = in_n2; in_n2 = ti; }
+        if (T > 1 && INB == 2 && t == T - 1) { const int ti = in_cur; in_cur = in_n1; in_n1 = ti; }
+      }
+    }
+    if ((T * G) & 1) {                                // odd number of groups per chunk: restore fragment parity 0
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[0][mi] = af[1][mi];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[0][ni] = bf[1][ni];
     }
   }
 
   // ---- epilogue: bias (+ residuals) + LeakyReLU, NHWC store (32 consecutive channels per half-wave) ----
-  const size_t out_img = (size_t)img * p.Ho * p.Wo;
+  // With TW == 32 a wave's 32 pixels are one tile row, so every element address is a wave-uniform base plus a
+  // 32-bit lane offset plus a compile-time multiple of the pixel stride: no 64-bit per-element arithmetic.
+  // Residual loads are unconditional (clamped channel, masked value) and issued 16 at a time ahead of the
+  // arithmetic: a per-element branch would make hipcc wait for every load separately.
+  static_assert(TW == 32, "epilogue assumes one tile row per 32-pixel MFMA tile");
+  constexpr int SX = TR ? 2 : 1;
+  const size_t blk_pix = (size_t)img * p.Ho * p.Wo + (size_t)(SX * y0) * p.Wo + SX * x0;
+  float* out_blk = p.out + blk_pix * p.out_cs + p.out_coff;
+  const bool has_res = p.res1 != nullptr;      // res1 and res2 come together (NonLocal residual + block skip)
+  const float* res1_blk = has_res ? p.res1 + blk_pix * p.res1_cs : nullptr;
+  const float* res2_blk = has_res ? p.res2 + blk_pix * p.res2_cs : nullptr;
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
@@ -247,34 +292,47 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + (wn * NI + ni) * 32 + r;
         const bool n_ok = n < p.n_store;
-        const float bias = n_ok ? p.bias[n] : 0.f;
+        const float bias = p.bias[n_ok ? n : 0];
+        const int ty = wm * MI + mi;
+        // pixel index (relative to the block origin) of this lane's register 0
+        const unsigned pix0 = (unsigned)((SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0) + SX * 4 * h);
+        f32x16 v = acc[ph][mi][ni];
+        if (has_res) {
+          const bool ok1 = n < p.res1_c, ok2 = n < p.res2_c;
+          const unsigned b1 = pix0 * (unsigned)p.res1_cs + (ok1 ? n : 0), b2 = pix0 * (unsigned)p.res2_cs + (ok2 ? n : 0);
+          const float m1 = ok1 ? 1.f : 0.f, m2 = ok2 ? 1.f : 0.f;
+          float r1[16], r2[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int px = (wm * MI + mi) * 32 + row;
-          const int ty = px / TW, tx = px % TW;
-          int oy, ox;
-          if (TR) {
-            oy = 2 * (y0 + ty) + (ph >> 1);
-            ox = 2 * (x0 + tx) + (ph & 1);
-          } else {
-            oy = y0 + ty;
-            ox = x0 + tx;
+          for (int i = 0; i < 16; ++i) {
+            const unsigned k = (unsigned)(SX * ((i & 3) + 8 * (i >> 2)));
+            r1[i] = res1_blk[b1 + k * (unsigned)p.res1_cs];
+            r2[i] = res2_blk[b2 + k * (unsigned)p.res2_cs];
           }
-          const size_t opix = out_img + (size_t)oy * p.Wo + ox;
-          float v = acc[ph][mi][ni][i] + bias;
-          if (p.res1 != nullptr && n < p.res1_c) v += p.res1[opix * p.res1_cs + n];
-          if (p.res2 != nullptr && n < p.res2_c) v += p.res2[opix * p.res2_cs + n];
-          if (p.act) v = v >= 0.f ? v : v * kLeakyAlpha;
-          if (n_ok) p.out[opix * p.out_cs + p.out_coff + n] = v;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = (v[i] + bias) + (r1[i] * m1 + r2[i] * m2);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] += bias;
+        }
+        if (p.act) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * kLeakyAlpha;
+        }
+        if (n_ok) {
+          const unsigned ob = pix0 * (unsigned)p.out_cs + (unsigned)n;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned k = (unsigned)(SX * ((i & 3) + 8 * (i >> 2)));
+            out_blk[ob + k * (unsigned)p.out_cs] = v[i];
+          }
         }
       }
 }
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, bool PF_IN>
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
 inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream) {
-  using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, PF_IN>;
-  auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, PF_IN>;
+  using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
+  auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
   static bool attr_set = false;
   if (!attr_set && C::SMEM_BYTES > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
