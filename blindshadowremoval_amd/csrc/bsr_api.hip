@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "attention.h"
+#include "conv_n16.h"
 #include "glue_kernels.h"
 #include "igemm_conv.h"
 
@@ -56,7 +57,7 @@ enum KClass { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2, K_ATT = 3, K_CONV7 = 4, K_G
 constexpr int C_RES = 257;   // ResBottleneck width (/root/reference/model.py:226)
 constexpr int CS_RES = 264;  // its channel stride (multiple of the 24-wide K chunk)
 constexpr int CS_XA = 120;   // cat[x(96), uv(3)] stride (model.py:238)
-constexpr int CS_CF = 72;    // cat[f(64), gs(1)] stride (model.py:267; gs moved to the tail, weights permuted)
+constexpr int CS_CF = 64;    // f = clr_up3 output; the gs channel of cat[gs, f] (model.py:267) is read from the gs output
 
 struct Plan {  // float offsets into the workspace for a (B,H,W) problem
   size_t xr, x1, c3, c2, xa, t1, t2, y3[6], qkv, att[6], r[6], xh, ybuf, qh, f1, f2, cf, c1, probe, total;
@@ -102,6 +103,7 @@ struct bsr_handle {
   std::unordered_map<std::string, LayerW> layers;
   float head_bias[2] = {0.f, 0.f};
   const float* tail_w = nullptr;
+  const float* clr_gs_w = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
   Plan plan{};
@@ -192,6 +194,22 @@ struct Launcher {
     check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
     end();
   }
+  template <int KH, int KW, bool GS, bool TAIL>
+  void conv16(int cls, const char* name, const float* in, int in_cs, int H, int W, float* out, int out_cs, int act, const float* gs,
+              const float* inputs, float* con_rgb, float* dif) {
+    if (rc != BSR_OK) return;
+    LayerW l;
+    rc = find_layer(h, name, 2, KH * KW, 36, 16, &l);
+    if (rc != BSR_OK) return;
+    if (l.n_pad != 16) { rc = fail(BSR_ERR_BLOB, std::string("layer '") + name + "' must be packed with n_pad 16"); return; }
+    bsr::ConvN16Args a{};
+    a.in = in; a.in_cs = in_cs; a.H = H; a.W = W; a.w = l.w; a.bias = l.b; a.out = out; a.out_cs = out_cs; a.act = act;
+    a.pad_t = (KH - 1) / 2; a.pad_l = (KW - 1) / 2;
+    a.gs = gs; a.w_gs = h->clr_gs_w; a.tail_w = h->tail_w; a.inputs = inputs; a.con_rgb = con_rgb; a.dif = dif;
+    begin(cls);
+    check(bsr::launch_conv_n16<KH, KW, GS, TAIL>(a, h->B, s), name);
+    end();
+  }
 };
 
 int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
@@ -262,6 +280,9 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
     if (nm == "heads.bias") {
       if (en.nfloats != 2) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: heads.bias must hold 2 floats"); }
       memcpy(h->head_bias, blob + en.offset, 8);
+    } else if (nm == "clr_conv1.gs") {
+      if (en.nfloats != 256) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: clr_conv1.gs must hold 16x16 floats"); }
+      h->clr_gs_w = dptr;
     } else if (nm == "tail.w") {
       if (en.nfloats != 16 * 16 + 16 + 48 + 3) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: tail.w has the wrong size"); }
       h->tail_w = dptr;
@@ -277,7 +298,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
       h->layers[nm.substr(0, nm.size() - 2)].b = dptr;
     }
   }
-  if (h->tail_w == nullptr) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob has no 'tail.w'"); }
+  if (h->tail_w == nullptr || h->clr_gs_w == nullptr) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob lacks 'tail.w' / 'clr_conv1.gs'"); }
   *out = h;
   return BSR_OK;
 }
@@ -395,10 +416,10 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
   // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
-  L.conv<7, 1, 1, false, 1, 32, 1>(K_CONV7, "heads", ws + p.ybuf, 64, 0, 64, H, W, ws + p.qh, 16, 0, 14, 0);
+  L.conv16<7, 1, false, false>(K_CONV7, "heads", ws + p.ybuf, 64, H, W, ws + p.qh, 16, 0, nullptr, nullptr, nullptr, nullptr);
   glue_begin();
   hipLaunchKernelGGL(bsr::heads_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.qh, inputs, h->head_bias[0],
-                     h->head_bias[1], gs, mask22, ws + p.cf, CS_CF, 64, W, npix);
+                     h->head_bias[1], gs, mask22, W, npix);
   glue_end("heads_post");
   // bmask / x_hole (model.py:256-259)
   glue_begin();
@@ -414,13 +435,8 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   L.conv<3, 3, 1, true, 2, 24, 1>(K_CONVT, "clr_up1", ws + p.r[5], CS_RES, 0, CS_RES, H8, W8, ws + p.f1, 128, 0, 128, 1);
   L.conv<3, 3, 1, true, 1, 32, 1>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
-  L.conv<3, 3, 1, false, 1, 24, 1>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, 0, CS_CF, H, W, ws + p.c1, 16, 0, 16, 1);
-  if (L.rc == BSR_OK) {
-    glue_begin();
-    hipLaunchKernelGGL(bsr::color_tail_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.c1, h->tail_w, inputs, con_rgb, dif,
-                       npix);
-    glue_end("color_tail");
-  }
+  // clr_conv1 (3x3 over cat[gs, f]) + clr_conv2 + clr_conv3 + dif, one kernel (model.py:267-269,288)
+  L.conv16<3, 3, true, true>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, H, W, nullptr, 0, 1, gs, inputs, con_rgb, dif);
   if (L.rc == BSR_OK) h->ran = true;
   return L.rc;
 }

@@ -1,0 +1,250 @@
+// 16-output-channel convolutions on v_mfma_f32_16x16x4_f32 — the two thin, full-resolution layers of the
+// generator, where a 32-wide MFMA tile would waste half (or more) of the matrix core:
+//   * heads  = conv2 | conv3, 7x7, 64 -> 1 each (/root/reference/model.py:204-205,246-247), run as a 7x1 conv
+//     with N = (kx, head) = 14 (-> 16); the 7 horizontal taps are summed by heads_post_kernel;
+//   * clr_conv1 = Conv(16, 3x3) over cat[gs, f] (model.py:217,267), optionally fused with clr_conv2 (1x1 16->16
+//     + BN + LeakyReLU), clr_conv3 (1x1 16->3) and dif = gray(con_rgb) - gray(inputs) (model.py:268-269,288).
+//
+// Transposed GEMM: A = weights (M = 16 output channels), B = pixels (N = 16 pixels), so the accumulator holds
+// 4 consecutive channels of one pixel per lane (one 16-byte NHWC store) and is directly the B operand of the
+// next 1x1 layer (k index = lane>>4, step = register) — the fused tail needs no LDS round trip.
+// K = 64 input channels in two 32-channel chunks; all taps of a chunk are staged per barrier.  The extra
+// `gs` input channel of clr_conv1 is one more K group built by an im2col gather from a (TH+2)x(TW+2) LDS tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "igemm_conv.h"
+
+namespace bsr {
+
+struct ConvN16Args {
+  const float* in;      // NHWC, 64 channels used, channel stride in_cs
+  int in_cs;
+  int H, W;
+  const float* w;       // packed [2][T][16][36]
+  const float* bias;    // [16]
+  float* out;           // NHWC, channel stride out_cs (unused when TAIL)
+  int out_cs;
+  int act;
+  int pad_t, pad_l;
+  const float* gs;      // GS: [B,H,W,1]
+  const float* w_gs;    // GS: [16 n][16 k] (k < 9 = 3x3 taps of the gs channel, rest 0)
+  const float* tail_w;  // TAIL: w2[16 k][16 n] | b2[16] | w3[16 k][3 n] | b3[3]
+  const float* inputs;  // TAIL: [B,H,W,3]
+  float* con_rgb;       // TAIL: [B,H,W,3]
+  float* dif;           // TAIL: [B,H,W,1]
+  int tiles_x, tiles_y;
+};
+
+template <int KH, int KW, bool GS, bool TAIL>
+struct ConvN16Cfg {
+  static constexpr int T = KH * KW, TH = 4, TW = 32, CC = 32, LDP = 36, G = 2;
+  static constexpr int IH = TH + KH - 1, IW = TW + KW - 1;
+  static constexpr int IN_FLOATS = IH * IW * LDP;
+  static constexpr int W_FLOATS = T * 16 * LDP;
+  static constexpr int GS_FLOATS = GS ? (TH + 2) * (TW + 2) + 2 : 0;
+  static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS + GS_FLOATS) * 4;
+  static constexpr int IN_V4 = IH * IW * (CC / 4);
+  static constexpr int IN_PER_THREAD = (IN_V4 + 255) / 256;
+  static constexpr int W_V4 = W_FLOATS / 4;
+  static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
+};
+
+template <int KH, int KW, bool GS, bool TAIL>
+__global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
+  using C = ConvN16Cfg<KH, KW, GS, TAIL>;
+  constexpr int T = C::T, IW = C::IW, LDP = C::LDP, TW = C::TW, TH = C::TH;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;
+  float* s_w = smem + C::IN_FLOATS;
+  float* s_gs = s_w + C::W_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  int bid = blockIdx.x;
+  const int tile_x = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int tile_y = bid % p.tiles_y;
+  const int img = bid / p.tiles_y;
+  const int y0 = tile_y * TH, x0 = tile_x * TW;
+  const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
+  const float* in_img = p.in + (size_t)img * p.H * p.W * p.in_cs;
+
+  auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD], unsigned& okmask) {
+    okmask = 0u;
+#pragma unroll
+    for (int i = 0; i < C::IN_PER_THREAD; ++i) {
+      int idx = tid + i * 256;
+      idx = idx < C::IN_V4 ? idx : C::IN_V4 - 1;
+      const int pix = idx / 8, c4 = idx % 8;
+      const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+      regs[i] = *reinterpret_cast<const f32x4*>(in_img + ((size_t)iyc * p.W + ixc) * p.in_cs + ch * 32 + c4 * 4);
+      okmask |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto store_in = [&](const f32x4 (&regs)[C::IN_PER_THREAD], unsigned okmask) {
+#pragma unroll
+    for (int i = 0; i < C::IN_PER_THREAD; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < C::IN_V4) {
+        f32x4 v = regs[i];
+        if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(s_in + (idx / 8) * LDP + (idx % 8) * 4) = v;
+      }
+    }
+  };
+  auto fetch_w = [&](int ch, f32x4 (&regs)[C::W_PER_THREAD]) {
+    const float* src = p.w + (size_t)ch * C::W_FLOATS;
+#pragma unroll
+    for (int i = 0; i < C::W_PER_THREAD; ++i) {
+      int idx = tid + i * 256;
+      idx = idx < C::W_V4 ? idx : C::W_V4 - 1;
+      regs[i] = *reinterpret_cast<const f32x4*>(src + idx * 4);
+    }
+  };
+  auto store_w = [&](const f32x4 (&regs)[C::W_PER_THREAD]) {
+#pragma unroll
+    for (int i = 0; i < C::W_PER_THREAD; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < C::W_V4) *reinterpret_cast<f32x4*>(s_w + idx * 4) = regs[i];
+    }
+  };
+
+  f32x4 in_regs[C::IN_PER_THREAD];
+  f32x4 w_regs[C::W_PER_THREAD];
+  unsigned in_ok = 0u;
+  fetch_in(0, in_regs, in_ok);
+  fetch_w(0, w_regs);
+  if (GS) {   // (TH+2) x (TW+2) halo tile of the gs channel, zero outside the image
+    constexpr int NG = (TH + 2) * (TW + 2);
+    if (tid < NG) {
+      const int gy = y0 - 1 + tid / (TW + 2), gx = x0 - 1 + tid % (TW + 2);
+      const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const float v = p.gs[((size_t)img * p.H + min(max(gy, 0), p.H - 1)) * p.W + min(max(gx, 0), p.W - 1)];
+      s_gs[tid] = ok ? v : 0.f;
+    }
+  }
+  store_in(in_regs, in_ok);
+  store_w(w_regs);
+  __syncthreads();
+
+  // this wave: tile row `wave`, two 16-pixel MFMA tiles
+  int x_base[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) x_base[mt] = (wave * IW + mt * 16 + r) * LDP + 4 * q;
+  const int w_base = r * LDP + 4 * q;
+  f32x4 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    if (ch == 0) {
+      fetch_in(1, in_regs, in_ok);
+      fetch_w(1, w_regs);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 wf[2], xf[2][2];
+    wf[0] = *reinterpret_cast<const f32x4*>(s_w + w_base);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) xf[0][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt]);
+#pragma unroll
+    for (int i = 0; i < T * 2; ++i) {        // (tap, 16-channel group) steps, fragments read one step ahead
+      const int cur = i & 1, nxt = cur ^ 1;
+      if (i + 1 < T * 2) {
+        const int t = (i + 1) / 2, g = (i + 1) % 2;
+        wf[nxt] = *reinterpret_cast<const f32x4*>(s_w + w_base + t * 16 * LDP + g * 16);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          xf[nxt][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt] + ((t / KW) * IW + (t % KW)) * LDP + g * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cur][j], xf[cur][mt][j], acc[mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch == 0) {
+      __syncthreads();
+      store_in(in_regs, in_ok);
+      store_w(w_regs);
+      __syncthreads();
+    }
+  }
+
+  if (GS) {   // the gs channel: K group k = 4q + j <-> tap (k/3, k%3), k < 9
+    const f32x4 wg = *reinterpret_cast<const f32x4*>(p.w_gs + r * 16 + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * q + j;
+      const int kk = k < 9 ? k : 0;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float xv = s_gs[(wave + kk / 3) * (TW + 2) + mt * 16 + r + kk % 3];
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j], k < 9 ? xv : 0.f, acc[mt], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: lane (pixel r of tile mt, q) holds channels 4q .. 4q+3
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * q);
+  const size_t row_pix = ((size_t)img * p.H + y0 + wave) * p.W + x0;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x4 v = acc[mt] + b4;
+    if (p.act) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * kLeakyAlpha;
+    }
+    const size_t pix = row_pix + mt * 16 + r;
+    if (!TAIL) {
+      *reinterpret_cast<f32x4*>(p.out + pix * p.out_cs + 4 * q) = v;
+    } else {
+      // clr_conv2: y2^T[c2][px] = sum_c W2^T[c2][c] * y1^T[c][px]; register e of v is channel c = 4q + e (k index q)
+      f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.tail_w[(4 * q + e) * 16 + r], v[e], a2, 0, 0, 0);
+      const f32x4 bb2 = *reinterpret_cast<const f32x4*>(p.tail_w + 256 + 4 * q);
+      a2 += bb2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a2[e] = a2[e] >= 0.f ? a2[e] : a2[e] * kLeakyAlpha;
+      // clr_conv3: rows c3 = 0..2 (lanes r < 3 carry the weights, the rest multiply by 0)
+      f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w3 = r < 3 ? p.tail_w[272 + (4 * q + e) * 3 + r] : 0.f;
+        a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3, a2[e], a3, 0, 0, 0);
+      }
+      if (q == 0) {   // rows 0..2 = R,G,B of pixel r
+#pragma clang fp contract(off)
+        const float cr = a3[0] + p.tail_w[320], cg = a3[1] + p.tail_w[321], cb = a3[2] + p.tail_w[322];
+        p.con_rgb[pix * 3 + 0] = cr;
+        p.con_rgb[pix * 3 + 1] = cg;
+        p.con_rgb[pix * 3 + 2] = cb;
+        const float g1 = (cr * 0.2989f + cg * 0.5870f) + cb * 0.1140f;
+        const float g0 = (p.inputs[pix * 3] * 0.2989f + p.inputs[pix * 3 + 1] * 0.5870f) + p.inputs[pix * 3 + 2] * 0.1140f;
+        p.dif[pix] = g1 - g0;
+      }
+    }
+  }
+}
+
+template <int KH, int KW, bool GS, bool TAIL>
+inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream) {
+  using C = ConvN16Cfg<KH, KW, GS, TAIL>;
+  auto kern = conv_n16_kernel<KH, KW, GS, TAIL>;
+  static bool attr_set = false;
+  if (!attr_set && C::SMEM_BYTES > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  a.tiles_x = a.W / C::TW;
+  a.tiles_y = a.H / C::TH;
+  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * batch), dim3(256), C::SMEM_BYTES, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace bsr

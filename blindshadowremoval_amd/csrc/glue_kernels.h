@@ -58,10 +58,8 @@ __global__ void uv_resize8_kernel(const float* __restrict__ uv, int H, int W, fl
 // Heads epilogue (model.py:246-252).  q [B,H,W,16]: q[y][x'][kx*2+o] = sum_{ky,c} y[y+ky-3][x'][c] * w_o[ky][kx][c]
 // (the 7x1 MFMA conv); here the 7 horizontal taps are summed, then
 //   mask = tanh(. + b2), con = . + b3, gs = gray(inputs)*(1+mask)+con, mask22 = [relu(mask), 0, relu(-mask)].
-// gs is also written into channel gs_coff of the clr_conv1 concat buffer (model.py:267).
 __global__ void heads_post_kernel(const float* __restrict__ q, const float* __restrict__ inputs, float b_mask, float b_con,
-                                  float* __restrict__ gs, float* __restrict__ mask22, float* __restrict__ cat, int cat_cs,
-                                  int gs_coff, int W, size_t npix) {
+                                  float* __restrict__ gs, float* __restrict__ mask22, int W, size_t npix) {
   const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= npix) return;
   const int x = (int)(pix % W);
@@ -80,7 +78,6 @@ __global__ void heads_post_kernel(const float* __restrict__ q, const float* __re
   const float g0 = gray3(inputs[pix * 3], inputs[pix * 3 + 1], inputs[pix * 3 + 2]);
   const float g = g0 * (1.f + mask) + con;
   gs[pix] = g;
-  cat[pix * cat_cs + gs_coff] = g;
   mask22[pix * 3 + 0] = fmaxf(mask, 0.f);
   mask22[pix * 3 + 1] = mask * 0.f;
   mask22[pix * 3 + 2] = fmaxf(-mask, 0.f);

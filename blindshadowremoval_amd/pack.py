@@ -29,8 +29,8 @@ TRANSPOSED = ("up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3")
 # name -> (CC, k_pad, n_pad): must match the launch table in csrc/bsr_api.hip
 GEOMETRY: Dict[str, Tuple[int, int, int]] = {
     "conv1": (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),
-    "up1": (24, 264, 96), "up2": (32, 160, 64), "up3": (32, 128, 64), "heads": (32, 64, 32),
-    "clr_up1": (24, 264, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (24, 72, 32),
+    "up1": (24, 264, 96), "up2": (32, 160, 64), "up3": (32, 128, 64), "heads": (32, 64, 16),
+    "clr_up1": (24, 264, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (32, 64, 16),
 }
 for _i in range(N_RES):
     _cin_pad = 120 if _i == 0 else 264
@@ -88,10 +88,10 @@ def layer_matrices(w: Dict[str, np.ndarray]) -> "Dict[str, Tuple[np.ndarray, np.
     k2, k3 = w["conv2/conv/kernel"][..., 0], w["conv3/conv/kernel"][..., 0]      # [7,7,64]
     hk = np.stack([k2, k3], axis=-1)                              # [ky,kx,c,head]
     out["heads"] = (hk.transpose(0, 2, 1, 3).reshape(7, 64, 14).astype(np.float64), np.zeros(14))
-    # clr_conv1: reference input cat[gs, f] (model.py:267); our buffer is [f(64), gs] -> rotate K
-    k = hwio("clr_conv1/conv")                                    # [9,65,16]
-    k = np.concatenate([k[:, 1:, :], k[:, :1, :]], axis=1)
-    out["clr_conv1"] = fold_bn(k, w["clr_conv1/conv/bias"], _bn(w, "clr_conv1/bnorm"))
+    # clr_conv1: reference input cat[gs, f] (model.py:267): the 64 f channels go through the K = 64 MFMA loop,
+    # the gs channel (reference channel 0) is a separate 9-tap K group ("clr_conv1.gs", see clr_gs_weights)
+    k, b = fold_bn(hwio("clr_conv1/conv"), w["clr_conv1/conv/bias"], _bn(w, "clr_conv1/bnorm"))   # [9,65,16]
+    out["clr_conv1"] = (k[:, 1:, :], b)
     for i in range(N_RES):
         st = "res_stack/%d/" % i
         out["res%d.conv1" % i] = fold_bn(hwio(st + "conv1"), w[st + "conv1/bias"], _bn(w, st + "bnorm1"))
@@ -102,6 +102,14 @@ def layer_matrices(w: Dict[str, np.ndarray]) -> "Dict[str, Tuple[np.ndarray, np.
         qb = np.concatenate([w[st + "non_local/%s/bias" % n] for n in ("theta", "phi", "g")])
         out["res%d.qkv" % i] = (qkv.astype(np.float64), qb.astype(np.float64))
         out["res%d.w" % i] = fold_bn(hwio(st + "non_local/w"), w[st + "non_local/w/bias"], _bn(w, st + "non_local/bnorm"))
+    return out
+
+
+def clr_gs_weights(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """[16 n][16 k] float32: BN-folded clr_conv1 weights of the gs input channel, k = 3x3 tap index (k >= 9 zero)."""
+    k, _ = fold_bn(w["clr_conv1/conv/kernel"].reshape(9, 65, 16), w["clr_conv1/conv/bias"], _bn(w, "clr_conv1/bnorm"))
+    out = np.zeros((16, 16), np.float32)
+    out[:, :9] = k[:, 0, :].T
     return out
 
 
@@ -122,6 +130,7 @@ def pack_generator(weights: Dict[str, np.ndarray]) -> bytes:
         entries.append((name + ".w", arr, tuple(arr.shape)))
         entries.append((name + ".b", bias, (n_pad, 0, 0, 0)))
     entries.append(("heads.bias", np.array([weights["conv2/conv/bias"][0], weights["conv3/conv/bias"][0]], np.float32), (2, 0, 0, 0)))
+    entries.append(("clr_conv1.gs", clr_gs_weights(weights), (16, 16, 0, 0)))
     entries.append(("tail.w", tail_weights(weights), (323, 0, 0, 0)))
 
     off = _HEADER.size + _ENTRY.size * len(entries)
