@@ -194,7 +194,7 @@ struct Launcher {
     check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
     end();
   }
-  template <int KH, int KW, bool GS, bool TAIL>
+  template <int KH, int KW, bool GS, bool TAIL, int RW>
   void conv16(int cls, const char* name, const float* in, int in_cs, int H, int W, float* out, int out_cs, int act, const float* gs,
               const float* inputs, float* con_rgb, float* dif) {
     if (rc != BSR_OK) return;
@@ -206,8 +206,9 @@ struct Launcher {
     a.in = in; a.in_cs = in_cs; a.H = H; a.W = W; a.w = l.w; a.bias = l.b; a.out = out; a.out_cs = out_cs; a.act = act;
     a.pad_t = (KH - 1) / 2; a.pad_l = (KW - 1) / 2;
     a.gs = gs; a.w_gs = h->clr_gs_w; a.tail_w = h->tail_w; a.inputs = inputs; a.con_rgb = con_rgb; a.dif = dif;
+    if (H % (4 * RW) != 0 || W % 32 != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': image is not a multiple of its tile"); return; }
     begin(cls);
-    check(bsr::launch_conv_n16<KH, KW, GS, TAIL>(a, h->B, s), name);
+    check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW>(a, h->B, s), name);
     end();
   }
 };
@@ -416,7 +417,7 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
   // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
-  L.conv16<7, 1, false, false>(K_CONV7, "heads", ws + p.ybuf, 64, H, W, ws + p.qh, 16, 0, nullptr, nullptr, nullptr, nullptr);
+  L.conv16<7, 1, false, false, 2>(K_CONV7, "heads", ws + p.ybuf, 64, H, W, ws + p.qh, 16, 0, nullptr, nullptr, nullptr, nullptr);
   glue_begin();
   hipLaunchKernelGGL(bsr::heads_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.qh, inputs, h->head_bias[0],
                      h->head_bias[1], gs, mask22, W, npix);
@@ -436,7 +437,7 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   L.conv<3, 3, 1, true, 1, 32, 1>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
   // clr_conv1 (3x3 over cat[gs, f]) + clr_conv2 + clr_conv3 + dif, one kernel (model.py:267-269,288)
-  L.conv16<3, 3, true, true>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, H, W, nullptr, 0, 1, gs, inputs, con_rgb, dif);
+  L.conv16<3, 3, true, true, 2>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, H, W, nullptr, 0, 1, gs, inputs, con_rgb, dif);
   if (L.rc == BSR_OK) h->ran = true;
   return L.rc;
 }

@@ -35,9 +35,9 @@ struct ConvN16Args {
   int tiles_x, tiles_y;
 };
 
-template <int KH, int KW, bool GS, bool TAIL>
+template <int KH, int KW, bool GS, bool TAIL, int RW>   // RW = tile rows per wave (MFMA work per staged byte)
 struct ConvN16Cfg {
-  static constexpr int T = KH * KW, TH = 4, TW = 32, CC = 32, LDP = 36, G = 2;
+  static constexpr int T = KH * KW, TH = 4 * RW, TW = 32, MT = 2 * RW, CC = 32, LDP = 36, G = 2;
   static constexpr int IH = TH + KH - 1, IW = TW + KW - 1;
   static constexpr int IN_FLOATS = IH * IW * LDP;
   static constexpr int W_FLOATS = T * 16 * LDP;
@@ -49,10 +49,10 @@ struct ConvN16Cfg {
   static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
 };
 
-template <int KH, int KW, bool GS, bool TAIL>
+template <int KH, int KW, bool GS, bool TAIL, int RW>
 __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
-  using C = ConvN16Cfg<KH, KW, GS, TAIL>;
-  constexpr int T = C::T, IW = C::IW, LDP = C::LDP, TW = C::TW, TH = C::TH;
+  using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
+  constexpr int T = C::T, IW = C::IW, LDP = C::LDP, TW = C::TW, TH = C::TH, MT = C::MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
   float* s_w = smem + C::IN_FLOATS;
@@ -118,25 +118,25 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   fetch_w(0, w_regs);
   if (GS) {   // (TH+2) x (TW+2) halo tile of the gs channel, zero outside the image
     constexpr int NG = (TH + 2) * (TW + 2);
-    if (tid < NG) {
-      const int gy = y0 - 1 + tid / (TW + 2), gx = x0 - 1 + tid % (TW + 2);
+    for (int i = tid; i < NG; i += 256) {
+      const int gy = y0 - 1 + i / (TW + 2), gx = x0 - 1 + i % (TW + 2);
       const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       const float v = p.gs[((size_t)img * p.H + min(max(gy, 0), p.H - 1)) * p.W + min(max(gx, 0), p.W - 1)];
-      s_gs[tid] = ok ? v : 0.f;
+      s_gs[i] = ok ? v : 0.f;
     }
   }
   store_in(in_regs, in_ok);
   store_w(w_regs);
   __syncthreads();
 
-  // this wave: tile row `wave`, two 16-pixel MFMA tiles
-  int x_base[2];
+  // this wave: tile rows wave*RW .. wave*RW+RW-1, two 16-pixel MFMA tiles per row
+  int x_base[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) x_base[mt] = (wave * IW + mt * 16 + r) * LDP + 4 * q;
+  for (int mt = 0; mt < MT; ++mt) x_base[mt] = ((wave * RW + mt / 2) * IW + (mt % 2) * 16 + r) * LDP + 4 * q;
   const int w_base = r * LDP + 4 * q;
-  f32x4 acc[2];
+  f32x4 acc[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {
@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
       fetch_w(1, w_regs);
     }
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 wf[2], xf[2][2];
+    f32x4 wf[2], xf[2][MT];
     wf[0] = *reinterpret_cast<const f32x4*>(s_w + w_base);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) xf[0][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt]);
+    for (int mt = 0; mt < MT; ++mt) xf[0][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt]);
 #pragma unroll
     for (int i = 0; i < T * 2; ++i) {        // (tap, 16-channel group) steps, fragments read one step ahead
       const int cur = i & 1, nxt = cur ^ 1;
@@ -156,14 +156,14 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
         const int t = (i + 1) / 2, g = (i + 1) % 2;
         wf[nxt] = *reinterpret_cast<const f32x4*>(s_w + w_base + t * 16 * LDP + g * 16);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
           xf[nxt][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt] + ((t / KW) * IW + (t % KW)) * LDP + g * 16);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cur][j], xf[cur][mt][j], acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cur][j], xf[cur][mt][j], acc[mt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (ch == 0) {
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
       const int k = 4 * q + j;
       const int kk = k < 9 ? k : 0;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const float xv = s_gs[(wave + kk / 3) * (TW + 2) + mt * 16 + r + kk % 3];
+      for (int mt = 0; mt < MT; ++mt) {
+        const float xv = s_gs[(wave * RW + mt / 2 + kk / 3) * (TW + 2) + (mt % 2) * 16 + r + kk % 3];
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j], k < 9 ? xv : 0.f, acc[mt], 0, 0, 0);
       }
     }
@@ -190,15 +190,15 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 
   // epilogue: lane (pixel r of tile mt, q) holds channels 4q .. 4q+3
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * q);
-  const size_t row_pix = ((size_t)img * p.H + y0 + wave) * p.W + x0;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
+    const size_t row_pix = ((size_t)img * p.H + y0 + wave * RW + mt / 2) * p.W + x0;
     f32x4 v = acc[mt] + b4;
     if (p.act) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * kLeakyAlpha;
     }
-    const size_t pix = row_pix + mt * 16 + r;
+    const size_t pix = row_pix + (mt % 2) * 16 + r;
     if (!TAIL) {
       *reinterpret_cast<f32x4*>(p.out + pix * p.out_cs + 4 * q) = v;
     } else {
@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   }
 }
 
-template <int KH, int KW, bool GS, bool TAIL>
+template <int KH, int KW, bool GS, bool TAIL, int RW>
 inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream) {
-  using C = ConvN16Cfg<KH, KW, GS, TAIL>;
-  auto kern = conv_n16_kernel<KH, KW, GS, TAIL>;
+  using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
+  auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW>;
   static bool attr_set = false;
   if (!attr_set && C::SMEM_BYTES > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);

@@ -216,11 +216,14 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       const int s = ch * T + t;
       const bool has1 = s + 1 < nsteps, has2 = s + 2 < nsteps;
       constexpr bool kRing1x1 = (T == 1 && INB == 3);
-      const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == T - 2 && more);
+      // input tiles stream from HBM (weights are L2 hits): issue their loads up to three taps before they are needed
+      constexpr int kInFetchTap = (T >= 4) ? T - 4 : 0;
+      constexpr int kInStoreTap = (INB == 2) ? T - 2 : T - 1;
+      const bool fetch_now = kRing1x1 ? has2 : (T > 1 && t == kInFetchTap && more);
+      const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == kInStoreTap && more);
       // (1) issue the global loads of step s+2 (and of the next input tile) — landed by the write point below
       if (has2) fetch_w(s + 2, w_regs);
-      if (stage_in) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs, in_ok);
-      if (INB == 1 && t == T - 1 && more) fetch_in(ch + 1, in_regs, in_ok);     // single buffer: keep the loads in flight
+      if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs, in_ok);
       __builtin_amdgcn_sched_barrier(0);
 
       // (2) MFMAs of tap t; group g+1's fragments (or step s+1's first group) are read before group g's MFMAs
