@@ -1,0 +1,192 @@
+"""Counterpart of the reference's inference harness: ``Config``, ``FSRNet.testFFHQ`` / ``FSRNet.test`` and the
+``Logging`` sink (/root/reference/train_test_GSC.py:18-79, 118-151, 360-422, 840-890; /root/reference/utils.py:196-233)
+with the same call surface, driving the HIP generator instead of the Keras model.
+
+Differences from the reference, all deliberate:
+* only the generator is constructed (the reference also builds 3 discriminators, 2 optimizers and downloads VGG19
+  even for testing: train_test_GSC.py:121-128);
+* a dataset element is ``(img[1,10,256,256,16], box[1,4], name)`` exactly as ``dataset.py`` yields it; the
+  reference runs the generator on all 10 rows and keeps row 0 (train_test_GSC.py:866-871, utils.py:231).  Rows are
+  independent at inference, so by default only row 0 of each element is computed and rows of several elements are
+  batched into one forward (``batch`` argument); ``all_rows=True`` reproduces the reference's 10-row forward;
+* ``test`` returns the generator outputs of the UCB path; the ~320 lines of dataset-specific numpy/cv2
+  post-processing behind it (train_test_GSC.py:424-748) are host code outside the hot path.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .model import Generator
+
+SPLIT_FFHQ = (3, 3, 3, 6, 1)      # img, gt, uv, reg, face  (train_test_GSC.py:419,870)
+
+
+class Config(object):
+    """Class-attribute configuration, as in the reference (train_test_GSC.py:18-51)."""
+    GPU_INDEX = 0
+    DATA_DIR_TEST = ['sample_imgs/*']
+    IMG_SIZE = 256
+    MAP_SIZE = 32
+    FIG_SIZE = 128
+    BATCH_SIZE = 1
+    CHECKPOINT_DIR = './log/test'
+
+    def __init__(self, gpu_idx: Optional[int] = None):
+        if gpu_idx is not None:
+            self.GPU_INDEX = gpu_idx
+
+    def compile(self) -> None:
+        os.makedirs(os.path.join(self.CHECKPOINT_DIR, 'test'), exist_ok=True)
+        print("\nConfigurations:")
+        for a in dir(self):
+            if not a.startswith("__") and not callable(getattr(self, a)) and a[0].isupper():
+                print("{:30} {}".format(a, getattr(self, a)))
+        print("\n")
+
+
+class Logging(object):
+    """utils.Logging counterpart (utils.py:127-253): running-mean text + PNG strips."""
+
+    def __init__(self, config: Config):
+        self.config = config
+        self.losses: Dict[str, List[float]] = {}
+        self.saved: List[str] = []
+
+    def display(self, losses: Dict[str, float], epoch: int, step: int, training: bool, allstep: int) -> None:
+        for k, v in losses.items():
+            acc = self.losses.setdefault(k, [0.0, 0])
+            acc[0] += float(v)
+            acc[1] += 1
+        txt = ''.join('%s:%.3g, ' % (k, s / max(c, 1)) for k, (s, c) in self.losses.items())
+        print('\r Testing ' + str(step + 1) + '/' + str(allstep) + ': ' + txt + '     ', end='', flush=True)
+
+    @staticmethod
+    def get_imgs(fig: Sequence[torch.Tensor]) -> np.ndarray:
+        """clip*255, grey -> 3 channels, take batch row 0, concatenate horizontally (utils.py:217-233).
+        Returned as RGB uint8 (the reference swaps to BGR only because cv2.imwrite expects BGR)."""
+        column = []
+        for img in fig:
+            img = torch.clamp(img[:1].detach().float().cpu(), 0.0, 1.0) * 255
+            if img.shape[3] == 1:
+                img = torch.cat([img, img, img], dim=3)
+            column.append(img[0, :, :, :3])
+        return np.rint(torch.cat(column, dim=1).numpy()).astype(np.uint8)
+
+    def save_img(self, fig: Sequence[torch.Tensor], fname: str) -> str:
+        strip = self.get_imgs(fig)
+        parts = fname.replace('\\', '/').split('/')
+        stem = (parts[-2] + '_' if len(parts) > 1 else '') + parts[-1].split('.')[0]
+        out = os.path.join(self.config.CHECKPOINT_DIR, 'test', stem + '-result.png')
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        from PIL import Image
+        Image.fromarray(strip).save(out)
+        self.saved.append(out)
+        return out
+
+
+def _name(x) -> str:
+    if isinstance(x, bytes):
+        return x.decode()
+    if isinstance(x, np.ndarray):
+        return _name(x.reshape(-1)[0])
+    return str(x)
+
+
+class FSRNet(object):
+    def __init__(self, config: Config, weights: Optional[Dict[str, np.ndarray]] = None):
+        self.config = config
+        self.gen = Generator(device=config.GPU_INDEX if torch.cuda.is_available() else None)
+        if weights is not None:
+            self.gen.load_weights(weights)
+        self.log = Logging(config)
+
+    # -- checkpoint -------------------------------------------------------------------------
+    def _restore(self) -> int:
+        last_epoch = self.gen.restore(self.config.CHECKPOINT_DIR) if self.gen._handle is None else -1
+        print('**********************************************************')
+        print('Restore from Epoch ' + (str(last_epoch) if last_epoch >= 0 else '(weights supplied)'))
+        print('**********************************************************')
+        if self.gen._handle is None:
+            raise RuntimeError("no generator weights: checkpoint data shard missing under %s" % self.config.CHECKPOINT_DIR)
+        return last_epoch
+
+    # -- steps ------------------------------------------------------------------------------
+    def _split(self, img: torch.Tensor, rows: Optional[int]) -> Tuple[torch.Tensor, ...]:
+        s = self.config.IMG_SIZE
+        img = torch.as_tensor(np.asarray(img) if not isinstance(img, torch.Tensor) else img, dtype=torch.float32)
+        img = img.reshape(-1, s, s, img.shape[-1])                         # [10,256,256,16] (train_test_GSC.py:866)
+        if rows is not None:
+            img = img[:rows]
+        return torch.split(img, list(SPLIT_FFHQ), dim=3)
+
+    def test_step_FFHQ(self, img, box=None, training: bool = False, all_rows: bool = False):
+        """train_test_GSC.py:863-890 for one dataset element."""
+        im, gt, uv, reg, face = self._split(img, None if all_rows else 1)
+        dev = "cuda:%d" % self.gen._device
+        _, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg, chuck=1, training=training)
+        mask_pred = mask_pred * face.to(dev)
+        con_rgb = torch.clamp(con_rgb, 0, 1)
+        return {}, [im.to(dev), con_rgb, mask_pred * 2]
+
+    def test_step(self, img, box=None, *masks, training: bool = False, all_rows: bool = False):
+        """Head of the UCB step (train_test_GSC.py:411-422): returns the generator outputs for the element."""
+        im, gt, uv, reg, face = self._split(img, None if all_rows else 1)
+        dev = "cuda:%d" % self.gen._device
+        gs, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg, chuck=4, training=training)
+        return {}, [im.to(dev), gs, con_rgb, mask_pred, gt.to(dev), face.to(dev)]
+
+    # -- loops ------------------------------------------------------------------------------
+    def _loop(self, dataset, batch: int, ucb: bool):
+        self._restore()
+        start = time.time()
+        names = list(dataset.name_list)
+        num_list = len(names)
+        results = []
+        pending: List[Tuple[int, str, torch.Tensor]] = []
+
+        def flush():
+            if not pending:
+                return
+            rows = torch.cat([self._split_row0(p[2]) for p in pending], dim=0)
+            im, gt, uv, reg, face = torch.split(rows, list(SPLIT_FFHQ), dim=3)
+            dev = "cuda:%d" % self.gen._device
+            gs, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg, chuck=4 if ucb else 1, training=False)
+            for j, (step, name, _) in enumerate(pending):
+                sl = slice(j, j + 1)
+                if ucb:
+                    figs = [im[sl].to(dev), gs[sl], con_rgb[sl], mask_pred[sl], gt[sl].to(dev), face[sl].to(dev)]
+                else:
+                    figs = [im[sl].to(dev), torch.clamp(con_rgb[sl], 0, 1), mask_pred[sl] * face[sl].to(dev) * 2]
+                self.log.display({}, 0, step, False, num_list)
+                self.log.save_img(figs[:3] if not ucb else [figs[0], torch.clamp(figs[2], 0, 1), figs[3] * figs[5] * 2], name)
+                results.append((name, figs))
+            pending.clear()
+
+        for step, img_name in enumerate(names):
+            element = next(dataset.feed)
+            img = element[0]
+            pending.append((step, _name(img_name), img))
+            if len(pending) >= batch:
+                flush()
+        flush()
+        print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
+        return results
+
+    def _split_row0(self, img) -> torch.Tensor:
+        s = self.config.IMG_SIZE
+        t = torch.as_tensor(np.asarray(img) if not isinstance(img, torch.Tensor) else img, dtype=torch.float32)
+        return t.reshape(-1, s, s, t.shape[-1])[:1]
+
+    def testFFHQ(self, dataset_val, batch: int = 16):
+        """train_test_GSC.py:840-860.  ``dataset_val`` needs ``.feed`` (iterator of (img[1,10,256,256,16], box, name))
+        and ``.name_list`` (dataset.py:29-30)."""
+        return self._loop(dataset_val, batch, ucb=False)
+
+    def test(self, dataset_val, batch: int = 16):
+        """train_test_GSC.py:360-408 (generator part; see module docstring)."""
+        return self._loop(dataset_val, batch, ucb=True)

@@ -67,9 +67,10 @@ def test_heads_decomposition(w):
     g = O.GeneratorOracle(w)
     ref_m = g.conv_block(torch.from_numpy(y), "conv2", bn=False, act=False).numpy()[0, ..., 0]
     ref_c = g.conv_block(torch.from_numpy(y), "conv3", bn=False, act=False).numpy()[0, ..., 0]
-    k, bias = packed(w, "heads")                                     # [7, 64, 32]
+    k, bias = packed(w, "heads")                                     # [7, 64, 16]
     assert np.all(bias == 0)
-    q = O.conv2d_same(torch.from_numpy(y), k.reshape(7, 1, 64, 32), bias, 1).numpy()
+    assert np.all(k[:, :, 14:] == 0)
+    q = O.conv2d_same(torch.from_numpy(y), k.reshape(7, 1, 64, 16), bias, 1).numpy()
     m = np.zeros((10, 12)); c = np.zeros((10, 12))
     for kx in range(7):
         for x in range(12):
@@ -97,16 +98,22 @@ def test_transposed_phase_decomposition(w):
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
-def test_clr_conv1_channel_rotation_and_qkv_order(w):
+def test_clr_conv1_gs_split_and_qkv_order(w):
+    """clr_conv1 over cat[gs, f] == 64-channel conv over f + a 9-tap im2col group over gs (conv_n16_kernel GS path)."""
     rng = np.random.default_rng(4)
     gs = rng.standard_normal((1, 6, 6, 1)).astype(np.float32)
     f = rng.standard_normal((1, 6, 6, 64)).astype(np.float32)
     ref = O.GeneratorOracle(w).conv_block(torch.from_numpy(np.concatenate([gs, f], -1)), "clr_conv1").numpy()
-    k, bias = packed(w, "clr_conv1")                                 # [9, 72, 32]
-    buf = np.concatenate([f, gs, np.zeros((1, 6, 6, 7), np.float32)], -1)
-    got = O.leaky_relu(O.conv2d_same(torch.from_numpy(buf), k.reshape(3, 3, 72, 32), bias, 1)).numpy()
-    np.testing.assert_allclose(got[..., :16], ref, atol=2e-5)
-    assert np.all(got[..., 16:] == 0)
+    k, bias = packed(w, "clr_conv1")                                 # [9, 64, 16]
+    wg = pack.clr_gs_weights(w)                                      # [16 n][16 k]
+    assert k.shape == (9, 64, 16) and wg.shape == (16, 16) and np.all(wg[:, 9:] == 0)
+    main = O.conv2d_same(torch.from_numpy(f), k.reshape(3, 3, 64, 16), bias, 1).numpy()
+    gsp = np.pad(gs[0, :, :, 0], 1)
+    extra = np.zeros((6, 6, 16))
+    for t in range(9):
+        extra += gsp[t // 3:t // 3 + 6, t % 3:t % 3 + 6, None] * wg[None, None, :, t]
+    got = O.leaky_relu(torch.from_numpy(main[0] + extra)).numpy()
+    np.testing.assert_allclose(got, ref[0], atol=2e-5)
     k, bias = packed(w, "res2.qkv")
     st = "res_stack/2/non_local/"
     for j, n in enumerate(("theta", "phi", "g")):
@@ -125,7 +132,7 @@ def test_blob_layout(w):
         name = name.rstrip(b"\0").decode()
         assert off % 16 == 0 and off + 4 * nfl <= len(blob)
         names[name] = (off, nfl, (d0, d1, d2, d3))
-    assert len(names) == n == 2 * len(pack.GEOMETRY) + 2
+    assert len(names) == n == 2 * len(pack.GEOMETRY) + 3
     off, nfl, dims = names["res0.conv1.w"]
     assert dims == (5, 1, 128, 28) and nfl == 5 * 128 * 28
     off, nfl, dims = names["up1.w"]
