@@ -49,6 +49,9 @@ struct ConvArgs {
   const float* res2;
   int res2_cs, res2_c;
   int tiles_x, tiles_y; // M tiles per image
+#ifdef BSR_STAMPS
+  unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
+#endif
 };
 
 // INB = number of LDS input-tile buffers: 1 (reload synchronously at chunk boundaries), 2 (taps > 1: next chunk's
@@ -86,6 +89,10 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   float* s_in = smem;
   float* s_w = smem + INB * C::IN_FLOATS;
 
+  // Prologue and epilogue are VALU/VMEM streams that share the SIMD with a co-resident wave's MFMA stream; at
+  // equal priority they get an issue slot only every few dozen cycles (measured: a 128-store epilogue took 41k
+  // cycles).  They run at raised priority; the MFMA main loop runs at priority 0.
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
@@ -112,6 +119,12 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) b_base[ni] = ((wn * NI + ni) * 32 + r) * LDP + 4 * h;
 
+  float bias_n[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + (wn * NI + ni) * 32 + r;
+    bias_n[ni] = p.bias[n < p.n_pad ? n : 0];
+  }
   f32x16 acc[NPH][MI][NI];
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
@@ -120,58 +133,66 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[ph][mi][ni][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[ph][mi][ni][i] = bias_n[ni];     // bias folded into the accumulator start value
 
-  // global -> register fetch of one input-tile chunk.  Loads are UNCONDITIONAL (clamped address) so hipcc
-  // keeps them in flight across the MFMAs; out-of-image pixels (TF SAME zero padding) are zeroed at store time
-  // from a per-thread validity bitmask.
-  auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD], unsigned& okmask) {
-    okmask = 0u;
+  // Staging addresses are "wave-uniform base + per-thread constant": the per-thread byte offsets (global source,
+  // LDS destination) and the zero-padding mask are computed ONCE here; per chunk / per tap only the scalar base
+  // moves, so the loads inside the MFMA loop cost no VALU address arithmetic.  Loads are unconditional (clamped
+  // address); out-of-image pixels (TF SAME zero padding) are zeroed at LDS-store time.
+  unsigned in_goff[C::IN_PER_THREAD], w_off[C::W_PER_THREAD];
+  int in_loff[C::IN_PER_THREAD];
+  unsigned in_okmask = 0u;
 #pragma unroll
-    for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-      int idx = tid + i * 256;
-      idx = idx < C::IN_V4 ? idx : C::IN_V4 - 1;
-      const int pix = idx / (CC / 4), q = idx % (CC / 4);
-      const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-      regs[i] = *reinterpret_cast<const f32x4*>(in_img + ((size_t)iyc * p.W + ixc) * p.in_cs + ch * CC + q * 4);
-      okmask |= (ok ? 1u : 0u) << i;
-    }
+  for (int i = 0; i < C::IN_PER_THREAD; ++i) {
+    const int idx0 = tid + i * 256;
+    const int idx = idx0 < C::IN_V4 ? idx0 : C::IN_V4 - 1;
+    const int pix = idx / (CC / 4), q = idx % (CC / 4);
+    const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+    const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+    in_goff[i] = (unsigned)(((iyc * p.W + ixc) * p.in_cs + q * 4) * 4);
+    in_loff[i] = idx0 < C::IN_V4 ? pix * LDP + q * 4 : -1;
+    in_okmask |= (ok ? 1u : 0u) << i;
+  }
+#pragma unroll
+  for (int i = 0; i < C::W_PER_THREAD; ++i) {
+    const int idx0 = tid + i * 256;
+    w_off[i] = (unsigned)((idx0 < C::W_V4 ? idx0 : C::W_V4 - 1) * 16);
+  }
+  auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
+    const char* base = reinterpret_cast<const char*>(in_img + ch * CC);
+#pragma unroll
+    for (int i = 0; i < C::IN_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + in_goff[i]);
   };
-  auto store_in = [&](int off, const f32x4 (&regs)[C::IN_PER_THREAD], unsigned okmask) {
+  auto store_in = [&](int off, const f32x4 (&regs)[C::IN_PER_THREAD]) {
 #pragma unroll
     for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < C::IN_V4) {
-        const int pix = idx / (CC / 4), q = idx % (CC / 4);
+      if (in_loff[i] >= 0) {
         f32x4 v = regs[i];
-        if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(s_in + off + pix * LDP + q * 4) = v;
+        if (!((in_okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(s_in + off + in_loff[i]) = v;
       }
     }
   };
   auto fetch_w = [&](int step, f32x4 (&regs)[C::W_PER_THREAD]) {
-    const float* src = p.w + ((size_t)step * p.n_pad + n0) * LDP;
+    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDP);
 #pragma unroll
-    for (int i = 0; i < C::W_PER_THREAD; ++i) {
-      int idx = tid + i * 256;
-      idx = idx < C::W_V4 ? idx : C::W_V4 - 1;
-      regs[i] = *reinterpret_cast<const f32x4*>(src + idx * 4);
-    }
+    for (int i = 0; i < C::W_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + w_off[i]);
   };
   auto store_w = [&](int off, const f32x4 (&regs)[C::W_PER_THREAD]) {
-    float* dst = s_w + off;
+    char* dst = reinterpret_cast<char*>(s_w + off);
 #pragma unroll
     for (int i = 0; i < C::W_PER_THREAD; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < C::W_V4) *reinterpret_cast<f32x4*>(dst + idx * 4) = regs[i];
+      if (tid + i * 256 < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
     }
   };
 
+#ifdef BSR_STAMPS
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0;
+  unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   f32x4 in_regs[C::IN_PER_THREAD];
   f32x4 w_regs[C::W_PER_THREAD];
-  unsigned in_ok = 0u;
   const int nsteps = p.nchunk * T;
 
   // LDS ring offsets (floats): weights of step s / s+1 / s+2; input tile of the current / next(+1) / next(+2) chunk
@@ -179,16 +200,16 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   int in_cur = 0, in_n1 = (INB > 1) ? C::IN_FLOATS : 0, in_n2 = (INB > 2) ? 2 * C::IN_FLOATS : 0;
 
   // prologue: steps 0 and 1 staged synchronously
-  fetch_in(0, in_regs, in_ok);
+  fetch_in(0, in_regs);
   fetch_w(0, w_regs);
-  store_in(0, in_regs, in_ok);
+  store_in(0, in_regs);
   store_w(0, w_regs);
   if (nsteps > 1) {
     fetch_w(1, w_regs);
     store_w(w_n1, w_regs);
     if (T == 1 && INB == 3) {
-      fetch_in(1, in_regs, in_ok);
-      store_in(in_n1, in_regs, in_ok);
+      fetch_in(1, in_regs);
+      store_in(in_n1, in_regs);
     }
   }
   __syncthreads();
@@ -208,6 +229,10 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
     return ((t / KW) * IW + (t % KW)) * LDP;
   };
   read_frags(0, in_cur + tap_offset(0), w_cur);
+  __builtin_amdgcn_s_setprio(0);
+#ifdef BSR_STAMPS
+  st1 = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int ch = 0; ch < p.nchunk; ++ch) {
     const bool more = ch + 1 < p.nchunk;
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == kInStoreTap && more);
       // (1) issue the global loads of step s+2 (and of the next input tile) — landed by the write point below
       if (has2) fetch_w(s + 2, w_regs);
-      if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs, in_ok);
+      if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs);
       __builtin_amdgcn_sched_barrier(0);
 
       // (2) MFMAs of tap t; group g+1's fragments (or step s+1's first group) are read before group g's MFMAs
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
         }
         if (g == G - 1) {                                                           // write point: stage step s+2
           if (has2) store_w(w_n2, w_regs);
-          if (stage_in) store_in(kRing1x1 ? in_n2 : in_n1, in_regs, in_ok);
+          if (stage_in) store_in(kRing1x1 ? in_n2 : in_n1, in_regs);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       // (3) one barrier per step publishes what was staged and frees the slot read in this step
       __syncthreads();
       if (INB == 1 && t == T - 1 && more) {          // single input buffer: swap it between chunks (2 barriers)
-        store_in(0, in_regs, in_ok);
+        store_in(0, in_regs);
         __syncthreads();
         read_frags(((T * G) & 1), tap_offset(0), w_n1);
       }
@@ -275,6 +300,10 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
     }
   }
 
+  __builtin_amdgcn_s_setprio(3);
+#ifdef BSR_STAMPS
+  st2 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: bias (+ residuals) + LeakyReLU, NHWC store (32 consecutive channels per half-wave) ----
   // With TW == 32 a wave's 32 pixels are one tile row, so every element address is a wave-uniform base plus a
   // 32-bit lane offset plus a compile-time multiple of the pixel stride: no 64-bit per-element arithmetic.
@@ -283,53 +312,68 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   static_assert(TW == 32, "epilogue assumes one tile row per 32-pixel MFMA tile");
   constexpr int SX = TR ? 2 : 1;
   const size_t blk_pix = (size_t)img * p.Ho * p.Wo + (size_t)(SX * y0) * p.Wo + SX * x0;
-  float* out_blk = p.out + blk_pix * p.out_cs + p.out_coff;
   const bool has_res = p.res1 != nullptr;      // res1 and res2 come together (NonLocal residual + block skip)
-  const float* res1_blk = has_res ? p.res1 + blk_pix * p.res1_cs : nullptr;
-  const float* res2_blk = has_res ? p.res2 + blk_pix * p.res2_cs : nullptr;
+  // per-lane constant parts (elements): register 0 of this lane is pixel column SX*4*h, channel r of the tile
+  const unsigned lane_out = (unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r;
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + (wn * NI + ni) * 32 + r;
+        const int nt = n0 + (wn * NI + ni) * 32;           // first channel of this 32-wide tile (uniform)
+        const int n = nt + r;
         const bool n_ok = n < p.n_store;
-        const float bias = p.bias[n_ok ? n : 0];
         const int ty = wm * MI + mi;
-        // pixel index (relative to the block origin) of this lane's register 0
-        const unsigned pix0 = (unsigned)((SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0) + SX * 4 * h);
+        // wave-uniform pixel index of this tile's register-0 row, relative to the block origin
+        const size_t tile_pix = blk_pix + (size_t)(SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0);
         f32x16 v = acc[ph][mi][ni];
         if (has_res) {
           const bool ok1 = n < p.res1_c, ok2 = n < p.res2_c;
-          const unsigned b1 = pix0 * (unsigned)p.res1_cs + (ok1 ? n : 0), b2 = pix0 * (unsigned)p.res2_cs + (ok2 ? n : 0);
           const float m1 = ok1 ? 1.f : 0.f, m2 = ok2 ? 1.f : 0.f;
+          const unsigned l1 = (unsigned)(SX * 4 * h) * (unsigned)p.res1_cs + (unsigned)(ok1 ? r : 0);
+          const unsigned l2 = (unsigned)(SX * 4 * h) * (unsigned)p.res2_cs + (unsigned)(ok2 ? r : 0);
+          const int nt1 = nt < p.res1_c ? nt : 0, nt2 = nt < p.res2_c ? nt : 0;
           float r1[16], r2[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const unsigned k = (unsigned)(SX * ((i & 3) + 8 * (i >> 2)));
-            r1[i] = res1_blk[b1 + k * (unsigned)p.res1_cs];
-            r2[i] = res2_blk[b2 + k * (unsigned)p.res2_cs];
+            const int k = SX * ((i & 3) + 8 * (i >> 2));
+            const float* b1 = p.res1 + (tile_pix + k) * p.res1_cs + nt1;      // uniform
+            const float* b2 = p.res2 + (tile_pix + k) * p.res2_cs + nt2;
+            r1[i] = b1[l1];
+            r2[i] = b2[l2];
           }
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = (v[i] + bias) + (r1[i] * m1 + r2[i] * m2);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] += bias;
+          for (int i = 0; i < 16; ++i) v[i] += r1[i] * m1 + r2[i] * m2;
         }
         if (p.act) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * kLeakyAlpha;
+          for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], v[i] * kLeakyAlpha);       // LeakyReLU(0.3) = max(x, 0.3x)
         }
         if (n_ok) {
-          const unsigned ob = pix0 * (unsigned)p.out_cs + (unsigned)n;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const unsigned k = (unsigned)(SX * ((i & 3) + 8 * (i >> 2)));
-            out_blk[ob + k * (unsigned)p.out_cs] = v[i];
+            const int k = SX * ((i & 3) + 8 * (i >> 2));
+            float* ob = p.out + (tile_pix + k) * p.out_cs + p.out_coff + nt;   // uniform
+#if defined(BSR_EPI_SKIP)
+            if (v[i] == 12345.678f) ob[lane_out] = v[i];
+#else
+            ob[lane_out] = v[i];
+#endif
           }
         }
       }
+#ifdef BSR_STAMPS
+  unsigned long long st2b = __builtin_amdgcn_s_memtime();
+  if (p.stamps != nullptr && lane == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long st3 = __builtin_amdgcn_s_memtime();
+
+    unsigned long long* d = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+    unsigned long long rt3 = __builtin_amdgcn_s_memrealtime();
+    d[0] = st1 - st0; d[1] = st2 - st1; d[2] = ((rt3 - rt0) << 32) | (st2b - st2); d[3] = st3 - st2;
+  }
+#endif
 }
 
 template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>

@@ -1,0 +1,65 @@
+// Diagnostic harness (not product code): times one igemm_conv_kernel configuration on random data and, with
+// -DBSR_STAMPS, reports where a wave's cycles go (prologue / main loop / epilogue).
+#define BSR_STAMPS 1
+#include "../blindshadowremoval_amd/csrc/igemm_conv.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+using namespace bsr;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int KH, int KW, int S, bool TR, int NI, int CC, int INB>
+int run(const char* name, int B, int H, int W, int Cin, int Cout) {
+  using C = ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
+  const int T = KH * KW, nchunk = Cin / CC, n_pad = ((Cout + C::BN - 1) / C::BN) * C::BN;
+  const int Ho = TR ? 2 * H : H / S, Wo = TR ? 2 * W : W / S;
+  size_t n_in = (size_t)B * H * W * Cin, n_out = (size_t)B * Ho * Wo * Cout, n_w = (size_t)nchunk * T * n_pad * (CC + 4);
+  std::vector<float> h_in(n_in), h_w(n_w);
+  for (auto& v : h_in) v = (float)rand() / RAND_MAX - 0.5f;
+  for (auto& v : h_w) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+  float *d_in, *d_out, *d_w, *d_b;
+  CK(hipMalloc(&d_in, n_in * 4)); CK(hipMalloc(&d_out, n_out * 4)); CK(hipMalloc(&d_w, n_w * 4)); CK(hipMalloc(&d_b, n_pad * 4));
+  CK(hipMemcpy(d_in, h_in.data(), n_in * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_w, h_w.data(), n_w * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(d_b, 0, n_pad * 4));
+  ConvArgs a{};
+  a.in = d_in; a.in_cs = Cin; a.in_coff = 0; a.H = H; a.W = W; a.out = d_out; a.out_cs = Cout; a.out_coff = 0; a.Ho = Ho; a.Wo = Wo;
+  a.w = d_w; a.bias = d_b; a.nchunk = nchunk; a.n_pad = n_pad; a.n_store = Cout; a.pad_t = (S == 2) ? 0 : (KH - 1) / 2; a.pad_l = (S == 2) ? 0 : (KW - 1) / 2; a.act = 1;
+  const int mh = TR ? H : Ho, mw = TR ? W : Wo;
+  size_t nblk = (size_t)(mw / 32) * (mh / 4) * B * (n_pad / C::BN);
+  unsigned long long* d_st;
+  CK(hipMalloc(&d_st, nblk * 16 * 8));
+  a.stamps = d_st;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e9;
+  for (int it = 0; it < 6; ++it) {
+    CK(hipEventRecord(e0));
+    CK((launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, B, 0)));
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it > 0) best = std::min(best, ms);
+  }
+  std::vector<unsigned long long> st(nblk * 16);
+  CK(hipMemcpy(st.data(), d_st, nblk * 16 * 8, hipMemcpyDeviceToHost));
+  double pro = 0, loop = 0, epi = 0, epi_issue = 0;
+  double rt = 0;
+  for (size_t i = 0; i < nblk * 4; ++i) { pro += st[i * 4]; loop += st[i * 4 + 1]; epi_issue += (st[i * 4 + 2] & 0xffffffffull); rt += (double)(st[i * 4 + 2] >> 32); epi += st[i * 4 + 3]; }
+  printf("   wave lifetime %.0f cycles = %.0f ticks of the 100 MHz realtime counter -> shader clock %.2f GHz\n", (pro + loop + epi) / (nblk * 4.0), rt / (nblk * 4.0), (pro + loop + epi) / rt * 0.1);
+  double nw = nblk * 4.0;
+  double flops = 2.0 * B * (TR ? H * W : Ho * Wo) * (double)T * Cin * Cout;
+  double mfma_per_wave = (double)nchunk * T * (CC / 2) * NI;       // MFMAs a wave issues
+  printf("%-10s %7.1f us  %6.1f TFLOP/s | blocks %zu, per wave (cycles): prologue %.0f  loop %.0f  epilogue %.0f (issue %.0f) | loop ticks per MFMA %.2f\n",
+         name, best * 1e3, flops / best / 1e9, nblk, pro / nw, loop / nw, epi / nw, epi_issue / nw, loop / nw / mfma_per_wave);
+  hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_st);
+  return 0;
+}
+
+int main() {
+  if (run<3, 3, 1, true, 2, 32, 1>("up3", 32, 128, 128, 128, 64)) return 1;
+  if (run<3, 3, 1, true, 2, 32, 2>("up3/inb2", 32, 128, 128, 128, 64)) return 1;
+  if (run<3, 3, 1, true, 1, 32, 1>("up3/ni1", 32, 128, 128, 128, 64)) return 1;
+  if (run<3, 3, 1, false, 2, 32, 1>("res.conv2", 32, 32, 32, 128, 128)) return 1;
+  if (run<3, 3, 1, false, 4, 32, 1>("conv2/ni4", 32, 32, 32, 128, 128)) return 1;
+  if (run<1, 1, 1, false, 3, 32, 3>("res.conv3", 32, 32, 32, 128, 264)) return 1;
+  if (run<1, 1, 1, false, 4, 24, 3>("qkv", 32, 32, 32, 264, 384)) return 1;
+  return 0;
+}
