@@ -14,6 +14,7 @@
 
 #include "attention.h"
 #include "conv_n16.h"
+#include "gemm_nloop.h"
 #include "glue_kernels.h"
 #include "igemm_conv.h"
 
@@ -162,7 +163,8 @@ struct Launcher {
   template <int KH, int KW, int S, bool TR, int NI, int CC, int INB>
   void conv(int cls, const char* name, const float* in, int in_cs, int in_coff, int k_pad, int H, int W, float* out, int out_cs,
             int out_coff, int n_store, int act, const float* res1 = nullptr, int res1_cs = 0, int res1_c = 0,
-            const float* res2 = nullptr, int res2_cs = 0, int res2_c = 0) {
+            const float* res2 = nullptr, int res2_cs = 0, int res2_c = 0, float* out2 = nullptr, int out2_cs = 0, int n_split = 0,
+            int n_store1 = 0) {
     if (rc != BSR_OK) return;
     using C = bsr::ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
     LayerW l;
@@ -185,6 +187,7 @@ struct Launcher {
     a.act = act;
     a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c;
     a.res2 = res2; a.res2_cs = res2_cs; a.res2_c = res2_c;
+    a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
     const int mh = TR ? H : a.Ho, mw = TR ? W : a.Wo;
     if (mh % 4 != 0 || mw % 32 != 0) {
       rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': feature map is not a multiple of the 4x32 tile");
@@ -194,6 +197,28 @@ struct Launcher {
     check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
     end();
   }
+  // 1x1 conv as a resident-activation GEMM (K = NCH*32) over all N
+  template <int NI, int NCH>
+  void gemm(int cls, const char* name, const float* in, int in_cs, size_t pixels, float* out, int out_cs, int n_store, int act,
+            const float* res1 = nullptr, int res1_cs = 0, int res1_c = 0, const float* res2 = nullptr, int res2_cs = 0, int res2_c = 0,
+            float* out2 = nullptr, int out2_cs = 0, int n_split = 0, int n_store1 = 0) {
+    if (rc != BSR_OK) return;
+    using C = bsr::GemmNLoopCfg<NI, NCH>;
+    LayerW l;
+    const int ng = (n_store + C::BN - 1) / C::BN;
+    rc = find_layer(h, name, NCH, 1, 36, ng * C::BN, &l);
+    if (rc != BSR_OK) return;
+    if (pixels % C::BM != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': pixel count is not a multiple of 128"); return; }
+    bsr::ConvArgs a{};
+    a.in = in; a.in_cs = in_cs; a.in_coff = 0; a.out = out; a.out_cs = out_cs; a.out_coff = 0;
+    a.w = l.w; a.bias = l.b; a.nchunk = l.nchunk; a.n_pad = l.n_pad; a.n_store = n_store; a.act = act;
+    a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c; a.res2 = res2; a.res2_cs = res2_cs; a.res2_c = res2_c;
+    a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
+    begin(cls);
+    check(bsr::launch_gemm_nloop<NI, NCH>(a, pixels, s), name);
+    end();
+  }
+
   template <int KH, int KW, bool GS, bool TAIL, int RW>
   void conv16(int cls, const char* name, const float* in, int in_cs, int H, int W, float* out, int out_cs, int act, const float* gs,
               const float* inputs, float* con_rgb, float* dif) {
@@ -393,10 +418,10 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
     L.conv<1, 1, 1, false, 2, 24, 3>(K_CONV1, nm, x, x_cs, 0, x_cs, H8, W8, ws + p.t1, 128, 0, 128, 1);
     snprintf(nm, sizeof nm, "res%d.conv2", i);
     L.conv<3, 3, 1, false, 2, 32, 1>(K_CONV3, nm, ws + p.t1, 128, 0, 128, H8, W8, ws + p.t2, 128, 0, 128, 1);
-    snprintf(nm, sizeof nm, "res%d.conv3", i);
-    L.conv<1, 1, 1, false, 3, 32, 3>(K_CONV1, nm, ws + p.t2, 128, 0, 128, H8, W8, y3, CS_RES, 0, CS_RES, 0);
-    snprintf(nm, sizeof nm, "res%d.qkv", i);
-    L.conv<1, 1, 1, false, 4, 24, 3>(K_CONV1, nm, y3, CS_RES, 0, CS_RES, H8, W8, ws + p.qkv, 384, 0, 384, 0);
+    // conv3+BN (128 -> 257 = y3) and theta|phi|g (257 -> 3x128, no activation in between: model.py:101,33-46) as ONE
+    // K = 128 GEMM: the qkv weights are composed offline with conv3's (pack.py), N = [y3 288 | qkv 384]
+    snprintf(nm, sizeof nm, "res%d.c3q", i);
+    L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_RES, 288 + 384, 0, nullptr, 0, 0, nullptr, 0, 0, ws + p.qkv, 384, 288, CS_RES);
     if (L.rc == BSR_OK) {
       L.begin(K_ATT);
       L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
@@ -404,8 +429,7 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
     }
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113)
     snprintf(nm, sizeof nm, "res%d.w", i);
-    L.conv<1, 1, 1, false, 3, 32, 3>(K_CONV1, nm, ws + p.att[i], 128, 0, 128, H8, W8, ws + p.r[i], CS_RES, 0, CS_RES, 1, x, x_cs, x_cs,
-                                         y3, CS_RES, CS_RES);
+    L.gemm<3, 4>(K_CONV1, nm, ws + p.att[i], 128, ncell, ws + p.r[i], CS_RES, CS_RES, 1, x, x_cs, x_cs, y3, CS_RES, CS_RES);
   };
   if ((H8 * W8) % 128 != 0) return fail(BSR_ERR_ARG, "bsr_forward: (H/8)*(W/8) must be a multiple of 128");
   res_block(0, ws + p.xa, CS_XA);

@@ -1,0 +1,205 @@
+// 1x1-convolution GEMM with a RESIDENT activation tile: out[px][n] = act(sum_k x[px][k] * W[k][n] + b[n] (+ residuals)).
+//
+// The bottleneck blocks run three K = 128 GEMMs per block with wide N (conv3 | theta|phi|g : N = 672, w : N = 288;
+// /root/reference/model.py:86,10-13,101-102,56-59).  With one workgroup per (128-pixel, 96-channel) tile the K loop is only four
+// steps long and prologue + epilogue cost as much as the MFMAs.  Here a workgroup owns 128 pixels for ALL N:
+// the [128][K] activation tile is staged in LDS once, the weights stream through the same 3-slot LDS ring as
+// igemm_conv_kernel, continuously across the N groups (no pipeline drain between groups), and each 96-channel group
+// ends with its own fused epilogue.  Same fragment scheme (v_mfma_f32_32x32x2_f32, ds_read_b128, K permuted
+// identically in A and B).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "igemm_conv.h"
+
+namespace bsr {
+
+template <int NI, int NCH>   // NI 32-wide channel tiles per group, NCH = K / 32 resident chunks
+struct GemmNLoopCfg {
+  static constexpr int CC = 32, LDP = 36, G = 4, BM = 128, BN = NI * 32;
+  static constexpr int IN_FLOATS = BM * LDP;                 // one K chunk of the activation tile
+  static constexpr int W_FLOATS = BN * LDP;
+  static constexpr int SMEM_BYTES = (NCH * IN_FLOATS + 3 * W_FLOATS) * 4;
+  static constexpr int IN_V4 = BM * (CC / 4);
+  static constexpr int IN_PER_THREAD = IN_V4 / 256;          // 4
+  static constexpr int W_V4 = W_FLOATS / 4;
+  static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// ConvArgs use: in/in_cs/in_coff (K = NCH*32 channels), H*W = pixels per image (flattened, multiple of 128),
+// w packed [NCH][1][n_pad][36], bias[n_pad], out/out_cs/out_coff/n_store (+ out2/n_split/n_store1), act, res1/res2.
+template <int NI, int NCH>
+__global__ __launch_bounds__(256, 1) void gemm_nloop_kernel(ConvArgs p) {
+  using C = GemmNLoopCfg<NI, NCH>;
+  constexpr int LDP = C::LDP, BN = C::BN, G = C::G;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;
+  float* s_w = smem + NCH * C::IN_FLOATS;
+
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const size_t pix0 = (size_t)blockIdx.x * C::BM;            // first pixel of this block (flattened B*H*W index)
+  const int ngroups = (p.n_store + BN - 1) / BN;
+  const int nsteps = ngroups * NCH;
+
+  const int a_base = (wave * 32 + r) * LDP + 4 * h;
+  int b_base[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) b_base[ni] = (ni * 32 + r) * LDP + 4 * h;
+
+  unsigned w_off[C::W_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < C::W_PER_THREAD; ++i) {
+    const int idx0 = tid + i * 256;
+    w_off[i] = (unsigned)((idx0 < C::W_V4 ? idx0 : C::W_V4 - 1) * 16);
+  }
+  auto fetch_w = [&](int s, f32x4 (&regs)[C::W_PER_THREAD]) {      // step s = (group, chunk)
+    const int ng = s / NCH, ch = s % NCH;
+    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)ch * p.n_pad + (size_t)ng * BN) * LDP);
+#pragma unroll
+    for (int i = 0; i < C::W_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + w_off[i]);
+  };
+  auto store_w = [&](int off, const f32x4 (&regs)[C::W_PER_THREAD]) {
+    char* dst = reinterpret_cast<char*>(s_w + off);
+#pragma unroll
+    for (int i = 0; i < C::W_PER_THREAD; ++i)
+      if (tid + i * 256 < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
+  };
+
+  // ---- prologue: the whole [128][K] activation tile + weight steps 0 and 1 ----
+  f32x4 w_regs[C::W_PER_THREAD];
+  {
+    const float* in_blk = p.in + pix0 * p.in_cs + p.in_coff;
+    f32x4 a_regs[NCH][C::IN_PER_THREAD];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int i = 0; i < C::IN_PER_THREAD; ++i) {
+        const int idx = tid + i * 256, px = idx / 8, q = idx % 8;
+        a_regs[ch][i] = *reinterpret_cast<const f32x4*>(in_blk + (size_t)px * p.in_cs + ch * 32 + q * 4);
+      }
+    fetch_w(0, w_regs);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int i = 0; i < C::IN_PER_THREAD; ++i) {
+        const int idx = tid + i * 256, px = idx / 8, q = idx % 8;
+        *reinterpret_cast<f32x4*>(s_in + ch * C::IN_FLOATS + px * LDP + q * 4) = a_regs[ch][i];
+      }
+    store_w(0, w_regs);
+    if (nsteps > 1) {
+      fetch_w(1, w_regs);
+      store_w(C::W_FLOATS, w_regs);
+    }
+  }
+  __syncthreads();
+
+  int w_cur = 0, w_n1 = C::W_FLOATS, w_n2 = 2 * C::W_FLOATS;
+  f32x4 af[2], bf[2][NI];
+  auto read_frags = [&](int slot, int a_off, int b_off) {
+    af[slot] = *reinterpret_cast<const f32x4*>(s_in + a_base + a_off);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_w + b_base[ni] + b_off);
+  };
+  read_frags(0, 0, w_cur);
+  __builtin_amdgcn_s_setprio(0);
+
+  const bool has_res = p.res1 != nullptr;
+  const unsigned lane_out = (unsigned)(4 * h) * (unsigned)p.out_cs + (unsigned)r;
+  const unsigned lane_out2 = (unsigned)(4 * h) * (unsigned)p.out2_cs + (unsigned)r;
+  const size_t tile_pix = pix0 + wave * 32;                   // this wave's 32 consecutive pixels
+
+  for (int ng = 0; ng < ngroups; ++ng) {
+    f32x16 acc[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = ng * BN + ni * 32 + r;
+      const float b = p.bias[n < p.n_pad ? n : 0];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ni][i] = b;
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int s = ng * NCH + ch;
+      const bool has1 = s + 1 < nsteps, has2 = s + 2 < nsteps;
+      if (has2) fetch_w(s + 2, w_regs);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int cur = g & 1, nxt = cur ^ 1;                 // G is even: every step starts on slot 0
+        if (g + 1 < G) {
+          read_frags(nxt, ch * C::IN_FLOATS + (g + 1) * 8, w_cur + (g + 1) * 8);
+        } else if (has1) {
+          read_frags(nxt, ((ch + 1) % NCH) * C::IN_FLOATS, w_n1);
+        }
+        if (g == G - 1 && has2) store_w(w_n2, w_regs);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][j], bf[cur][ni][j], acc[ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = tw;
+    }
+
+    // ---- epilogue of this channel group (same form as igemm_conv_kernel's) ----
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nt = ng * BN + ni * 32;
+      const int n = nt + r;
+      const bool second = p.out2 != nullptr && nt >= p.n_split;
+      const bool n_ok = second ? n < p.n_store : (p.out2 != nullptr ? n < p.n_store1 : n < p.n_store);
+      f32x16 v = acc[ni];
+      if (has_res) {
+        const bool ok1 = n < p.res1_c, ok2 = n < p.res2_c;
+        const float m1 = ok1 ? 1.f : 0.f, m2 = ok2 ? 1.f : 0.f;
+        const unsigned l1 = (unsigned)(4 * h) * (unsigned)p.res1_cs + (unsigned)(ok1 ? r : 0);
+        const unsigned l2 = (unsigned)(4 * h) * (unsigned)p.res2_cs + (unsigned)(ok2 ? r : 0);
+        const int nt1 = nt < p.res1_c ? nt : 0, nt2 = nt < p.res2_c ? nt : 0;
+        float r1[16], r2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = (i & 3) + 8 * (i >> 2);
+          r1[i] = (p.res1 + (tile_pix + k) * p.res1_cs + nt1)[l1];
+          r2[i] = (p.res2 + (tile_pix + k) * p.res2_cs + nt2)[l2];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += r1[i] * m1 + r2[i] * m2;
+      }
+      if (p.act) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], v[i] * kLeakyAlpha);
+      }
+      if (n_ok) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = (i & 3) + 8 * (i >> 2);
+          float* ob = second ? p.out2 + (tile_pix + k) * p.out2_cs + (nt - p.n_split) : p.out + (tile_pix + k) * p.out_cs + p.out_coff + nt;
+          ob[second ? lane_out2 : lane_out] = v[i];
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+}
+
+template <int NI, int NCH>
+inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, hipStream_t stream) {
+  using C = GemmNLoopCfg<NI, NCH>;
+  auto kern = gemm_nloop_kernel<NI, NCH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total_pixels / C::BM)), dim3(256), C::SMEM_BYTES, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace bsr

@@ -42,6 +42,9 @@ struct ConvArgs {
   const float* bias;    // [n_pad]
   int nchunk, n_pad;
   int n_store;          // channels [0, n_store) are written
+  float* out2;          // optional second destination: channels [n_split, n_store) go to out2[.., n - n_split]
+  int out2_cs, n_split; // (n_split is a multiple of 32; channels [n_store1, n_split) of the first range are dropped)
+  int n_store1;         // with out2: channels [0, n_store1) go to `out`
   int pad_t, pad_l;     // TF SAME pad-before (rows, cols); unused for transposed
   int act;              // 1: LeakyReLU(0.3)
   const float* res1;    // optional residuals, NHWC at the OUTPUT resolution, added before the activation
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   const bool has_res = p.res1 != nullptr;      // res1 and res2 come together (NonLocal residual + block skip)
   // per-lane constant parts (elements): register 0 of this lane is pixel column SX*4*h, channel r of the tile
   const unsigned lane_out = (unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r;
+  const unsigned lane_out2 = (unsigned)(SX * 4 * h) * (unsigned)p.out2_cs + (unsigned)r;
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
@@ -323,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       for (int ni = 0; ni < NI; ++ni) {
         const int nt = n0 + (wn * NI + ni) * 32;           // first channel of this 32-wide tile (uniform)
         const int n = nt + r;
-        const bool n_ok = n < p.n_store;
+        const bool second = p.out2 != nullptr && nt >= p.n_split;            // uniform per tile
+        const bool n_ok = second ? n < p.n_store : (p.out2 != nullptr ? n < p.n_store1 : n < p.n_store);
         const int ty = wm * MI + mi;
         // wave-uniform pixel index of this tile's register-0 row, relative to the block origin
         const size_t tile_pix = blk_pix + (size_t)(SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0);
@@ -354,11 +359,12 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int k = SX * ((i & 3) + 8 * (i >> 2));
-            float* ob = p.out + (tile_pix + k) * p.out_cs + p.out_coff + nt;   // uniform
+            float* ob = second ? p.out2 + (tile_pix + k) * p.out2_cs + (nt - p.n_split)
+                               : p.out + (tile_pix + k) * p.out_cs + p.out_coff + nt;   // uniform
 #if defined(BSR_EPI_SKIP)
             if (v[i] == 12345.678f) ob[lane_out] = v[i];
 #else
-            ob[lane_out] = v[i];
+            ob[second ? lane_out2 : lane_out] = v[i];
 #endif
           }
         }

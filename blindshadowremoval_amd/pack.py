@@ -36,8 +36,7 @@ for _i in range(N_RES):
     _cin_pad = 120 if _i == 0 else 264
     GEOMETRY["res%d.conv1" % _i] = (24, _cin_pad, 128)
     GEOMETRY["res%d.conv2" % _i] = (32, 128, 128)
-    GEOMETRY["res%d.conv3" % _i] = (32, 128, 288)
-    GEOMETRY["res%d.qkv" % _i] = (24, 264, 384)
+    GEOMETRY["res%d.c3q" % _i] = (32, 128, 672)       # [y3: 257 real of 288 | theta|phi|g: 384]
     GEOMETRY["res%d.w" % _i] = (32, 128, 288)
 
 
@@ -96,11 +95,19 @@ def layer_matrices(w: Dict[str, np.ndarray]) -> "Dict[str, Tuple[np.ndarray, np.
         st = "res_stack/%d/" % i
         out["res%d.conv1" % i] = fold_bn(hwio(st + "conv1"), w[st + "conv1/bias"], _bn(w, st + "bnorm1"))
         out["res%d.conv2" % i] = fold_bn(hwio(st + "conv2"), w[st + "conv2/bias"], _bn(w, st + "bnorm2"))
-        out["res%d.conv3" % i] = fold_bn(hwio(st + "conv3"), w[st + "conv3/bias"], _bn(w, st + "bnorm3"))
-        # theta | phi | g share their input: one GEMM with N = 3 x 128 (query, key, value order of the attention kernel)
-        qkv = np.concatenate([hwio(st + "non_local/" + n) for n in ("theta", "phi", "g")], axis=2)
-        qb = np.concatenate([w[st + "non_local/%s/bias" % n] for n in ("theta", "phi", "g")])
-        out["res%d.qkv" % i] = (qkv.astype(np.float64), qb.astype(np.float64))
+        # conv3 + bnorm3 -> y3 (257), then theta | phi | g = 1x1 convs of y3 with NO nonlinearity in between
+        # (model.py:101-102, 33-46): composed offline into one K = 128 GEMM, N = [y3 (257, padded to 288) | q k v (3 x 128)].
+        # theta | phi | g keep the query / key / value order of the attention kernel.
+        k3, b3 = fold_bn(hwio(st + "conv3"), w[st + "conv3/bias"], _bn(w, st + "bnorm3"))            # [1,128,257], [257]
+        qkv = np.concatenate([hwio(st + "non_local/" + n) for n in ("theta", "phi", "g")], axis=2).astype(np.float64)   # [1,257,384]
+        qb = np.concatenate([w[st + "non_local/%s/bias" % n] for n in ("theta", "phi", "g")]).astype(np.float64)
+        kc = np.zeros((1, 128, 672))
+        bc = np.zeros(672)
+        kc[0, :, :257] = k3[0]
+        bc[:257] = b3
+        kc[0, :, 288:] = k3[0] @ qkv[0]
+        bc[288:] = b3 @ qkv[0] + qb
+        out["res%d.c3q" % i] = (kc, bc)
         out["res%d.w" % i] = fold_bn(hwio(st + "non_local/w"), w[st + "non_local/w/bias"], _bn(w, st + "non_local/bnorm"))
     return out
 

@@ -114,12 +114,18 @@ def test_clr_conv1_gs_split_and_qkv_order(w):
         extra += gsp[t // 3:t // 3 + 6, t % 3:t % 3 + 6, None] * wg[None, None, :, t]
     got = O.leaky_relu(torch.from_numpy(main[0] + extra)).numpy()
     np.testing.assert_allclose(got, ref[0], atol=2e-5)
-    k, bias = packed(w, "res2.qkv")
-    st = "res_stack/2/non_local/"
-    for j, n in enumerate(("theta", "phi", "g")):
-        np.testing.assert_array_equal(k[0, :257, 128 * j:128 * (j + 1)], w[st + n + "/kernel"][0, 0])
-        np.testing.assert_array_equal(bias[128 * j:128 * (j + 1)], w[st + n + "/bias"])
-    assert np.all(k[0, 257:] == 0)
+    # conv3 + theta|phi|g composed into one K = 128 GEMM: N = [y3 (257 of 288) | q k v (384)]
+    k, bias = packed(w, "res2.c3q")                                  # [1, 128, 672]
+    st = "res_stack/2/"
+    rng = np.random.default_rng(6)
+    t2 = torch.from_numpy(rng.standard_normal((1, 4, 4, 128)).astype(np.float32))
+    y3 = O.batchnorm_infer(O.conv2d_same(t2, w[st + "conv3/kernel"], w[st + "conv3/bias"]), *bn_args(w, st + "bnorm3"))
+    got = O.conv2d_same(t2, k.reshape(1, 1, 128, 672), bias, 1).numpy()
+    np.testing.assert_allclose(got[..., :257], y3.numpy(), atol=2e-5)
+    assert np.all(got[..., 257:288] == 0)
+    for j, n in enumerate(("theta", "phi", "g")):                    # query, key, value order of the attention kernel
+        ref = O.conv2d_same(y3, w[st + "non_local/" + n + "/kernel"], w[st + "non_local/" + n + "/bias"]).numpy()
+        np.testing.assert_allclose(got[..., 288 + 128 * j:288 + 128 * (j + 1)], ref, atol=2e-5)
 
 
 def test_blob_layout(w):
