@@ -67,7 +67,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("BSR_BENCH_FORCE_DIST") == "1"      # the latter exercises the RCCL path on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:

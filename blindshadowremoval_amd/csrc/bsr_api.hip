@@ -205,8 +205,9 @@ struct Launcher {
     if (rc != BSR_OK) return;
     using C = bsr::GemmNLoopCfg<NI, NCH>;
     LayerW l;
-    const int ng = (n_store + C::BN - 1) / C::BN;
-    rc = find_layer(h, name, NCH, 1, 36, ng * C::BN, &l);
+    constexpr int kNSplit = 2;                                  // two workgroups per CU share the N range
+    const int tiles = (n_store + 31) / 32;
+    rc = find_layer(h, name, NCH, 1, 36, (tiles + NI) * 32, &l);   // the last group of a range may read (zero) rows past its tiles
     if (rc != BSR_OK) return;
     if (pixels % C::BM != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': pixel count is not a multiple of 128"); return; }
     bsr::ConvArgs a{};
@@ -215,7 +216,7 @@ struct Launcher {
     a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c; a.res2 = res2; a.res2_cs = res2_cs; a.res2_c = res2_c;
     a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
     begin(cls);
-    check(bsr::launch_gemm_nloop<NI, NCH>(a, pixels, s), name);
+    check(bsr::launch_gemm_nloop<NI, NCH>(a, pixels, kNSplit, s), name);
     end();
   }
 

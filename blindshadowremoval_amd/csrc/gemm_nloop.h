@@ -2,10 +2,11 @@
 //
 // The bottleneck blocks run three K = 128 GEMMs per block with wide N (conv3 | theta|phi|g : N = 672, w : N = 288;
 // /root/reference/model.py:86,10-13,101-102,56-59).  With one workgroup per (128-pixel, 96-channel) tile the K loop is only four
-// steps long and prologue + epilogue cost as much as the MFMAs.  Here a workgroup owns 128 pixels for ALL N:
-// the [128][K] activation tile is staged in LDS once, the weights stream through the same 3-slot LDS ring as
-// igemm_conv_kernel, continuously across the N groups (no pipeline drain between groups), and each 96-channel group
-// ends with its own fused epilogue.  Same fragment scheme (v_mfma_f32_32x32x2_f32, ds_read_b128, K permuted
+// steps long and prologue + epilogue cost as much as the MFMAs.  Here a workgroup owns 128 pixels for a long run of
+// N tiles (blockIdx.y splits the tiles in NSPLIT ranges so two workgroups share a CU): each wave keeps the A fragments
+// of its 32 pixels x K in REGISTERS for the whole kernel (K = 128 -> 64 VGPRs, no activation LDS at all), the weights
+// stream through the same 3-slot LDS ring as igemm_conv_kernel, continuously across the N groups (no pipeline drain
+// between groups), and each group of NI tiles ends with its own fused epilogue.  Same fragment scheme (v_mfma_f32_32x32x2_f32, ds_read_b128, K permuted
 // identically in A and B).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -13,41 +14,40 @@
 
 namespace bsr {
 
-template <int NI, int NCH>   // NI 32-wide channel tiles per group, NCH = K / 32 resident chunks
+template <int NI, int NCH>   // NI 32-wide channel tiles per group, NCH = K / 32
 struct GemmNLoopCfg {
   static constexpr int CC = 32, LDP = 36, G = 4, BM = 128, BN = NI * 32;
-  static constexpr int IN_FLOATS = BM * LDP;                 // one K chunk of the activation tile
   static constexpr int W_FLOATS = BN * LDP;
-  static constexpr int SMEM_BYTES = (NCH * IN_FLOATS + 3 * W_FLOATS) * 4;
-  static constexpr int IN_V4 = BM * (CC / 4);
-  static constexpr int IN_PER_THREAD = IN_V4 / 256;          // 4
+  static constexpr int MAX_TILES = 24;                        // tiles per blockIdx.y range (bias staged in LDS)
+  static constexpr int SMEM_BYTES = (3 * W_FLOATS + MAX_TILES * 32) * 4;
   static constexpr int W_V4 = W_FLOATS / 4;
   static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
-  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
-// ConvArgs use: in/in_cs/in_coff (K = NCH*32 channels), H*W = pixels per image (flattened, multiple of 128),
-// w packed [NCH][1][n_pad][36], bias[n_pad], out/out_cs/out_coff/n_store (+ out2/n_split/n_store1), act, res1/res2.
+// ConvArgs use: in/in_cs/in_coff (K = NCH*32 channels), pixels flattened (multiple of 128),
+// w packed [NCH][1][n_pad][36] with n_pad >= 32 * (tiles + NI - 1), bias[n_pad], out/out_cs/out_coff/n_store
+// (+ out2/n_split/n_store1), act, res1/res2.  tiles_x = tiles per blockIdx.y range.
 template <int NI, int NCH>
-__global__ __launch_bounds__(256, 1) void gemm_nloop_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   using C = GemmNLoopCfg<NI, NCH>;
-  constexpr int LDP = C::LDP, BN = C::BN, G = C::G;
+  constexpr int LDP = C::LDP, G = C::G;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_in = smem;
-  float* s_w = smem + NCH * C::IN_FLOATS;
+  float* s_w = smem;
+  float* s_bias = smem + 3 * C::W_FLOATS;
 
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
   const size_t pix0 = (size_t)blockIdx.x * C::BM;            // first pixel of this block (flattened B*H*W index)
-  const int ngroups = (p.n_store + BN - 1) / BN;
+  const int tiles_total = (p.n_store + 31) / 32;
+  const int t0 = blockIdx.y * p.tiles_x;                      // this block's tile range [t0, t1)
+  const int t1 = min(t0 + p.tiles_x, tiles_total);
+  const int ngroups = (t1 - t0 + NI - 1) / NI;
   const int nsteps = ngroups * NCH;
 
-  const int a_base = (wave * 32 + r) * LDP + 4 * h;
   int b_base[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) b_base[ni] = (ni * 32 + r) * LDP + 4 * h;
-
   unsigned w_off[C::W_PER_THREAD];
 #pragma unroll
   for (int i = 0; i < C::W_PER_THREAD; ++i) {
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nloop_kernel(ConvArgs p) {
   }
   auto fetch_w = [&](int s, f32x4 (&regs)[C::W_PER_THREAD]) {      // step s = (group, chunk)
     const int ng = s / NCH, ch = s % NCH;
-    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)ch * p.n_pad + (size_t)ng * BN) * LDP);
+    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)ch * p.n_pad + (size_t)(t0 + ng * NI) * 32) * LDP);
 #pragma unroll
     for (int i = 0; i < C::W_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + w_off[i]);
   };
@@ -67,42 +67,30 @@ __global__ __launch_bounds__(256, 1) void gemm_nloop_kernel(ConvArgs p) {
       if (tid + i * 256 < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
   };
 
-  // ---- prologue: the whole [128][K] activation tile + weight steps 0 and 1 ----
-  f32x4 w_regs[C::W_PER_THREAD];
+  // ---- prologue: this lane's A fragments (pixel r of the wave's 32, channels 8g + 4h .. +3) + weight steps 0, 1 ----
+  f32x4 afr[NCH * G];
   {
-    const float* in_blk = p.in + pix0 * p.in_cs + p.in_coff;
-    f32x4 a_regs[NCH][C::IN_PER_THREAD];
+    const float* row = p.in + (pix0 + wave * 32 + r) * p.in_cs + p.in_coff + 4 * h;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-      for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-        const int idx = tid + i * 256, px = idx / 8, q = idx % 8;
-        a_regs[ch][i] = *reinterpret_cast<const f32x4*>(in_blk + (size_t)px * p.in_cs + ch * 32 + q * 4);
-      }
-    fetch_w(0, w_regs);
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-      for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-        const int idx = tid + i * 256, px = idx / 8, q = idx % 8;
-        *reinterpret_cast<f32x4*>(s_in + ch * C::IN_FLOATS + px * LDP + q * 4) = a_regs[ch][i];
-      }
-    store_w(0, w_regs);
-    if (nsteps > 1) {
-      fetch_w(1, w_regs);
-      store_w(C::W_FLOATS, w_regs);
-    }
+    for (int g = 0; g < NCH * G; ++g) afr[g] = *reinterpret_cast<const f32x4*>(row + g * 8);
+  }
+  for (int i = tid; i < (t1 - t0) * 32; i += 256) s_bias[i] = p.bias[t0 * 32 + i];   // keeps bias loads out of the MFMA loop's vmcnt queue
+  f32x4 w_regs[C::W_PER_THREAD];
+  fetch_w(0, w_regs);
+  store_w(0, w_regs);
+  if (nsteps > 1) {
+    fetch_w(1, w_regs);
+    store_w(C::W_FLOATS, w_regs);
   }
   __syncthreads();
 
   int w_cur = 0, w_n1 = C::W_FLOATS, w_n2 = 2 * C::W_FLOATS;
-  f32x4 af[2], bf[2][NI];
-  auto read_frags = [&](int slot, int a_off, int b_off) {
-    af[slot] = *reinterpret_cast<const f32x4*>(s_in + a_base + a_off);
+  f32x4 bf[2][NI];
+  auto read_frags = [&](int slot, int b_off) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_w + b_base[ni] + b_off);
   };
-  read_frags(0, 0, w_cur);
+  read_frags(0, w_cur);
   __builtin_amdgcn_s_setprio(0);
 
   const bool has_res = p.res1 != nullptr;
@@ -111,11 +99,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nloop_kernel(ConvArgs p) {
   const size_t tile_pix = pix0 + wave * 32;                   // this wave's 32 consecutive pixels
 
   for (int ng = 0; ng < ngroups; ++ng) {
+    const int tg = t0 + ng * NI;                              // first tile of this group
+    const int nvalid = min(NI, t1 - tg);                      // tiles of this group that exist (uniform)
     f32x16 acc[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int n = ng * BN + ni * 32 + r;
-      const float b = p.bias[n < p.n_pad ? n : 0];
+      const float b = s_bias[min(ng * NI + ni, t1 - t0 - 1) * 32 + r];
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[ni][i] = b;
     }
@@ -129,17 +118,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nloop_kernel(ConvArgs p) {
       for (int g = 0; g < G; ++g) {
         const int cur = g & 1, nxt = cur ^ 1;                 // G is even: every step starts on slot 0
         if (g + 1 < G) {
-          read_frags(nxt, ch * C::IN_FLOATS + (g + 1) * 8, w_cur + (g + 1) * 8);
+          read_frags(nxt, w_cur + (g + 1) * 8);
         } else if (has1) {
-          read_frags(nxt, ((ch + 1) % NCH) * C::IN_FLOATS, w_n1);
+          read_frags(nxt, w_n1);
         }
         if (g == G - 1 && has2) store_w(w_n2, w_regs);
         __builtin_amdgcn_sched_barrier(0);
+        const f32x4 a = afr[ch * G + g];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int ni = 0; ni < NI; ++ni) {
+          if (ni < nvalid) {
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][j], bf[cur][ni][j], acc[ni], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[cur][ni][j], acc[ni], 0, 0, 0);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
@@ -150,7 +142,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nloop_kernel(ConvArgs p) {
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int nt = ng * BN + ni * 32;
+      if (ni >= nvalid) continue;
+      const int nt = (tg + ni) * 32;
       const int n = nt + r;
       const bool second = p.out2 != nullptr && nt >= p.n_split;
       const bool n_ok = second ? n < p.n_store : (p.out2 != nullptr ? n < p.n_store1 : n < p.n_store);
@@ -189,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nloop_kernel(ConvArgs p) {
 }
 
 template <int NI, int NCH>
-inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, hipStream_t stream) {
+inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, int nsplit, hipStream_t stream) {
   using C = GemmNLoopCfg<NI, NCH>;
   auto kern = gemm_nloop_kernel<NI, NCH>;
   static bool attr_set = false;
@@ -198,7 +191,10 @@ inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, hipStream_t
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(total_pixels / C::BM)), dim3(256), C::SMEM_BYTES, stream, a);
+  const int tiles_total = (a.n_store + 31) / 32;
+  a.tiles_x = (tiles_total + nsplit - 1) / nsplit;            // tiles per blockIdx.y range
+  if (a.tiles_x > C::MAX_TILES) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total_pixels / C::BM), nsplit), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }
 

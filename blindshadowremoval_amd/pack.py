@@ -36,8 +36,8 @@ for _i in range(N_RES):
     _cin_pad = 120 if _i == 0 else 264
     GEOMETRY["res%d.conv1" % _i] = (24, _cin_pad, 128)
     GEOMETRY["res%d.conv2" % _i] = (32, 128, 128)
-    GEOMETRY["res%d.c3q" % _i] = (32, 128, 672)       # [y3: 257 real of 288 | theta|phi|g: 384]
-    GEOMETRY["res%d.w" % _i] = (32, 128, 288)
+    GEOMETRY["res%d.c3q" % _i] = (32, 128, 768)       # [y3: 257 real of 288 | theta|phi|g: 384 | 3 zero tiles of slack]
+    GEOMETRY["res%d.w" % _i] = (32, 128, 384)           # 257 real of 288 + 3 zero tiles of slack (gemm_nloop group reads)
 
 
 def fold_bn(kernel_tkn: np.ndarray, bias: np.ndarray, bn: Dict[str, np.ndarray] | None):

@@ -120,7 +120,8 @@ def test_clr_conv1_gs_split_and_qkv_order(w):
     rng = np.random.default_rng(6)
     t2 = torch.from_numpy(rng.standard_normal((1, 4, 4, 128)).astype(np.float32))
     y3 = O.batchnorm_infer(O.conv2d_same(t2, w[st + "conv3/kernel"], w[st + "conv3/bias"]), *bn_args(w, st + "bnorm3"))
-    got = O.conv2d_same(t2, k.reshape(1, 1, 128, 672), bias, 1).numpy()
+    got = O.conv2d_same(t2, k[:, :, :672].reshape(1, 1, 128, 672), bias[:672], 1).numpy()
+    assert np.all(k[:, :, 672:] == 0) and np.all(bias[672:] == 0)
     np.testing.assert_allclose(got[..., :257], y3.numpy(), atol=2e-5)
     assert np.all(got[..., 257:288] == 0)
     for j, n in enumerate(("theta", "phi", "g")):                    # query, key, value order of the attention kernel
