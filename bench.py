@@ -141,6 +141,11 @@ def main():
         n33 = acc["conv3x3"][1] + acc["convT3x3"][1]
         achieved = GFLOP_3X3_PER_IMAGE * B / t33 / 1e3            # TFLOP/s
         t_all = sum(v[0] for v in acc.values()) * 1e-3
+        traffic = None          # HBM bytes of the same launches, from the committed PMC passes (tools/pmc_traffic.py)
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.isfile(tpath) and B == 32:
+            with open(tpath) as ft:
+                traffic = json.load(ft).get("path_3x3_hbm_bytes_per_forward")
         result = {
             "metric": "images/sec at 256x256 batch inference (GSC generator forward)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +157,9 @@ def main():
                        "parallelism": "dp%d" % world,
                        "collective": ("all_gather(con_rgb|dif) per step, async" if distributed and not args.no_gather else "none")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per forward of the same 3x3-path launches (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r1_pmc_traffic.csv); "
+                                         "algorithmic activation bytes of these layers (each input read once, each output written once): 3.61e9 per 32-image forward",
                          "kernel": "igemm_conv_kernel (3x3 + stride-2 3x3 + transposed 3x3 layers)",
                          "launches_per_forward": n33, "avg_launch_ms": round(t33 * 1e3 / n33, 4),
                          "algorithmic_gflop_per_forward": round(GFLOP_3X3_PER_IMAGE * B, 2),
