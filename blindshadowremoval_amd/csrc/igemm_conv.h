@@ -250,8 +250,10 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       const bool fetch_now = kRing1x1 ? has2 : (T > 1 && t == kInFetchTap && more);
       const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == kInStoreTap && more);
       // (1) issue the global loads of step s+2 (and of the next input tile) — landed by the write point below
+#ifndef BSR_NO_STAGE
       if (has2) fetch_w(s + 2, w_regs);
       if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 
       // (2) MFMAs of tap t; group g+1's fragments (or step s+1's first group) are read before group g's MFMAs
@@ -267,10 +269,12 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
         } else if (INB > 1) {
           if (has1) read_frags(nxt, in_n1 + tap_offset(0), w_n1);                   // next chunk's tile is already staged
         }
+#ifndef BSR_NO_STAGE_W
         if (g == G - 1) {                                                           // write point: stage step s+2
           if (has2) store_w(w_n2, w_regs);
           if (stage_in) store_in(kRing1x1 ? in_n2 : in_n1, in_regs);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)

@@ -9,6 +9,7 @@
 using namespace bsr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
+static int g_mode = 0;
 template <int KH, int KW, int S, bool TR, int NI, int CC, int INB>
 int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   using C = ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
@@ -16,8 +17,8 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   const int Ho = TR ? 2 * H : H / S, Wo = TR ? 2 * W : W / S;
   size_t n_in = (size_t)B * H * W * Cin, n_out = (size_t)B * Ho * Wo * Cout, n_w = (size_t)nchunk * T * n_pad * (CC + 4);
   std::vector<float> h_in(n_in), h_w(n_w);
-  for (auto& v : h_in) v = (float)rand() / RAND_MAX - 0.5f;
-  for (auto& v : h_w) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+  for (auto& v : h_in) v = g_mode == 1 ? 0.f : (g_mode == 2 ? 0.25f : (float)rand() / RAND_MAX - 0.5f);
+  for (auto& v : h_w) v = g_mode == 1 ? 0.f : (g_mode == 2 ? 0.03125f : ((float)rand() / RAND_MAX - 0.5f) * 0.1f);
   float *d_in, *d_out, *d_w, *d_b;
   CK(hipMalloc(&d_in, n_in * 4)); CK(hipMalloc(&d_out, n_out * 4)); CK(hipMalloc(&d_w, n_w * 4)); CK(hipMalloc(&d_b, n_pad * 4));
   CK(hipMemcpy(d_in, h_in.data(), n_in * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_w, h_w.data(), n_w * 4, hipMemcpyHostToDevice));
@@ -53,7 +54,8 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_mode = atoi(argv[1]);
   if (run<3, 3, 1, true, 2, 32, 1>("up3", 32, 128, 128, 128, 64)) return 1;
   if (run<3, 3, 1, true, 2, 32, 2>("up3/inb2", 32, 128, 128, 128, 64)) return 1;
   if (run<3, 3, 1, true, 1, 32, 1>("up3/ni1", 32, 128, 128, 128, 64)) return 1;
