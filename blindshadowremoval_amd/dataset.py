@@ -1,0 +1,179 @@
+"""Host-side input preparation — counterpart of the reference's test-time loaders
+(`Dataset(config, 'test')`, `parse_fn_test_FFHQ`, `parse_fn_test`: /root/reference/dataset.py:18-72, 148-302, 616-770;
+helpers `face_crop_and_resize`, `generate_face_region`: /root/reference/utils.py:356-433, 255-276;
+`generate_uv_map`, `generate_offset_map`: /root/reference/warp.py:194-232).
+
+It yields what `FSRNet.testFFHQ` / `test` consume: `.name_list` and `.feed`, an iterator of
+`(img[1,R,256,256,16], box[1,4], name)` with channel layout [img3, gt3, uvm3, reg_in3, reg_out3, face1]
+(SURVEY.md Appendix D).  No TensorFlow / OpenCV: PNGs are decoded with PIL and the three OpenCV calls on the path are
+restated with OpenCV's documented semantics (INTER_LINEAR resize; 5x5 Gaussian with sigma 0 = [1,4,6,4,1]/16,
+BORDER_REFLECT_101).  Delaunay interpolation uses matplotlib.tri exactly as the reference does.
+
+The reference stacks 10 rows per element (row 0 = the image, rows 1-9 = random same-folder images) and consumes only
+row 0 (utils.py:231); rows are independent at inference, so `rows=1` is the default and `rows=10` reproduces the
+reference layout (siblings drawn with a seeded RNG instead of the reference's unseeded `random`).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import random
+import re
+from typing import Iterator, List, Optional, Tuple
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "face_model.npz")
+_ANCHORS = np.asarray([[0, 0], [0, 255], [255, 0], [255, 255], [0, 127], [127, 0], [255, 127], [127, 255],
+                       [0, 63], [0, 191], [255, 63], [255, 191], [63, 0], [191, 0], [63, 255], [191, 255]]) / 255   # warp.py:195-198
+
+
+def _face_model():
+    z = np.load(_DATA)
+    return z["uv"], z["lm_ref"]
+
+
+def natural_key(s: str):
+    """natsort-style key: digit runs compare numerically (dataset.py:47,57 use natsorted)."""
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)]
+
+
+def imread_rgb(path: str) -> np.ndarray:
+    """cv2.cvtColor(cv2.imread(p), COLOR_BGR2RGB) / 255. (dataset.py:627)."""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"), np.float64) / 255.0
+
+
+def resize_linear(img: np.ndarray, size: int) -> np.ndarray:
+    """cv2.resize(img, (size, size)) with the default INTER_LINEAR: half-pixel centres, edge clamp, no antialias."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(img, np.float64)).permute(2, 0, 1)[None]
+    out = torch.nn.functional.interpolate(t, size=(size, size), mode="bilinear", align_corners=False, antialias=False)
+    return out[0].permute(1, 2, 0).numpy()
+
+
+def gaussian_blur5(a: np.ndarray) -> np.ndarray:
+    """cv2.GaussianBlur(a, (5,5), 0): OpenCV's fixed 5-tap kernel [1,4,6,4,1]/16, BORDER_REFLECT_101."""
+    k = np.array([1, 4, 6, 4, 1], np.float64) / 16.0
+    p = np.pad(np.asarray(a, np.float64), 2, mode="reflect")
+    tmp = sum(k[i] * p[:, i:i + a.shape[1]] for i in range(5))
+    return sum(k[i] * tmp[i:i + a.shape[0], :] for i in range(5))
+
+
+def face_crop_and_resize(img0: np.ndarray, lm0: np.ndarray, fsize: int):
+    """utils.face_crop_and_resize with aug=False (utils.py:356-433): crop box from the landmark extent (x1.4, shifted up
+    by 20 %), zero-extend when it leaves the image, resize to fsize; landmarks normalised by the box size."""
+    # dtype flow mirrors the reference: landmarks stay float32, the box centre is float32 arithmetic (int() truncation of
+    # e.g. 127.999998 vs 128.0 changes the crop), the half-length is promoted to float64 by the `* 1.4` (numpy-1.x
+    # scalar rules, the reference's environment)
+    img, lm = np.copy(img0), np.array(lm0, np.float32)
+    h, w = img.shape[0], img.shape[1]
+    two = np.float32(2)
+    center = [(lm[:, 0].min() + lm[:, 0].max()) / two, (lm[:, 1].min() + lm[:, 1].max()) / two]
+    length = float(max((lm[:, 0].max() - lm[:, 0].min()) / two, (lm[:, 1].max() - lm[:, 1].min()) / two)) * 1.4
+    box = [int(center[0]) - int(length), int(center[1]) - int(length * 1.2),
+           int(center[0]) + int(length), int(center[1]) + int(length) + int(length) - int(length * 1.2)]
+    box0 = list(box)
+    lm[:, 0] = lm[:, 0] - np.float32(box[0])
+    lm[:, 1] = lm[:, 1] - np.float32(box[1])
+    px = max(-box[0], box[2] - w) if (box[0] < 0 or box[2] > w) else 0
+    py = max(-box[1], box[3] - h) if (box[1] < 0 or box[3] > h) else 0
+    if px > 0 or py > 0:
+        big = np.zeros((h + 2 * py + 2, w + 2 * px + 2, img.shape[2]))
+        big[py:py + h, px:px + w, :] = img
+        img = big
+        box = [box[0] + px, box[1] + py, box[2] + px, box[3] + py]
+    img = img[box[1]:box[3], box[0]:box[2], :]
+    if img.shape[0] == img.shape[1] and img.shape[0] > 0:
+        img = resize_linear(img, fsize)
+    else:
+        img = np.zeros((fsize, fsize, img.shape[2]))
+    return img, lm / np.float32(length * 2), box0
+
+
+def _grid(size: int):
+    return np.meshgrid(np.linspace(0, 1, size), np.linspace(0, 1, size))
+
+
+def generate_face_region(lm: np.ndarray, size: int) -> np.ndarray:
+    """utils.generate_face_region (utils.py:255-276): convex hull of the landmarks + mirrored jaw line, blurred."""
+    import matplotlib.tri as mtri
+    more = np.copy(lm[0:17, :])
+    more[:, 1] = more[0, 1] - (more[:, 1] - more[0, 1]) * 0.8
+    src = np.concatenate([lm, more], axis=0)
+    xi, yi = _grid(size)
+    interp = mtri.LinearTriInterpolator(mtri.Triangulation(src[:, 0], src[:, 1]), src[:, 0])
+    m = np.nan_to_num(np.ma.filled(interp(xi, yi), np.nan))
+    return gaussian_blur5((m > 0).astype(np.float32)).astype(np.float32).reshape(size, size, 1)
+
+
+def generate_uv_map(lm: np.ndarray, uv: np.ndarray, size: int) -> np.ndarray:
+    """warp.generate_uv_map (warp.py:215-232): barycentric interpolation of the canonical UVZ table, 0 outside the hull."""
+    import matplotlib.tri as mtri
+    xi, yi = _grid(size)
+    tri = mtri.Triangulation(lm[:, 0], lm[:, 1])
+    ch = [np.ma.filled(mtri.LinearTriInterpolator(tri, uv[:, c])(xi, yi), np.nan) for c in (1, 0, 2)]   # stacked [y, x, z]
+    return np.nan_to_num(np.stack(ch, axis=2))
+
+
+def generate_offset_map(source: np.ndarray, target: np.ndarray, size: int) -> np.ndarray:
+    """warp.generate_offset_map (warp.py:194-213): landmark offsets (+16 fixed anchors) interpolated over the target mesh."""
+    import matplotlib.tri as mtri
+    xi, yi = _grid(size)
+    s = np.concatenate([source, _ANCHORS], axis=0).astype(np.float32)
+    t = np.concatenate([target, _ANCHORS], axis=0).astype(np.float32)
+    off = s - t
+    tri = mtri.Triangulation(t[:, 0], t[:, 1])
+    mx = np.ma.filled(mtri.LinearTriInterpolator(tri, off[:, 0])(xi, yi), np.nan)
+    my = np.ma.filled(mtri.LinearTriInterpolator(tri, off[:, 1])(xi, yi), np.nan)
+    return np.stack([my, mx, mx * 0], axis=2)
+
+
+def build_row(img_path: str, lm_path: str, gt_path: Optional[str] = None, size: int = 256) -> Tuple[np.ndarray, np.ndarray]:
+    """One `[size,size,16]` row + crop box, in the order of dataset.py:627-638."""
+    uv, lm_ref = _face_model()
+    img = imread_rgb(img_path)
+    gt = imread_rgb(gt_path) if gt_path else img
+    both = np.concatenate([img, gt], axis=2)
+    crop, lm, box = face_crop_and_resize(both, np.load(lm_path), size)
+    face = generate_face_region(lm, size)
+    uvm = generate_uv_map(lm, uv, size)
+    reg_in = generate_offset_map(lm, lm_ref, size)
+    reg_out = generate_offset_map(lm_ref, lm, size)
+    return np.concatenate([crop, uvm, reg_in, reg_out, face], axis=2).astype(np.float32), np.asarray(box, np.float32)
+
+
+class Dataset:
+    """`Dataset(config, 'test')` counterpart (dataset.py:18-72).  `ucb=True` switches to `parse_fn_test`, whose ground truth
+    comes from the sibling `gt` tree (dataset.py:155)."""
+
+    def __init__(self, config, mode: str = "test", dset=None, ucb: bool = False, rows: int = 1, seed: int = 0):
+        if mode != "test" or dset is not None:
+            raise NotImplementedError("only the GSC test loaders are provided (training / SFW loaders are out of scope)")
+        self.config, self.mode, self.ucb, self.rows = config, mode, ucb, rows
+        self._rng = random.Random(seed)
+        self.name_list: List[str] = []
+        for d in config.DATA_DIR_TEST:                                     # dataset.py:55-61
+            for folder in sorted(glob.glob(d), key=natural_key):
+                self.name_list += sorted(glob.glob(os.path.join(folder, "*.npy")), key=natural_key)
+        self.feed: Iterator = self._iterate()
+
+    def _gt_path(self, lm_path: str) -> Optional[str]:
+        if not self.ucb:
+            return None
+        parts = lm_path.replace("\\", "/").split("/")
+        return os.path.splitext("/".join(parts[:-3] + ["gt"] + parts[-2:]))[0] + ".png"      # .../train/input/x/y -> .../train/gt/x/y
+
+    def _iterate(self):
+        size = self.config.IMG_SIZE
+        for lm_path in self.name_list:
+            img_path = os.path.splitext(lm_path)[0] + ".png"
+            gt_path = self._gt_path(lm_path)
+            row0, box = build_row(img_path, lm_path, gt_path, size)
+            rows = [row0]
+            siblings = sorted(glob.glob(os.path.join(os.path.dirname(lm_path), "*.npy")), key=natural_key)
+            for _ in range(self.rows - 1):                                 # rows 1..9: random same-folder images (dataset.py:641-762)
+                sib = siblings[self._rng.randint(0, len(siblings) - 1)]
+                rows.append(row0 if sib == lm_path else build_row(os.path.splitext(sib)[0] + ".png", sib, gt_path or img_path, size)[0])
+            name = (gt_path or img_path).encode()
+            yield np.stack(rows, axis=0)[None], box[None], np.array([name])

@@ -1,0 +1,89 @@
+"""Input-preparation counterpart (blindshadowremoval_amd/dataset.py) against the fixture produced by the REFERENCE's own
+functions on sample_imgs/02165 (tests/golden/sample_02165.npz, tools/make_sample_fixture.py).  The sample image and
+landmarks live under /root/reference, so the end-to-end comparison runs in the build container only."""
+import os
+
+import numpy as np
+import pytest
+
+from blindshadowremoval_amd import dataset as D
+
+# the reference's sample input (a 256x256 PNG + 68 landmarks) is committed as a data fixture so config 1 runs on the GPU box
+REF_SAMPLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_imgs", "02165", "02165")
+
+
+def test_natural_sort_and_blur():
+    assert sorted(["a10", "a9", "a100", "b1"], key=D.natural_key) == ["a9", "a10", "a100", "b1"]
+    a = np.zeros((9, 9), np.float32)
+    a[4, 4] = 1
+    b = D.gaussian_blur5(a)
+    np.testing.assert_allclose(b[4, 2:7], np.array([1, 4, 6, 4, 1]) / 16 * 6 / 16, rtol=1e-12)
+    assert abs(b.sum() - 1) < 1e-12
+    e = np.zeros((6, 6)); e[0, 1] = 1                             # BORDER_REFLECT_101: index -1 mirrors index 1 (edge not repeated)
+    assert abs(D.gaussian_blur5(e)[0, 0] - (6 / 16) * (8 / 16)) < 1e-12 and abs(D.gaussian_blur5(e)[0, 1] - (6 / 16) * (6 / 16 + 1 / 16)) < 1e-12
+
+
+def test_face_model_tables():
+    uv, lm_ref = D._face_model()
+    assert uv.shape == (68, 3) and lm_ref.shape == (68, 2)
+    assert 0 < uv.min() and uv.max() < 1 and 0 < lm_ref.min() and lm_ref.max() < 1
+
+
+def test_crop_box_and_zero_extension():
+    img = np.random.default_rng(0).random((100, 120, 3))
+    lm = np.array([[10.0, 20.0], [90.0, 80.0]] * 34)
+    crop, lmn, box = D.face_crop_and_resize(img, lm, 64)
+    # centre (50,50), half-length 40*1.4 = 56 -> box x 50-56..50+56, y 50-67..50+56+56-67: leaves the image -> zero-extended
+    assert box == [-6, -17, 106, 95] and crop.shape == (64, 64, 3)
+    assert np.all(crop[0] == 0)                                    # rows above the image are zeros
+    np.testing.assert_allclose(lmn[0], [(10 + 6) / 112, (20 + 17) / 112])
+
+
+def test_row_matches_reference_prepared_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "sample_02165.npz"))
+    row, box = D.build_row(REF_SAMPLE + ".png", REF_SAMPLE + ".npy")
+    assert row.shape == (256, 256, 16) and row.dtype == np.float32
+    np.testing.assert_array_equal(box, z["box"])
+    for name, sl, tol in (("img", slice(0, 3), 1e-6), ("gt", slice(3, 6), 1e-6), ("uvm", slice(6, 9), 1e-6),
+                          ("reg_in", slice(9, 12), 1e-6), ("reg_out", slice(12, 15), 1e-6), ("face", slice(15, 16), 1e-6)):
+        np.testing.assert_allclose(row[..., sl], z["row"][..., sl], atol=tol, err_msg=name)
+
+
+def test_dataset_feed_layout():
+    from blindshadowremoval_amd.fsrnet import Config
+    cfg = Config()
+    cfg.DATA_DIR_TEST = [os.path.join(os.path.dirname(REF_SAMPLE), "..", "*")]
+    ds = D.Dataset(cfg, "test", rows=10)
+    assert [os.path.normpath(n) for n in ds.name_list] == [os.path.normpath(REF_SAMPLE + ".npy")]
+    img, box, name = next(ds.feed)
+    assert img.shape == (1, 10, 256, 256, 16) and box.shape == (1, 4) and name[0].endswith(b"02165.png")
+    np.testing.assert_array_equal(img[0, 0], img[0, 9])          # single-image folder: every sibling is the image itself
+    with pytest.raises(StopIteration):
+        next(ds.feed)
+    if not os.path.isdir("/root/reference/UCB/train/input"):
+        return
+    ucb = D.Dataset(type("C", (), {"DATA_DIR_TEST": ["/root/reference/UCB/train/input/*"], "IMG_SIZE": 256})(), "test", ucb=True)
+    assert len(ucb.name_list) == 100                              # 100 items, not 99
+    assert ucb._gt_path(ucb.name_list[0]).replace("/gt/", "/input/") == os.path.splitext(ucb.name_list[0])[0] + ".png"
+    im, bx, nm = next(ucb.feed)
+    assert im.shape == (1, 1, 256, 256, 16) and not np.array_equal(im[0, 0, ..., 0:3], im[0, 0, ..., 3:6])   # UCB gt differs from input
+
+
+@pytest.mark.gpu
+def test_config1_end_to_end(tmp_path, golden_dir):
+    """BASELINE config 1: the sample_imgs face through Dataset -> FSRNet.testFFHQ on the GPU, against the oracle."""
+    import torch
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    from blindshadowremoval_amd.weights import init_weights
+    from oracle.gsc_oracle import GeneratorOracle, test_step_ffhq
+    cfg = Config(0)
+    cfg.CHECKPOINT_DIR = str(tmp_path)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "sample_imgs", "*")]
+    w = init_weights(1)
+    ds = D.Dataset(cfg, "test", rows=10)
+    res = FSRNet(cfg, weights=w).testFFHQ(ds)
+    assert len(res) == 1 and os.path.isfile(os.path.join(str(tmp_path), "test", "02165_02165-result.png"))
+    row, _ = D.build_row(REF_SAMPLE + ".png", REF_SAMPLE + ".npy")
+    ref = test_step_ffhq(GeneratorOracle(w), torch.from_numpy(row)[None])
+    for a, b in zip(res[0][1], ref):
+        assert float((a.cpu() - b).abs().max()) <= 1e-3
