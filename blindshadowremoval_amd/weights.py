@@ -31,8 +31,15 @@ def _conv(spec, stem, kh, cin, cout, bn, transpose=False):
             spec[stem + "/bnorm/" + p] = (cout,)
 
 
-def generator_variable_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
-    """name -> shape for the 258 float32 variables of the GSC generator."""
+def generator_variable_shapes(variant: str = "gsc") -> "OrderedDict[str, Tuple[int, ...]]":
+    """name -> shape for the 258 float32 variables of the generator.  ``variant``: "gsc" (/root/reference/model.py) or
+    "tsm" (/root/reference/model_with_TSM.py: ShareLayer widens the bottleneck inputs to 291 / 877 channels)."""
+    if variant not in ("gsc", "tsm"):
+        raise ValueError("variant must be 'gsc' or 'tsm'")
+    tsm = variant == "tsm"
+    c0 = N_CH[3] + 3 + (2 * N_CH[3] if tsm else 0)            # cat[x, (x_share,) uv]: 99 | 291
+    c12 = max(c0, RES_CH)                                       # output width of res blocks 0-2: 257 | 291
+    c3 = c12 + 1 + 3 + (2 * c12 if tsm else 0)                  # cat[x_hole, bmask, (x_share,) uv]: 261 | 877
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     _conv(s, "conv1", 7, 3, N_CH[0], True)                 # model.py:203
     _conv(s, "conv2", 7, N_CH[1], 1, False)                # model.py:204 (mask head)
@@ -40,10 +47,10 @@ def generator_variable_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
     _conv(s, "down1", 3, N_CH[0], N_CH[1], True)           # model.py:207
     _conv(s, "down2", 3, N_CH[1], N_CH[2], True)
     _conv(s, "down3", 3, N_CH[2], N_CH[3], True)
-    _conv(s, "up1", 3, RES_CH, N_CH[3], True, transpose=True)            # model.py:210,243
+    _conv(s, "up1", 3, c12, N_CH[3], True, transpose=True)               # model.py:210,243
     _conv(s, "up2", 3, N_CH[3] + N_CH[2], N_CH[2], True, transpose=True)  # cat[y,x3] model.py:244
     _conv(s, "up3", 3, N_CH[2] + N_CH[1], N_CH[1], True, transpose=True)  # cat[y,x2] model.py:245
-    _conv(s, "clr_up1", 3, RES_CH + 4, N_CH[4], True, transpose=True)     # 261 -> 128 model.py:214,264
+    _conv(s, "clr_up1", 3, c3, N_CH[4], True, transpose=True)             # 261 -> 128 model.py:214,264
     _conv(s, "clr_up2", 3, N_CH[4], N_CH[3], True, transpose=True)
     _conv(s, "clr_up3", 3, N_CH[3], N_CH[2], True, transpose=True)
     _conv(s, "clr_conv1", 3, N_CH[2] + 1, 16, True)        # cat[gs,f] model.py:217,267
@@ -51,7 +58,7 @@ def generator_variable_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
     _conv(s, "clr_conv3", 1, 16, 3, False)
     half = RES_CH // 2                                      # 128
     for i in range(N_RES):
-        cin = (N_CH[3] + 3) if i == 0 else (RES_CH if i < N_RES // 2 else RES_CH + 4)   # 99 / 257 / 261
+        cin = c0 if i == 0 else (c12 if i < N_RES // 2 else c3)   # GSC 99 / 257 / 261, TSM 291 / 291 / 877
         st = "res_stack/%d/" % i
         for name, shp in (("conv1", (1, 1, cin, half)), ("conv2", (3, 3, half, half)), ("conv3", (1, 1, half, RES_CH))):
             s[st + name + "/kernel"] = shp
@@ -85,7 +92,7 @@ def _gain(name: str) -> float:
     return 1.6
 
 
-def init_weights(seed: int = 1, con_bias_shift: float = 0.25) -> Dict[str, np.ndarray]:
+def init_weights(seed: int = 1, con_bias_shift: float = 0.25, variant: str = "gsc") -> Dict[str, np.ndarray]:
     """Seeded synthetic weights (SURVEY.md §8d recipe): kernels N(0, 1.6/fan_in), biases / beta /
     moving_mean N(0, 0.05^2), gamma U[0.8,1.2], moving_variance U[0.75,1.25].
 
@@ -93,7 +100,7 @@ def init_weights(seed: int = 1, con_bias_shift: float = 0.25) -> Dict[str, np.nd
     in-network 0.1 threshold (/root/reference/model.py:256) so ``bmask`` is non-degenerate."""
     rng = np.random.default_rng(seed)
     out: Dict[str, np.ndarray] = {}
-    for name, shp in generator_variable_shapes().items():
+    for name, shp in generator_variable_shapes(variant).items():
         leaf = name.rsplit("/", 1)[1]
         if leaf == "kernel":
             transpose = name.split("/")[0] in ("up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3")
@@ -114,9 +121,14 @@ def init_weights(seed: int = 1, con_bias_shift: float = 0.25) -> Dict[str, np.nd
     return out
 
 
-def check_weights(weights: Dict[str, np.ndarray]) -> None:
+def detect_variant(weights: Dict[str, np.ndarray]) -> str:
+    k = weights.get("res_stack/0/conv1/kernel")
+    return "tsm" if k is not None and k.shape[2] == 291 else "gsc"
+
+
+def check_weights(weights: Dict[str, np.ndarray], variant: str = "gsc") -> None:
     """Raise ValueError if ``weights`` is not exactly the generator's variable set."""
-    spec = generator_variable_shapes()
+    spec = generator_variable_shapes(variant)
     missing = [k for k in spec if k not in weights]
     if missing:
         raise ValueError("missing generator variables: %s%s" % (missing[:4], " ..." if len(missing) > 4 else ""))

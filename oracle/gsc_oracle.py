@@ -207,6 +207,111 @@ class GeneratorOracle:
     __call__ = forward
 
 
+# ---------------------------------------------------------------------------------------------------
+# TSM variant (BASELINE config 5): ShareLayer + UV/offset warp.  /root/reference/model_with_TSM.py:199-325, warp.py:71-165
+# ---------------------------------------------------------------------------------------------------
+def batch_map_coordinates(x: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """``tf_batch_map_coordinates`` (warp.py:71-115): x [B,S,S,C], coords [B,N,2] (axis-0, axis-1) -> [B,N,C].
+    Clamp to [0,S-1]; corners lt = floor, rb = ceil; lerp along axis 0 first (``vals_t``/``vals_b``), then along axis 1."""
+    B, S = x.shape[0], x.shape[1]
+    coords = coords.clamp(0, S - 1)
+    lt = torch.floor(coords).long()
+    rb = torch.ceil(coords).long()
+    bi = torch.arange(B).reshape(B, 1).expand(B, coords.shape[1])
+
+    def g(i0, i1):
+        return x[bi, i0, i1]                                  # [B,N,C]
+    v_lt, v_rb = g(lt[..., 0], lt[..., 1]), g(rb[..., 0], rb[..., 1])
+    v_lb, v_rt = g(lt[..., 0], rb[..., 1]), g(rb[..., 0], lt[..., 1])
+    off = coords - lt.to(coords.dtype)
+    o0, o1 = off[..., 0:1], off[..., 1:2]
+    vals_t = v_lt + (v_rt - v_lt) * o0
+    vals_b = v_lb + (v_rb - v_lb) * o0
+    return vals_t + (vals_b - vals_t) * o1
+
+
+def batch_map_offsets(x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    """``tf_batch_map_offsets`` (warp.py:134-165): offsets [B,H,W,>=2] are resized to SxS, scaled by S, channels 0:2 kept,
+    added to the 'ij' grid and sampled bilinearly."""
+    B, S = x.shape[0], x.shape[1]
+    off = resize_bilinear(offsets, (S, S)) * S
+    off = off[..., 0:2].reshape(B, -1, 2)
+    ii, jj = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    grid = torch.stack([ii, jj], dim=-1).to(torch.float32).reshape(1, -1, 2)
+    return batch_map_coordinates(x, off + grid).reshape(B, S, S, -1)
+
+
+def share_layer(x: torch.Tensor, reg: torch.Tensor, frame: int, share: bool = True) -> torch.Tensor:
+    """``ShareLayer.call`` (model_with_TSM.py:204-229).  The reference reshapes to [1, frame, ...] (batch == frame); groups of
+    ``frame`` consecutive images generalise that to batch = k * frame."""
+    if not share:
+        return torch.cat([x, x], dim=3)
+    reg_in, reg_out = torch.split(reg, reg.shape[3] // 2, dim=3)
+    x_reg = batch_map_offsets(x, reg_in)
+    B, w, h, ch = x_reg.shape
+    xr = x_reg.reshape(B // frame, frame, w, h, ch)
+    sh = torch.cat([xr.max(dim=1).values, xr.mean(dim=1)], dim=3)           # [G,w,h,2ch]
+    sh = sh.unsqueeze(1).expand(B // frame, frame, w, h, 2 * ch).reshape(B, w, h, 2 * ch)
+    return batch_map_offsets(sh, reg_out)
+
+
+class GeneratorTSMOracle(GeneratorOracle):
+    """``Generator`` of /root/reference/model_with_TSM.py:231-325 at ``training=False``."""
+
+    def forward(self, inputs, uv, reg, frame, share=True, chuck=1, training=False, probes: Optional[dict] = None,
+                bmask_override: Optional[torch.Tensor] = None):
+        assert not training
+        inputs, uv, reg = _t(inputs), _t(uv), _t(reg)
+        x1 = self.conv_block(inputs, "conv1")
+        x2 = self.conv_block(x1, "down1", 2)
+        x3 = self.conv_block(x2, "down2", 2)
+        x = self.conv_block(x3, "down3", 2)
+        h, w = x.shape[1], x.shape[2]
+        uv_s = resize_bilinear(uv, (h, w))                                     # :269
+        x_share = share_layer(x, reg, frame, share)                           # :271
+        x = torch.cat([x, x_share, uv_s], dim=3)                              # :272
+        if probes is not None:
+            probes.update(x_share1=x_share, x0=x)
+        for i in range(self.n_res // 2):
+            x = self.res_bottleneck(x, i, probes)
+        if probes is not None:
+            probes["res2"] = x
+        y = self.convt_block(x, "up1")
+        y = self.convt_block(torch.cat([y, x3], dim=3), "up2")
+        y = self.convt_block(torch.cat([y, x2], dim=3), "up3")
+        mask = torch.tanh(self.conv_block(y, "conv2", 1, bn=False, act=False))
+        con = self.conv_block(y, "conv3", 1, bn=False, act=False)
+        g0 = rgb_to_grayscale(inputs)
+        gs = g0 * (1 + mask) + con
+        dif = gs - g0
+        mask22 = torch.cat([torch.relu(mask), mask * 0, torch.relu(-mask)], dim=3)
+        d32 = resize_bilinear(dif, (h, w))
+        bmask = (d32 > BMASK_THRESHOLD).to(torch.float32)                     # :289
+        if probes is not None:
+            probes.update(d32=d32, bmask=bmask)
+        if bmask_override is not None:
+            bmask = _t(bmask_override).reshape(bmask.shape)
+        x_hole = x * (1 - bmask)                                              # :291
+        x_share = share_layer(x_hole, reg, frame, share)                      # :292
+        x = torch.cat([x_hole, bmask, x_share, uv_s], dim=3)                  # :293
+        if probes is not None:
+            probes.update(x_share2=x_share)
+        for i in range(self.n_res // 2, self.n_res):
+            x = self.res_bottleneck(x, i, probes)
+        if probes is not None:
+            probes["res5"] = x
+        f = self.convt_block(x, "clr_up1")
+        f = self.convt_block(f, "clr_up2")
+        f = self.convt_block(f, "clr_up3")
+        c = self.conv_block(torch.cat([gs, f], dim=3), "clr_conv1")
+        c = self.conv_block(c, "clr_conv2")
+        con_rgb = self.conv_block(c, "clr_conv3", bn=False, act=False)
+        dif2 = rgb_to_grayscale(con_rgb) - rgb_to_grayscale(inputs)
+        return gs, con_rgb, mask22, dif2
+
+    __call__ = forward
+
+
 def test_step_ffhq(gen, img16: torch.Tensor):
     """Restatement of ``FSRNet.test_step_FFHQ`` (/root/reference/train_test_GSC.py:863-890) for a
     ``[N,256,256,16]`` packed tensor: split [3,3,3,6,1], generator, ``mask_pred*face``,
