@@ -2,11 +2,11 @@
 ``FSRNet.test*`` inference path).  See DESIGN.md."""
 from .weights import generator_variable_shapes, init_weights  # noqa: F401
 
-__all__ = ["Generator", "generator_variable_shapes", "init_weights"]
+__all__ = ["Generator", "GeneratorTSM", "generator_variable_shapes", "init_weights"]
 
 
 def __getattr__(name):
-    if name == "Generator":
-        from .model import Generator
-        return Generator
+    if name in ("Generator", "GeneratorTSM"):
+        from . import model
+        return getattr(model, name)
     raise AttributeError(name)

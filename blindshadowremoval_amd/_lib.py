@@ -15,7 +15,7 @@ CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue")
 _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
-EXPORTS = ("bsr_create", "bsr_forward", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
+EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
            "bsr_get_timing", "bsr_debug_attention", "bsr_destroy", "bsr_last_error", "bsr_abi_version")
 
 
@@ -39,6 +39,8 @@ def load() -> ctypes.CDLL:
     lib.bsr_create.restype = c_i
     lib.bsr_forward.argtypes = [c_v, c_v, c_v, c_i, c_i, c_i, c_v, c_v, c_v, c_v, c_v]
     lib.bsr_forward.restype = c_i
+    lib.bsr_forward_tsm.argtypes = [c_v, c_v, c_v, c_v, c_i, c_i, c_i, c_i, c_i, c_v, c_v, c_v, c_v, c_v]
+    lib.bsr_forward_tsm.restype = c_i
     lib.bsr_workspace_bytes.argtypes = [c_i, c_i, c_i]
     lib.bsr_workspace_bytes.restype = c_sz
     lib.bsr_reserve.argtypes = [c_v, c_i, c_i, c_i]

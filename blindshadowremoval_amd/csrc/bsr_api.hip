@@ -56,15 +56,26 @@ struct LayerW {
 enum KClass { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2, K_ATT = 3, K_CONV7 = 4, K_GLUE = 5 };
 
 constexpr int C_RES = 257;   // ResBottleneck width (/root/reference/model.py:226)
-constexpr int CS_RES = 264;  // its channel stride (multiple of the 24-wide K chunk)
-constexpr int CS_XA = 120;   // cat[x(96), uv(3)] stride (model.py:238)
+constexpr int CS_RES = 264;  // channel stride of its 257-wide tensors (multiple of the 24-wide K chunk)
+
+// Channel plan of the bottleneck trunk.  GSC (/root/reference/model.py:238,259): xa = cat[x 96 | uv 3], blocks 0-2 are 257
+// wide, xh = cat[x_hole 257 | bmask | uv 3].  TSM (/root/reference/model_with_TSM.py:272,293) inserts the ShareLayer output:
+// xa = cat[x 96 | x_share 192 | uv 3] = 291, blocks 0-2 keep 291, xh = cat[x_hole 291 | bmask | x_share 582 | uv 3] = 877.
+struct Variant {
+  bool tsm;
+  int c_a, cs_a, uv_a;        // res0 input: real channels, stride, uv slot
+  int c_r, cs_r;              // blocks 0-2 output
+  int c_h, cs_h, uv_h;        // blocks 3-5 input/output, uv slot
+};
+constexpr Variant kGSC{false, 99, 120, 96, 257, 264, 261, 264, 258};
+constexpr Variant kTSM{true, 291, 312, 288, 291, 312, 877, 888, 874};
 constexpr int CS_CF = 64;    // f = clr_up3 output; the gs channel of cat[gs, f] (model.py:267) is read from the gs output
 
 struct Plan {  // float offsets into the workspace for a (B,H,W) problem
-  size_t xr, x1, c3, c2, xa, t1, t2, y3[6], qkv, att[6], r[6], xh, ybuf, qh, f1, f2, cf, c1, probe, total;
+  size_t xr, x1, c3, c2, xa, t1, t2, y3[6], qkv, att[6], r[6], xh, ybuf, qh, f1, f2, cf, c1, probe, reg32, share, total;
 };
 
-Plan make_plan(size_t B, size_t H, size_t W) {
+Plan make_plan(size_t B, size_t H, size_t W, const Variant& v = kGSC) {
   Plan p;
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -77,14 +88,14 @@ Plan make_plan(size_t B, size_t H, size_t W) {
   p.x1 = take(px * 32);
   p.c3 = take(px / 4 * 128);
   p.c2 = take(px / 16 * 160);
-  p.xa = take(cells * CS_XA);
+  p.xa = take(cells * v.cs_a);
   p.t1 = take(cells * 128);
   p.t2 = take(cells * 128);
   for (int i = 0; i < 6; ++i) p.y3[i] = take(cells * CS_RES);
   p.qkv = take(cells * 384);
   for (int i = 0; i < 6; ++i) p.att[i] = take(cells * 128);
-  for (int i = 0; i < 6; ++i) p.r[i] = take(cells * CS_RES);
-  p.xh = take(cells * CS_RES);
+  for (int i = 0; i < 6; ++i) p.r[i] = take(cells * (i < 3 ? v.cs_r : v.cs_h));
+  p.xh = take(cells * v.cs_h);
   p.ybuf = take(px * 64);
   p.qh = take(px * 16);
   p.f1 = take(px / 16 * 128);
@@ -92,6 +103,8 @@ Plan make_plan(size_t B, size_t H, size_t W) {
   p.cf = take(px * CS_CF);
   p.c1 = take(px * 16);
   p.probe = take(cells * 2);
+  p.reg32 = take(v.tsm ? cells * 4 : 0);
+  p.share = take(v.tsm ? cells * 2 * v.c_r : 0);
   p.total = off;
   return p;
 }
@@ -102,6 +115,7 @@ struct bsr_handle {
   int device = 0;
   float* d_blob = nullptr;
   std::unordered_map<std::string, LayerW> layers;
+  Variant var = kGSC;
   float head_bias[2] = {0.f, 0.f};
   const float* tail_w = nullptr;
   const float* clr_gs_w = nullptr;
@@ -240,7 +254,7 @@ struct Launcher {
 };
 
 int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
-  Plan p = make_plan(B, H, W);
+  Plan p = make_plan(B, H, W, h->var);
   if (p.total > h->ws_floats) {
     HIP_TRY(hipStreamSynchronize(s));
     if (h->ws) HIP_TRY(hipFree(h->ws));
@@ -326,6 +340,11 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
     }
   }
   if (h->tail_w == nullptr || h->clr_gs_w == nullptr) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob lacks 'tail.w' / 'clr_conv1.gs'"); }
+  {   // GSC or TSM weights?  (res0.conv1 has K = 120 -> 5 chunks of 24, or K = 312 -> 13)
+    auto it = h->layers.find("res0.conv1");
+    if (it == h->layers.end()) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob has no 'res0.conv1'"); }
+    h->var = it->second.nchunk == 13 ? kTSM : kGSC;
+  }
   *out = h;
   return BSR_OK;
 }
@@ -342,7 +361,7 @@ void bsr_destroy(bsr_handle* h) {
 int bsr_reserve(bsr_handle* h, int B, int H, int W) {
   if (h == nullptr || B <= 0 || H <= 0 || W <= 0) return fail(BSR_ERR_ARG, "bsr_reserve: bad argument");
   HIP_TRY(hipSetDevice(h->device));
-  Plan p = make_plan(B, H, W);
+  Plan p = make_plan(B, H, W, h->var);
   if (p.total > h->ws_floats) {
     HIP_TRY(hipDeviceSynchronize());
     if (h->ws) HIP_TRY(hipFree(h->ws));
@@ -376,11 +395,16 @@ int bsr_get_timing(bsr_handle* h, float ms[BSR_NUM_CLASSES], int launches[BSR_NU
   return BSR_OK;
 }
 
-int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W, float* gs, float* con_rgb, float* mask22,
-                float* dif, void* stream) {
+static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, const float* reg, int frame, int share, int B, int H, int W,
+                        float* gs, float* con_rgb, float* mask22, float* dif, void* stream) {
   if (h == nullptr || inputs == nullptr || uv == nullptr || gs == nullptr || con_rgb == nullptr || mask22 == nullptr || dif == nullptr)
     return fail(BSR_ERR_ARG, "bsr_forward: null argument");
   if (B <= 0) return fail(BSR_ERR_ARG, "bsr_forward: B must be positive");
+  const Variant& V = h->var;
+  if (V.tsm != (reg != nullptr))
+    return fail(BSR_ERR_ARG, V.tsm ? "bsr_forward: this handle holds TSM weights: call bsr_forward_tsm" : "bsr_forward_tsm: this handle holds GSC weights: call bsr_forward");
+  if (V.tsm && (frame <= 0 || B % frame != 0 || H != W))
+    return fail(BSR_ERR_ARG, "bsr_forward_tsm: B must be a multiple of frame and the image square (warp.py assumes a square map)");
   if (H <= 0 || W <= 0 || H % 32 != 0 || W % 256 != 0)
     return fail(BSR_ERR_ARG, "bsr_forward: H must be a multiple of 32 and W a multiple of 256 (reference: 256x256)");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -404,15 +428,31 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   // down1..3 = Conv(stride 2) (model.py:207-209,231-233); x2 / x3 land in their skip-concat slots (model.py:244-245)
   L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down1", ws + p.x1, 32, 0, 32, H, W, ws + p.c3, 128, 64, 64, 1);
   L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down2", ws + p.c3, 128, 64, 64, H2, W2, ws + p.c2, 160, 96, 64, 1);
-  L.conv<3, 3, 2, false, 3, 16, 1>(K_CONV3, "down3", ws + p.c2, 160, 96, 64, H4, W4, ws + p.xa, CS_XA, 0, 96, 1);
+  L.conv<3, 3, 2, false, 3, 16, 1>(K_CONV3, "down3", ws + p.c2, 160, 96, 64, H4, W4, ws + p.xa, V.cs_a, 0, 96, 1);
   // uv = resize(uv, [h,w]); x = cat[x, uv] (model.py:237-238) and the uv slot of cat[x_hole, bmask, uv] (model.py:259)
   glue_begin();
-  hipLaunchKernelGGL(bsr::uv_resize8_kernel, dim3((unsigned)((ncell * 3 + 255) / 256)), dim3(256), 0, s, uv, H, W, ws + p.xa, CS_XA, 96,
-                     ws + p.xh, CS_RES, C_RES + 1, ncell);
+  hipLaunchKernelGGL(bsr::uv_resize8_kernel, dim3((unsigned)((ncell * 3 + 255) / 256)), dim3(256), 0, s, uv, H, W, ws + p.xa, V.cs_a, V.uv_a,
+                     ws + p.xh, V.cs_h, V.uv_h, ncell);
   glue_end("uv_resize8");
 
+  // TSM: x_share = ShareLayer(x, reg, frame, share) into channels [96, 288) of xa (model_with_TSM.py:271-272)
+  auto share_layer = [&](const float* x, int x_cs, int C, float* out, int out_cs, int out_coff) {
+    glue_begin();
+    if (share) hipLaunchKernelGGL(bsr::share_reduce_kernel, dim3((unsigned)(ncell / frame)), dim3(128), 0, s, x, x_cs, C, ws + p.reg32, H8, frame, ws + p.share);
+    hipLaunchKernelGGL(bsr::share_unwarp_kernel, dim3((unsigned)ncell), dim3(128), 0, s, ws + p.share, x, x_cs, C, ws + p.reg32, H8, frame, share, out, out_cs, out_coff);
+    glue_end("share_layer");
+  };
+  if (V.tsm) {
+    glue_begin();
+    hipLaunchKernelGGL(bsr::reg_resize8_kernel, dim3((unsigned)((ncell * 4 + 255) / 256)), dim3(256), 0, s, reg, H, W, ws + p.reg32, ncell);
+    glue_end("reg_resize8");
+    share_layer(ws + p.xa, V.cs_a, 96, ws + p.xa, V.cs_a, 96);
+  }
+
   // ResBottleneck + NonLocalBlock (model.py:98-113, 23-61)
-  auto res_block = [&](int i, const float* x, int x_cs) {
+  auto res_block = [&](int i, const float* x, int x_cs, int x_c) {
+    float* r_out = ws + p.r[i];
+    const int o_cs = i < 3 ? V.cs_r : V.cs_h;
     char nm[32];
     float* y3 = ws + p.y3[i];
     snprintf(nm, sizeof nm, "res%d.conv1", i);
@@ -430,15 +470,20 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
     }
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113)
     snprintf(nm, sizeof nm, "res%d.w", i);
-    L.gemm<3, 4>(K_CONV1, nm, ws + p.att[i], 128, ncell, ws + p.r[i], CS_RES, CS_RES, 1, x, x_cs, x_cs, y3, CS_RES, CS_RES);
+    L.gemm<3, 4>(K_CONV1, nm, ws + p.att[i], 128, ncell, r_out, o_cs, o_cs < 288 ? o_cs : 288, 1, x, x_cs, x_cs, y3, CS_RES, CS_RES);
+    if (x_c > 288 && L.rc == BSR_OK) {      // the block output keeps the wider of x / y (model.py:105-113): channels the GEMM does not cover
+      glue_begin();
+      hipLaunchKernelGGL(bsr::lrelu_copy_kernel, dim3((unsigned)((ncell * (x_c - 288) + 255) / 256)), dim3(256), 0, s, x, x_cs, r_out, o_cs, 288, x_c, ncell);
+      glue_end("lrelu_copy");
+    }
   };
   if ((H8 * W8) % 128 != 0) return fail(BSR_ERR_ARG, "bsr_forward: (H/8)*(W/8) must be a multiple of 128");
-  res_block(0, ws + p.xa, CS_XA);
-  res_block(1, ws + p.r[0], CS_RES);
-  res_block(2, ws + p.r[1], CS_RES);
+  res_block(0, ws + p.xa, V.cs_a, V.c_a);
+  res_block(1, ws + p.r[0], V.cs_r, V.c_r);
+  res_block(2, ws + p.r[1], V.cs_r, V.c_r);
 
   // greyscale decoder: up1..3 = ConvT (model.py:243-245)
-  L.conv<3, 3, 1, true, 1, 24, 1>(K_CONVT, "up1", ws + p.r[2], CS_RES, 0, CS_RES, H8, W8, ws + p.c2, 160, 0, 96, 1);
+  L.conv<3, 3, 1, true, 1, 24, 1>(K_CONVT, "up1", ws + p.r[2], V.cs_r, 0, V.cs_r, H8, W8, ws + p.c2, 160, 0, 96, 1);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
   // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
@@ -449,22 +494,34 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
   glue_end("heads_post");
   // bmask / x_hole (model.py:256-259)
   glue_begin();
-  hipLaunchKernelGGL(bsr::bmask_xhole_kernel, dim3((unsigned)ncell), dim3(64), 0, s, gs, inputs, H, W, ws + p.r[2], CS_RES, C_RES, ws + p.xh,
-                     CS_RES, ws + p.probe);
+  hipLaunchKernelGGL(bsr::bmask_xhole_kernel, dim3((unsigned)ncell), dim3(64), 0, s, gs, inputs, H, W, ws + p.r[2], V.cs_r, V.c_r, ws + p.xh,
+                     V.cs_h, ws + p.probe);
   glue_end("bmask_xhole");
+  if (V.tsm) share_layer(ws + p.xh, V.cs_h, V.c_r, ws + p.xh, V.cs_h, V.c_r + 1);    // model_with_TSM.py:292-293
 
-  res_block(3, ws + p.xh, CS_RES);
-  res_block(4, ws + p.r[3], CS_RES);
-  res_block(5, ws + p.r[4], CS_RES);
+  res_block(3, ws + p.xh, V.cs_h, V.c_h);
+  res_block(4, ws + p.r[3], V.cs_h, V.c_h);
+  res_block(5, ws + p.r[4], V.cs_h, V.c_h);
 
   // colour decoder (model.py:264-269)
-  L.conv<3, 3, 1, true, 2, 24, 1>(K_CONVT, "clr_up1", ws + p.r[5], CS_RES, 0, CS_RES, H8, W8, ws + p.f1, 128, 0, 128, 1);
+  L.conv<3, 3, 1, true, 2, 24, 1>(K_CONVT, "clr_up1", ws + p.r[5], V.cs_h, 0, V.cs_h, H8, W8, ws + p.f1, 128, 0, 128, 1);
   L.conv<3, 3, 1, true, 1, 32, 1>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
   // clr_conv1 (3x3 over cat[gs, f]) + clr_conv2 + clr_conv3 + dif, one kernel (model.py:267-269,288)
   L.conv16<3, 3, true, true, 2>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, H, W, nullptr, 0, 1, gs, inputs, con_rgb, dif);
   if (L.rc == BSR_OK) h->ran = true;
   return L.rc;
+}
+
+int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W, float* gs, float* con_rgb, float* mask22,
+                float* dif, void* stream) {
+  return forward_impl(h, inputs, uv, nullptr, 1, 0, B, H, W, gs, con_rgb, mask22, dif, stream);
+}
+
+int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const float* reg, int B, int H, int W, int frame, int share,
+                    float* gs, float* con_rgb, float* mask22, float* dif, void* stream) {
+  if (reg == nullptr) return fail(BSR_ERR_ARG, "bsr_forward_tsm: null reg");
+  return forward_impl(h, inputs, uv, reg, frame, share != 0, B, H, W, gs, con_rgb, mask22, dif, stream);
 }
 
 int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream) {
@@ -493,8 +550,8 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
   if (nm == "x1") src = {p.x1, H, W, 32, 0, 32};
   else if (nm == "x2") src = {p.c3, H / 2, W / 2, 128, 64, 64};
   else if (nm == "x3") src = {p.c2, H / 4, W / 4, 160, 96, 64};
-  else if (nm == "x0") src = {p.xa, H / 8, W / 8, CS_XA, 0, 99};
-  else if ((i = res_idx("res")) >= 0) src = {p.r[i], H / 8, W / 8, CS_RES, 0, i < 3 ? C_RES : C_RES + 4};
+  else if (nm == "x0") src = {p.xa, H / 8, W / 8, h->var.cs_a, 0, h->var.c_a};
+  else if ((i = res_idx("res")) >= 0) src = {p.r[i], H / 8, W / 8, i < 3 ? h->var.cs_r : h->var.cs_h, 0, i < 3 ? h->var.c_r : h->var.c_h};
   else if ((i = res_idx("att")) >= 0) src = {p.att[i], H / 8, W / 8, 128, 0, 128};
   else if ((i = res_idx("y3_")) >= 0) src = {p.y3[i], H / 8, W / 8, CS_RES, 0, C_RES};
   else if (nm == "up1") src = {p.c2, H / 4, W / 4, 160, 0, 96};
@@ -502,7 +559,7 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
   else if (nm == "y") src = {p.ybuf, H, W, 64, 0, 64};
   else if (nm == "d32") src = {p.probe, H / 8, W / 8, 2, 0, 1};
   else if (nm == "bmask") src = {p.probe, H / 8, W / 8, 2, 1, 1};
-  else if (nm == "xh") src = {p.xh, H / 8, W / 8, CS_RES, 0, C_RES + 4};
+  else if (nm == "xh") src = {p.xh, H / 8, W / 8, h->var.cs_h, 0, h->var.c_h};
   else if (nm == "f1") src = {p.f1, H / 4, W / 4, 128, 0, 128};
   else if (nm == "f2") src = {p.f2, H / 2, W / 2, 96, 0, 96};
   else if (nm == "f") src = {p.cf, H, W, CS_CF, 0, 64};

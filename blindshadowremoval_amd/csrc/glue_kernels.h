@@ -151,6 +151,108 @@ __global__ void color_tail_kernel(const float* __restrict__ c1, const float* __r
   dif[pix] = gray3(o[0], o[1], o[2]) - gray3(inputs[pix * 3], inputs[pix * 3 + 1], inputs[pix * 3 + 2]);
 }
 
+// ---- TSM ShareLayer (/root/reference/model_with_TSM.py:199-229) = offset warp -> group max|mean -> tile -> inverse warp ----
+// tf_batch_map_offsets (/root/reference/warp.py:134-165): offsets = resize(reg, [S,S]) * S (centre-2x2 mean for the exact
+// 8x reduction), channels 0:2; coords = offsets + (i, j); clamp to [0, S-1]; corners floor / ceil; lerp along axis 0
+// first, then axis 1 (warp.py:111-113).
+
+// reg [B,H,W,6] = reg_in(3) | reg_out(3) -> reg32 [B*cells][4] = (in0, in1, out0, out1) * S
+__global__ void reg_resize8_kernel(const float* __restrict__ reg, int H, int W, float* __restrict__ reg32, size_t ncell) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncell * 4) return;
+  const size_t cell = gid / 4;
+  const int k = (int)(gid % 4);
+  const int c = (k & 1) + 3 * (k >> 1);                    // channels 0,1 of reg_in and 3,4 (= 0,1 of reg_out)
+  const int h8 = H / 8, w8 = W / 8;
+  const int p = (int)(cell % w8), o = (int)((cell / w8) % h8);
+  const size_t img = cell / ((size_t)w8 * h8);
+  const float* src = reg + ((img * H + 8 * o + 3) * W + 8 * p + 3) * 6 + c;
+  const float a = src[0], b = src[6], cc = src[(size_t)W * 6], d = src[(size_t)W * 6 + 6];
+  const float v = 0.5f * (0.5f * a + 0.5f * b) + 0.5f * (0.5f * cc + 0.5f * d);
+  reg32[gid] = v * (float)h8;
+}
+
+struct WarpTaps {
+  int i0, i1, j0, j1;
+  float o0, o1;
+};
+__device__ __forceinline__ WarpTaps warp_taps(float c0, float c1, int S) {
+  c0 = fminf(fmaxf(c0, 0.f), (float)(S - 1));
+  c1 = fminf(fmaxf(c1, 0.f), (float)(S - 1));
+  const float f0 = floorf(c0), f1 = floorf(c1);
+  WarpTaps t;
+  t.i0 = (int)f0; t.i1 = (int)ceilf(c0); t.j0 = (int)f1; t.j1 = (int)ceilf(c1);
+  t.o0 = c0 - f0; t.o1 = c1 - f1;
+  return t;
+}
+__device__ __forceinline__ float warp_lerp(float lt, float rt, float lb, float rb, float o0, float o1) {
+  const float vt = lt + (rt - lt) * o0;      // (i0,j0) -> (i1,j0)
+  const float vb = lb + (rb - lb) * o0;      // (i0,j1) -> (i1,j1)
+  return vt + (vb - vt) * o1;
+}
+
+// share[g][cell][0..C) = max_f warp(x[g*frame+f], reg_in), [C..2C) = mean_f.  One workgroup per (group, cell).
+__global__ void share_reduce_kernel(const float* __restrict__ x, int x_cs, int C, const float* __restrict__ reg32, int S, int frame,
+                                    float* __restrict__ share) {
+  const int cells = S * S;
+  const int cell = blockIdx.x % cells, g = blockIdx.x / cells;
+  const int i = cell / S, j = cell % S;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mx = -INFINITY, sum = 0.f;
+    for (int f = 0; f < frame; ++f) {
+      const size_t b = (size_t)g * frame + f;
+      const float* r = reg32 + (b * cells + cell) * 4;
+      const WarpTaps t = warp_taps(r[0] + (float)i, r[1] + (float)j, S);
+      const float* xb = x + b * cells * x_cs + c;
+      const float v = warp_lerp(xb[(size_t)(t.i0 * S + t.j0) * x_cs], xb[(size_t)(t.i1 * S + t.j0) * x_cs],
+                                xb[(size_t)(t.i0 * S + t.j1) * x_cs], xb[(size_t)(t.i1 * S + t.j1) * x_cs], t.o0, t.o1);
+      mx = fmaxf(mx, v);
+      sum += v;
+    }
+    float* o = share + ((size_t)g * cells + cell) * 2 * C;
+    o[c] = mx;
+    o[C + c] = sum / (float)frame;
+  }
+}
+
+// out[b][cell][coff .. coff+2C) = warp(share[b / frame], reg_out[b])   (share != 0), or cat[x, x] (share == 0)
+__global__ void share_unwarp_kernel(const float* __restrict__ share, const float* __restrict__ x, int x_cs, int C,
+                                    const float* __restrict__ reg32, int S, int frame, int do_share, float* __restrict__ out, int out_cs,
+                                    int out_coff) {
+  const int cells = S * S;
+  const int cell = blockIdx.x % cells;
+  const size_t b = blockIdx.x / cells;
+  float* o = out + (b * cells + cell) * out_cs + out_coff;
+  if (!do_share) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float v = x[(b * cells + cell) * x_cs + c];
+      o[c] = v;
+      o[C + c] = v;
+    }
+    return;
+  }
+  const int i = cell / S, j = cell % S;
+  const float* r = reg32 + (b * cells + cell) * 4;
+  const WarpTaps t = warp_taps(r[2] + (float)i, r[3] + (float)j, S);
+  const float* sb = share + (b / frame) * cells * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {
+    o[c] = warp_lerp(sb[(size_t)(t.i0 * S + t.j0) * 2 * C + c], sb[(size_t)(t.i1 * S + t.j0) * 2 * C + c],
+                     sb[(size_t)(t.i0 * S + t.j1) * 2 * C + c], sb[(size_t)(t.i1 * S + t.j1) * 2 * C + c], t.o0, t.o1);
+  }
+}
+
+// out[px][c] = LeakyReLU(x[px][c]) for c in [c0, c1): the channels of a ResBottleneck output beyond the 288 the `w` GEMM
+// covers (the wider of x / y is kept, the narrower zero-padded: model.py:105-113; only the TSM widths 291 / 877 get here)
+__global__ void lrelu_copy_kernel(const float* __restrict__ x, int x_cs, float* __restrict__ out, int out_cs, int c0, int c1, size_t npix) {
+  const int nc = c1 - c0;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= npix * nc) return;
+  const size_t px = gid / nc;
+  const int c = c0 + (int)(gid % nc);
+  const float v = x[px * x_cs + c];
+  out[px * out_cs + c] = fmaxf(v, v * kLeakyAlpha);
+}
+
 // dense copy of a channel slice of an NHWC buffer (debug probes only)
 __global__ void slice_copy_kernel(const float* __restrict__ src, int cs, int coff, int c, float* __restrict__ dst, size_t npix) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -111,6 +111,39 @@ class Generator:
         self._shape = (B, H, W)
         return gs, con_rgb, mask22, dif
 
+    # -- TSM variant ------------------------------------------------------------------------
+    def call_tsm(self, inputs, uv, reg, frame: int, share: bool = True, chuck: int = 1, training: bool = False):
+        """``Generator.call(inputs, uv, reg, frame, share, chuck, training)`` of /root/reference/model_with_TSM.py:261-325
+        (call site /root/reference/train_with_TSM.py:676).  Needs TSM weights (291-channel ``res_stack/0/conv1``)."""
+        if training:
+            raise NotImplementedError("only the inference path (training=False) is implemented")
+        if self._handle is None:
+            raise RuntimeError("Generator has no weights: call load_weights() or restore() first")
+        dev = self._device
+        inputs = self._check_input(inputs, "inputs", dev)
+        uv = self._check_input(uv, "uv", dev)
+        if not isinstance(reg, torch.Tensor):
+            reg = torch.as_tensor(np.asarray(reg))
+        if reg.dim() != 4 or reg.shape[-1] != 6 or reg.shape[:3] != inputs.shape[:3] or reg.dtype != torch.float32:
+            raise ValueError("reg must be float32 [B,H,W,6] (reg_in | reg_out), got %s %s" % (tuple(reg.shape), reg.dtype))
+        reg = reg.to("cuda:%d" % dev).contiguous()
+        B, H, W, _ = inputs.shape
+        if H != W or H % 256:
+            raise ValueError("the TSM path needs square images with H a multiple of 256, got %dx%d" % (H, W))
+        if frame <= 0 or B % frame:
+            raise ValueError("batch %d is not a multiple of frame %d" % (B, frame))
+        with torch.cuda.device(dev):
+            gs = torch.empty((B, H, W, 1), dtype=torch.float32, device=inputs.device)
+            con_rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=inputs.device)
+            mask22 = torch.empty((B, H, W, 3), dtype=torch.float32, device=inputs.device)
+            dif = torch.empty((B, H, W, 1), dtype=torch.float32, device=inputs.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = self._lib.bsr_forward_tsm(self._handle, inputs.data_ptr(), uv.data_ptr(), reg.data_ptr(), B, H, W, int(frame), 1 if share else 0,
+                                           gs.data_ptr(), con_rgb.data_ptr(), mask22.data_ptr(), dif.data_ptr(), stream)
+        _lib.check(rc, "bsr_forward_tsm")
+        self._shape = (B, H, W)
+        return gs, con_rgb, mask22, dif
+
     # -- test / measurement hooks -----------------------------------------------------------
     def probe(self, name: str) -> torch.Tensor:
         """Intermediate of the last forward as a dense NHWC tensor (see bsr_probe in include/bsr_hip.h)."""
@@ -133,3 +166,11 @@ class Generator:
         n = (ctypes.c_int * _lib.NUM_CLASSES)()
         _lib.check(self._lib.bsr_get_timing(self._handle, ctypes.byref(ms), ctypes.byref(n)), "bsr_get_timing")
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.CLASS_NAMES)}
+
+
+class GeneratorTSM(Generator):
+    """Drop-in for ``Generator`` of /root/reference/model_with_TSM.py:231-325 (temporal-sharing variant, BASELINE config 5):
+    ``gen(inputs, uv, reg, frame, share, chuck, training)``."""
+
+    def __call__(self, inputs, uv, reg, frame, share=True, chuck: int = 1, training: bool = False):
+        return self.call_tsm(inputs, uv, reg, frame, share, chuck, training)

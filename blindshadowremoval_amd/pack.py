@@ -17,7 +17,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-from .weights import BN_EPS, N_RES, check_weights
+from .weights import BN_EPS, N_RES, check_weights, detect_variant
 
 BLOB_MAGIC = 0x57525342   # "BSRW"
 BLOB_VERSION = 1
@@ -26,18 +26,25 @@ _HEADER = struct.Struct("<4I")
 
 TRANSPOSED = ("up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3")
 
-# name -> (CC, k_pad, n_pad): must match the launch table in csrc/bsr_api.hip
-GEOMETRY: Dict[str, Tuple[int, int, int]] = {
-    "conv1": (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),
-    "up1": (24, 264, 96), "up2": (32, 160, 64), "up3": (32, 128, 64), "heads": (32, 64, 16),
-    "clr_up1": (24, 264, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (32, 64, 16),
-}
-for _i in range(N_RES):
-    _cin_pad = 120 if _i == 0 else 264
-    GEOMETRY["res%d.conv1" % _i] = (24, _cin_pad, 128)
-    GEOMETRY["res%d.conv2" % _i] = (32, 128, 128)
-    GEOMETRY["res%d.c3q" % _i] = (32, 128, 768)       # [y3: 257 real of 288 | theta|phi|g: 384 | 3 zero tiles of slack]
-    GEOMETRY["res%d.w" % _i] = (32, 128, 384)           # 257 real of 288 + 3 zero tiles of slack (gemm_nloop group reads)
+def geometry(variant: str = "gsc") -> Dict[str, Tuple[int, int, int]]:
+    """name -> (CC, k_pad, n_pad): must match the launch table in csrc/bsr_api.hip.  The TSM variant
+    (/root/reference/model_with_TSM.py) only widens the K of the layers fed by the ShareLayer concats: 291 -> 312, 877 -> 888."""
+    tsm = variant == "tsm"
+    k_a, k_r, k_h = (312, 312, 888) if tsm else (120, 264, 264)
+    g: Dict[str, Tuple[int, int, int]] = {
+        "conv1": (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),
+        "up1": (24, k_r, 96), "up2": (32, 160, 64), "up3": (32, 128, 64), "heads": (32, 64, 16),
+        "clr_up1": (24, k_h, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (32, 64, 16),
+    }
+    for i in range(N_RES):
+        g["res%d.conv1" % i] = (24, k_a if i == 0 else (k_r if i < N_RES // 2 else k_h), 128)
+        g["res%d.conv2" % i] = (32, 128, 128)
+        g["res%d.c3q" % i] = (32, 128, 768)       # [y3: 257 real of 288 | theta|phi|g: 384 | 3 zero tiles of slack]
+        g["res%d.w" % i] = (32, 128, 384)         # 257 real of 288 + 3 zero tiles of slack (gemm_nloop group reads)
+    return g
+
+
+GEOMETRY = geometry("gsc")
 
 
 def fold_bn(kernel_tkn: np.ndarray, bias: np.ndarray, bn: Dict[str, np.ndarray] | None):
@@ -129,10 +136,12 @@ def tail_weights(w: Dict[str, np.ndarray]) -> np.ndarray:
 
 def pack_generator(weights: Dict[str, np.ndarray]) -> bytes:
     """reference-named variables -> blob for ``bsr_create``."""
-    check_weights(weights)
+    variant = detect_variant(weights)
+    check_weights(weights, variant)
+    geo = geometry(variant)
     entries: List[Tuple[str, np.ndarray, Tuple[int, int, int, int]]] = []
     for name, (k, b) in layer_matrices(weights).items():
-        cc, k_pad, n_pad = GEOMETRY[name]
+        cc, k_pad, n_pad = geo[name]
         arr, bias = pack_taps(k, b, cc, k_pad, n_pad)
         entries.append((name + ".w", arr, tuple(arr.shape)))
         entries.append((name + ".b", bias, (n_pad, 0, 0, 0)))

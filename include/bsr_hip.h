@@ -47,6 +47,14 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
 int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W,
                 float* gs, float* con_rgb, float* mask22, float* dif, void* stream);
 
+/* TSM variant (BASELINE config 5): replaces Generator.call(inputs, uv, reg, frame, share, chuck, training=False) of
+ * /root/reference/model_with_TSM.py:261-325 (call site /root/reference/train_with_TSM.py:676).  The handle must have been
+ * created from TSM weights (res_stack/0/conv1 with 291 input channels).  reg: [B,H,W,6] = reg_in(3) | reg_out(3) offset
+ * fields (image-fraction units); consecutive groups of `frame` images share features through the UV/offset warp
+ * (ShareLayer, model_with_TSM.py:199-229; warp.py:134-165).  share = 0 reproduces the tf.cond(share, ...) false branch. */
+int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const float* reg, int B, int H, int W, int frame, int share,
+                    float* gs, float* con_rgb, float* mask22, float* dif, void* stream);
+
 /* Bytes of activation workspace the library holds for a batch of B HxW images (grown lazily by
  * bsr_forward; growth synchronises the stream — call bsr_reserve first to keep forwards allocation-free). */
 size_t bsr_workspace_bytes(int B, int H, int W);

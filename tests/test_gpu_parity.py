@@ -154,3 +154,41 @@ def test_wider_input_512(gen_w):
     torch.manual_seed(8)
     inp, uv = torch.rand(1, 256, 512, 3), torch.rand(1, 256, 512, 3)
     run_and_compare(gen, w, inp, uv)
+
+
+@pytest.mark.parametrize("frame,share", [(2, True), (4, True), (2, False)])
+def test_tsm_variant_matches_oracle(frame, share):
+    """BASELINE config 5 path: TSM generator = GSC net + ShareLayer (offset warp -> group max|mean -> inverse warp),
+    /root/reference/model_with_TSM.py:199-325, against the TSM oracle whose warp is pinned to the reference's scipy form."""
+    from blindshadowremoval_amd import GeneratorTSM
+    from oracle.gsc_oracle import GeneratorTSMOracle
+    w = init_weights(1, variant="tsm")
+    gen = GeneratorTSM().load_weights(w)
+    torch.manual_seed(13 + frame)
+    B = 4
+    inp, uv = torch.rand(B, 256, 256, 3), torch.rand(B, 256, 256, 3)
+    # smooth offset fields of a few cells amplitude (real fields are |.| <~ 0.11 image fractions), some leaving the map
+    reg = torch.nn.functional.interpolate((torch.rand(B, 6, 9, 9) - 0.5) * 0.3, size=(256, 256), mode="bicubic", align_corners=True).permute(0, 2, 3, 1).contiguous()
+    reg[..., 2] = 0
+    reg[..., 5] = 0
+    out = [t.cpu() for t in gen(inp.cuda(), uv.cuda(), reg.cuda(), frame, share)]
+    bmask = gen.probe("bmask").cpu()
+    oracle = GeneratorTSMOracle(w)
+    pr = {}
+    ref = oracle(inp, uv, reg, frame, share, probes=pr)
+    assert float((gen.probe("d32").cpu() - pr["d32"]).abs().max()) <= 1e-3
+    flips = bmask != pr["bmask"]
+    if int(flips.sum()):
+        assert float((pr["d32"][flips] - 0.1).abs().max()) < 2e-5
+        pr = {}
+        ref = oracle(inp, uv, reg, frame, share, probes=pr, bmask_override=bmask)
+    assert float((gen.probe("x0").cpu() - pr["x0"]).abs().max()) <= 1e-4         # cat[x, x_share, uv]: first ShareLayer
+    assert float((gen.probe("res2").cpu() - pr["res2"]).abs().max()) <= 1e-3    # 291-wide blocks
+    assert float((gen.probe("res5").cpu() - pr["res5"]).abs().max()) <= 1e-3    # 877-wide blocks
+    for a, b, name in zip(out, ref, ("gs", "con_rgb", "mask22", "dif")):
+        assert float((a - b).abs().max()) <= 1e-3, name
+    # API misuse: GSC call on a TSM handle, bad frame
+    with pytest.raises(RuntimeError, match="TSM weights"):
+        gen.__class__.__mro__[1].__call__(gen, inp[:1], uv[:1])
+    with pytest.raises(ValueError):
+        gen(inp, uv, reg, 3, True)
