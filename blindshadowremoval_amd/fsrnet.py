@@ -190,3 +190,92 @@ class FSRNet(object):
     def test(self, dataset_val, batch: int = 16):
         """train_test_GSC.py:360-408 (generator part; see module docstring)."""
         return self._loop(dataset_val, batch, ucb=True)
+
+
+def roc_auc_score(labels: np.ndarray, scores: np.ndarray) -> float:
+    """Area under the ROC curve = Mann-Whitney U with average ranks for ties (what sklearn.metrics.roc_auc_score computes
+    for binary labels; the reference calls it at train_with_TSM.py:701)."""
+    labels = np.asarray(labels).reshape(-1) > 0.5
+    scores = np.asarray(scores, np.float64).reshape(-1)
+    order = np.argsort(scores, kind="mergesort")
+    s = scores[order]
+    ranks = np.empty(len(s), np.float64)
+    i = 0
+    while i < len(s):
+        j = i
+        while j + 1 < len(s) and s[j + 1] == s[i]:
+            j += 1
+        ranks[i:j + 1] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    r = np.empty_like(ranks)
+    r[order] = ranks
+    n_pos, n_neg = int(labels.sum()), int((~labels).sum())
+    if n_pos == 0 or n_neg == 0:
+        raise ValueError("roc_auc_score needs both classes")
+    return float((r[labels].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
+
+
+class FSRNetTSM(object):
+    """Inference harness of the temporal-sharing variant (/root/reference/train_with_TSM.py:619-748): `testsfw`
+    (image + mirror, frame = 2, shadow-segmentation AUC) and `testsfw_video` (10 video frames, frame = 10)."""
+    SPLIT_SFW = (3, 3, 1, 3, 6, 1)        # img, cmap, mask, uv, reg, face   (train_with_TSM.py:675)
+    SPLIT_VIDEO = (3, 3, 6, 1)            # img, uv, reg, face               (train_with_TSM.py:727)
+
+    def __init__(self, config: Config, weights: Optional[Dict[str, np.ndarray]] = None):
+        from .model import GeneratorTSM
+        self.config = config
+        self.gen = GeneratorTSM(device=config.GPU_INDEX if torch.cuda.is_available() else None)
+        if weights is not None:
+            self.gen.load_weights(weights)
+        self.log = Logging(config)
+
+    def _prep(self, img, n: int, split):
+        s = self.config.IMG_SIZE
+        t = torch.as_tensor(np.asarray(img) if not isinstance(img, torch.Tensor) else img, dtype=torch.float32)
+        return torch.split(t.reshape(n, s, s, t.shape[-1]), list(split), dim=3)
+
+    def test_step_sfw(self, img, box=None, training: bool = False):
+        """train_with_TSM.py:668-707: element = [2,256,256,17] (image + mirror)."""
+        im, cmap, mask, uv, reg, face = self._prep(img, 2, self.SPLIT_SFW)
+        dev = "cuda:%d" % self.gen._device
+        _, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg.contiguous().to(dev), frame=2, share=True,
+                                            chuck=1, training=training)
+        mask_pred = mask_pred * face.to(dev)
+        con_rgb = torch.clamp(con_rgb, 0, 1)
+        label = (mask[0] == 2).float()                                              # :685
+        pred0 = mask_pred[0].detach().cpu()
+        mse = float(((mask[0] - pred0) ** 2).mean())
+        losses = {"psnr": float(10 * np.log10(1.0 / mse)) if mse > 0 else float("inf")}
+        lab = np.concatenate([[1, 0], label.numpy().reshape(-1)])                   # :688-692: one forced sample of each class
+        sc = np.concatenate([[1, 0], pred0.numpy().reshape(-1)])
+        losses["auc"] = roc_auc_score(lab, sc)
+        return losses, [im.to(dev), con_rgb, mask_pred * 2, label.reshape(1, *label.shape).to(dev)]
+
+    def test_step_sfw_video(self, img, box=None, training: bool = False):
+        """train_with_TSM.py:720-748: element = [10,256,256,13] (10 consecutive frames share features)."""
+        im, uv, reg, face = self._prep(img, 10, self.SPLIT_VIDEO)
+        dev = "cuda:%d" % self.gen._device
+        _, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg.contiguous().to(dev), frame=10, share=True,
+                                            chuck=1, training=training)
+        return {}, [im.to(dev), torch.clamp(con_rgb, 0, 1), mask_pred * face.to(dev) * 2]
+
+    def _loop(self, dataset_val, step_fn):
+        if self.gen._handle is None and self.gen.restore(self.config.CHECKPOINT_DIR) == 0 and self.gen._handle is None:
+            raise RuntimeError("no generator weights: checkpoint data shard missing under %s" % self.config.CHECKPOINT_DIR)
+        start = time.time()
+        names = list(dataset_val.name_list)
+        results = []
+        for step, img_name in enumerate(names):
+            element = next(dataset_val.feed)
+            losses, figs = step_fn(element[0], element[1] if len(element) > 1 else None, training=False)
+            self.log.display(losses, 0, step, False, len(names))
+            self.log.save_img(figs, _name(img_name))
+            results.append((_name(img_name), losses, figs))
+        print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
+        return results
+
+    def testsfw(self, dataset_val):
+        return self._loop(dataset_val, self.test_step_sfw)
+
+    def testsfw_video(self, dataset_val):
+        return self._loop(dataset_val, self.test_step_sfw_video)
