@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   float* s_w = smem;
   float* s_bias = smem + 3 * C::W_FLOATS;
 
+#ifdef BSR_STAMPS
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st_epi = 0, rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
@@ -67,7 +70,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
       if (tid + i * 256 < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
   };
 
-  // ---- prologue: this lane's A fragments (pixel r of the wave's 32, channels 8g + 4h .. +3) + weight steps 0, 1 ----
+  // ---- prologue: everything is issued before anything is waited for: weight steps 0 and 1, the bias slice, and this
+  // lane's A fragments (pixel r of the wave's 32, channels 8g + 4h .. +3) ----
+  f32x4 w_regs[C::W_PER_THREAD], w_regs1[C::W_PER_THREAD];
+  fetch_w(0, w_regs);
+  if (nsteps > 1) fetch_w(1, w_regs1);
   f32x4 afr[NCH * G];
   {
     const float* row = p.in + (pix0 + wave * 32 + r) * p.in_cs + p.in_coff + 4 * h;
@@ -75,13 +82,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
     for (int g = 0; g < NCH * G; ++g) afr[g] = *reinterpret_cast<const f32x4*>(row + g * 8);
   }
   for (int i = tid; i < (t1 - t0) * 32; i += 256) s_bias[i] = p.bias[t0 * 32 + i];   // keeps bias loads out of the MFMA loop's vmcnt queue
-  f32x4 w_regs[C::W_PER_THREAD];
-  fetch_w(0, w_regs);
   store_w(0, w_regs);
-  if (nsteps > 1) {
-    fetch_w(1, w_regs);
-    store_w(C::W_FLOATS, w_regs);
-  }
+  if (nsteps > 1) store_w(C::W_FLOATS, w_regs1);
   __syncthreads();
 
   int w_cur = 0, w_n1 = C::W_FLOATS, w_n2 = 2 * C::W_FLOATS;
@@ -92,6 +94,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   };
   read_frags(0, w_cur);
   __builtin_amdgcn_s_setprio(0);
+#ifdef BSR_STAMPS
+  st1 = __builtin_amdgcn_s_memtime();
+#endif
 
   const bool has_res = p.res1 != nullptr;
   const unsigned lane_out = (unsigned)(4 * h) * (unsigned)p.out_cs + (unsigned)r;
@@ -140,6 +145,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
 
     // ---- epilogue of this channel group (same form as igemm_conv_kernel's) ----
     __builtin_amdgcn_s_setprio(3);
+#ifdef BSR_STAMPS
+    const unsigned long long se0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       if (ni >= nvalid) continue;
@@ -178,7 +186,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
       }
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef BSR_STAMPS
+    st_epi += __builtin_amdgcn_s_memtime() - se0;
+#endif
   }
+#ifdef BSR_STAMPS
+  if (p.stamps != nullptr && lane == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime(), rt3 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* d = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+    d[0] = st1 - st0; d[1] = st3 - st1 - st_epi; d[2] = ((rt3 - rt0) << 32) | st_epi; d[3] = st_epi;
+  }
+#endif
 }
 
 template <int NI, int NCH>

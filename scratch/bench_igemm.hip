@@ -2,6 +2,7 @@
 // -DBSR_STAMPS, reports where a wave's cycles go (prologue / main loop / epilogue).
 #define BSR_STAMPS 1
 #include "../blindshadowremoval_amd/csrc/igemm_conv.h"
+#include "../blindshadowremoval_amd/csrc/gemm_nloop.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -54,8 +55,43 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   return 0;
 }
 
+int run_gemm(const char* name, int pixels, int N, int nsplit, bool res) {
+  const int K = 128, n_pad = ((N + 31) / 32 + 3) * 32;
+  size_t n_in = (size_t)pixels * K, n_out = (size_t)pixels * N, n_w = (size_t)4 * n_pad * 36;
+  float *d_in, *d_out, *d_w, *d_b, *d_r;
+  CK(hipMalloc(&d_in, n_in * 4)); CK(hipMalloc(&d_out, n_out * 4)); CK(hipMalloc(&d_w, n_w * 4)); CK(hipMalloc(&d_b, n_pad * 4)); CK(hipMalloc(&d_r, n_out * 4));
+  std::vector<float> h_in(n_in), h_w(n_w);
+  for (auto& v : h_in) v = (float)rand() / RAND_MAX - 0.5f;
+  for (auto& v : h_w) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+  CK(hipMemcpy(d_in, h_in.data(), n_in * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_w, h_w.data(), n_w * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(d_b, 0, n_pad * 4)); CK(hipMemset(d_r, 0, n_out * 4));
+  ConvArgs a{};
+  a.in = d_in; a.in_cs = K; a.out = d_out; a.out_cs = N; a.w = d_w; a.bias = d_b; a.nchunk = 4; a.n_pad = n_pad; a.n_store = N; a.act = 1;
+  if (res) { a.res1 = d_r; a.res1_cs = N; a.res1_c = N; a.res2 = d_r; a.res2_cs = N; a.res2_c = N; }
+  size_t nblk = (size_t)(pixels / 128) * nsplit;
+  unsigned long long* d_st; CK(hipMalloc(&d_st, nblk * 16 * 8)); a.stamps = d_st;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e9;
+  for (int it = 0; it < 6; ++it) {
+    CK(hipEventRecord(e0)); CK((launch_gemm_nloop<3, 4>(a, pixels, nsplit, 0))); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it > 0) best = std::min(best, ms);
+  }
+  std::vector<unsigned long long> st(nblk * 16);
+  CK(hipMemcpy(st.data(), d_st, nblk * 16 * 8, hipMemcpyDeviceToHost));
+  double pro = 0, loop = 0, epi = 0, rt = 0;
+  for (size_t i = 0; i < nblk * 4; ++i) { pro += st[i * 4]; loop += st[i * 4 + 1]; epi += st[i * 4 + 3]; rt += (double)(st[i * 4 + 2] >> 32); }
+  double nw = nblk * 4.0;
+  printf("%-12s %7.1f us  %6.1f TFLOP/s | blocks %zu | per wave: prologue %.0f  loop(excl epi) %.0f  epilogues %.0f | clock %.2f GHz, lifetime %.1f us\n", name, best * 1e3,
+         2.0 * pixels * K * N / best / 1e9, nblk, pro / nw, loop / nw, epi / nw, (pro + loop + epi) / rt * 0.1, rt / nw * 0.01);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc > 1) g_mode = atoi(argv[1]);
+  if (run_gemm("c3q", 32768, 672, 2, false)) return 1;
+  if (run_gemm("c3q/split1", 32768, 672, 1, false)) return 1;
+  if (run_gemm("w", 32768, 288, 2, true)) return 1;
+  if (run_gemm("w/nores", 32768, 288, 2, false)) return 1;
   if (run<3, 3, 1, true, 2, 32, 1>("up3", 32, 128, 128, 128, 64)) return 1;
   if (run<3, 3, 1, true, 2, 32, 2>("up3/inb2", 32, 128, 128, 128, 64)) return 1;
   if (run<3, 3, 1, true, 1, 32, 1>("up3/ni1", 32, 128, 128, 128, 64)) return 1;
