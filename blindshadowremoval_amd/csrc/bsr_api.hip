@@ -17,6 +17,7 @@
 #include "gemm_nloop.h"
 #include "glue_kernels.h"
 #include "igemm_conv.h"
+#include "stem7.h"
 
 namespace {
 
@@ -84,7 +85,7 @@ Plan make_plan(size_t B, size_t H, size_t W, const Variant& v = kGSC) {
     return o;
   };
   const size_t px = B * H * W, cells = px / 64;
-  p.xr = take(px * 24);
+  p.xr = take(0);      // (the im2row buffer of the first version; the stem kernel reads the image directly)
   p.x1 = take(px * 32);
   p.c3 = take(px / 4 * 128);
   p.c2 = take(px / 16 * 160);
@@ -420,11 +421,17 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   auto glue_begin = [&]() { L.begin(K_GLUE); };
   auto glue_end = [&](const char* what) { L.check(hipGetLastError(), what); L.end(); };
 
-  // conv1 = Conv(32, 7x7) (model.py:203,230): im2row over kx, then a 7x1 MFMA conv with K = 7 x 24
-  glue_begin();
-  hipLaunchKernelGGL(bsr::im2row7_kernel, dim3((unsigned)((npix * 6 + 255) / 256)), dim3(256), 0, s, inputs, ws + p.xr, W, npix);
-  glue_end("im2row7");
-  L.conv<7, 1, 1, false, 1, 24, 1>(K_CONV7, "conv1", ws + p.xr, 24, 0, 24, H, W, ws + p.x1, 32, 0, 32, 1);
+  // conv1 = Conv(32, 7x7) + BN + LeakyReLU (model.py:203,230): dedicated stem kernel (7 row taps x 21 contiguous floats)
+  {
+    LayerW l;
+    L.rc = find_layer(h, "conv1", 1, 7, 28, 32, &l);
+    if (L.rc == BSR_OK) {
+      bsr::StemArgs a{inputs, ws + p.x1, l.w, l.b, H, W, 0, 0};
+      L.begin(K_CONV7);
+      L.check(bsr::launch_stem7<4>(a, B, s), "conv1");
+      L.end();
+    }
+  }
   // down1..3 = Conv(stride 2) (model.py:207-209,231-233); x2 / x3 land in their skip-concat slots (model.py:244-245)
   L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down1", ws + p.x1, 32, 0, 32, H, W, ws + p.c3, 128, 64, 64, 1);
   L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down2", ws + p.c3, 128, 64, 64, H2, W2, ws + p.c2, 160, 96, 64, 1);

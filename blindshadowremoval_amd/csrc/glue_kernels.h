@@ -15,27 +15,6 @@ __device__ __forceinline__ float gray3(float r, float g, float b) {
   return (r * 0.2989f + g * 0.5870f) + b * 0.1140f;
 }
 
-// inputs [B,H,W,3] -> xr [B,H,W,24]: xr[y][x][kx*3+c] = in[y][x+kx-3][c] (zero outside), ch 21..23 = 0.
-// Turns the 7x7x3 stem conv (model.py:203,230) into a 7x1 conv over 24 channels for the MFMA kernel.
-__global__ void im2row7_kernel(const float* __restrict__ in, float* __restrict__ xr, int W, size_t npix) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (pixel, float4 of 24 ch)
-  const size_t pix = gid / 6;
-  const int q = (int)(gid % 6);
-  if (pix >= npix) return;
-  const int x = (int)(pix % W);
-  f32x4 v;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int k = q * 4 + e;           // kx*3 + c
-    const int kx = k / 3, c = k % 3;
-    const int sx = x + kx - 3;
-    float val = 0.f;
-    if (k < 21 && sx >= 0 && sx < W) val = in[(pix + (size_t)(kx - 3)) * 3 + c];
-    v[e] = val;
-  }
-  *reinterpret_cast<f32x4*>(xr + pix * 24 + q * 4) = v;
-}
-
 // tf.image.resize(uv, [H/8, W/8]) bilinear, half-pixel centres (model.py:237): for an exact 8x reduction
 // the sample point is 8o+3.5, i.e. the mean of the centre 2x2 block.  Writes the 3 channels into two
 // concat slots: dst_a[..., coff_a..] (model.py:238) and dst_b[..., coff_b..] (model.py:259).

@@ -1,0 +1,112 @@
+// Stem: conv1 = Conv(32, 7x7) + BN + LeakyReLU over the 3-channel image (/root/reference/model.py:203,230), Cin = 3.
+//
+// K = 7 x 7 x 3 = 147 is too thin per tap for the generic channel-chunk kernel, but in NHWC a pixel's 7 horizontal taps x 3
+// channels are 21 CONTIGUOUS floats of the image row.  The raw (TH+6) x (TW+6) x 3 tile is staged once in LDS and the
+// A fragment of pixel tx, K group g is simply the 4 floats at row + 3*tx + 8g + 4h (+j): the "im2row" is only an
+// address pattern (stride 3 floats per lane: conflict-free ds_read_b32), no 24-channel expansion buffer exists.
+// GEMM per vertical tap ky: M = pixels, N = 32, K = 21 -> 24 (the 3 pad columns read the next pixel's data and meet
+// zero weights).  All 7 taps' weights (25 KB) are staged once, so the MFMA stream has no barrier inside.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "igemm_conv.h"
+
+namespace bsr {
+
+struct StemArgs {
+  const float* in;     // [B,H,W,3]
+  float* out;          // [B,H,W,32]
+  const float* w;      // packed [1][7][32][28]  (taps = ky, K index = kx*3 + c, 21 real of 24)
+  const float* bias;   // [32]
+  int H, W;
+  int tiles_x, tiles_y;
+};
+
+template <int RW>   // image rows per wave
+struct StemCfg {
+  static constexpr int TH = 4 * RW, TW = 32, IH = TH + 6, ROWF = 120;   // 38 pixels x 3 floats = 114 used, reads reach 116
+  static constexpr int IN_FLOATS = IH * ROWF;
+  static constexpr int W_FLOATS = 7 * 32 * 28;
+  static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS) * 4;
+};
+
+template <int RW>
+__global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
+  using C = StemCfg<RW>;
+  constexpr int ROWF = C::ROWF;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_w = smem;                    // weights first: 16-byte aligned rows for ds_read_b128
+  float* s_in = smem + C::W_FLOATS;
+
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  int bid = blockIdx.x;
+  const int tile_x = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int tile_y = bid % p.tiles_y;
+  const int img = bid / p.tiles_y;
+  const int y0 = tile_y * C::TH, x0 = tile_x * C::TW;
+  const float* in_img = p.in + (size_t)img * p.H * p.W * 3;
+
+  // stage the weights (linear copy) and the raw image tile (zero outside the image: TF SAME padding 3/3)
+  for (int i = tid; i < C::W_FLOATS / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+  for (int i = tid; i < C::IN_FLOATS; i += 256) {
+    const int row = i / ROWF, f = i % ROWF;
+    const int px = f / 3, c = f % 3;
+    const int iy = y0 - 3 + row, ix = x0 - 3 + px;
+    float v = 0.f;
+    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = in_img[((size_t)iy * p.W + ix) * 3 + c];
+    s_in[i] = v;
+  }
+  const float bias = p.bias[r];
+  f32x16 acc[RW];
+#pragma unroll
+  for (int mi = 0; mi < RW; ++mi)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mi][i] = bias;
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
+
+  const int a_base = (wave * RW) * ROWF + 3 * r + 4 * h;      // + (mi + ky) * ROWF + 8g + j
+  const int b_base = r * 28 + 4 * h;                            // + ky * 32 * 28 + 8g
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(s_w + b_base + ky * 32 * 28 + g * 8);
+      float af[RW][4];
+#pragma unroll
+      for (int mi = 0; mi < RW; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[mi][j] = s_in[a_base + (mi + ky) * ROWF + g * 8 + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < RW; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[j], acc[mi], 0, 0, 0);
+    }
+  }
+
+  __builtin_amdgcn_s_setprio(3);
+  const unsigned lane_out = (unsigned)(4 * h) * 32u + (unsigned)r;
+#pragma unroll
+  for (int mi = 0; mi < RW; ++mi) {
+    const size_t row_pix = ((size_t)img * p.H + y0 + wave * RW + mi) * p.W + x0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = (i & 3) + 8 * (i >> 2);
+      const float v = acc[mi][i];
+      (p.out + (row_pix + k) * 32)[lane_out] = fmaxf(v, v * kLeakyAlpha);
+    }
+  }
+}
+
+template <int RW>
+inline hipError_t launch_stem7(StemArgs a, int batch, hipStream_t stream) {
+  using C = StemCfg<RW>;
+  a.tiles_x = a.W / C::TW;
+  a.tiles_y = a.H / C::TH;
+  hipLaunchKernelGGL(stem7_kernel<RW>, dim3(a.tiles_x * a.tiles_y * batch), dim3(256), C::SMEM_BYTES, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace bsr

@@ -45,7 +45,8 @@ def test_bn_fold_matches_conv_then_bn(w):
 
 
 def test_stem_im2row_equivalence(w):
-    """conv1 7x7x3 == 7x1 conv over the 24-channel row-expanded input (im2row7_kernel + igemm 7x1)."""
+    """conv1 7x7x3 == 7 row taps over 24-wide windows of the raw NHWC row (21 contiguous floats + 3 zero-weight columns):
+    the address pattern stem7_kernel reads from its LDS tile, emulated here with an explicit row expansion."""
     rng = np.random.default_rng(1)
     x = rng.random((1, 12, 16, 3)).astype(np.float32)
     ref = O.GeneratorOracle(w).conv_block(torch.from_numpy(x), "conv1").numpy()
