@@ -33,6 +33,9 @@ struct ConvN16Args {
   float* con_rgb;       // TAIL: [B,H,W,3]
   float* dif;           // TAIL: [B,H,W,1]
   int tiles_x, tiles_y;
+#ifdef BSR_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
 template <int KH, int KW, bool GS, bool TAIL, int RW>   // RW = tile rows per wave (MFMA work per staged byte)
@@ -58,6 +61,9 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   float* s_w = smem + C::IN_FLOATS;
   float* s_gs = s_w + C::W_FLOATS;
 
+#ifdef BSR_STAMPS
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   int bid = blockIdx.x;
@@ -129,6 +135,32 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   store_w(w_regs);
   __syncthreads();
 
+#ifdef BSR_STAMPS
+  st1 = __builtin_amdgcn_s_memtime();
+#endif
+  // fused-tail operands are fetched now, so their latency hides under the MFMA loop instead of serialising the epilogue:
+  // clr_conv2 A operand W2^T[c2 = r][c = 4q + e], clr_conv3 A operand W3^T[c3 = r < 3][c = 4q + e], biases, and (lanes q == 0) the
+  // input pixels for the final grayscale difference
+  float tw2[4], tw3[4], tin[MT][3];
+  f32x4 tb2 = {0.f, 0.f, 0.f, 0.f};
+  float tb3[3] = {0.f, 0.f, 0.f};
+  if (TAIL) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      tw2[e] = p.tail_w[(4 * q + e) * 16 + r];
+      tw3[e] = p.tail_w[272 + (4 * q + e) * 3 + (r < 3 ? r : 0)];      // masked to rows r < 3 at use (no early wait)
+    }
+    tb2 = *reinterpret_cast<const f32x4*>(p.tail_w + 256 + 4 * q);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tb3[c] = p.tail_w[320 + c];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const size_t pix = ((size_t)img * p.H + y0 + wave * RW + mt / 2) * p.W + x0 + (mt % 2) * 16 + r;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tin[mt][c] = p.inputs[pix * 3 + c];
+    }
+  }
+
   // this wave: tile rows wave*RW .. wave*RW+RW-1, two 16-pixel MFMA tiles per row
   int x_base[MT];
 #pragma unroll
@@ -188,6 +220,9 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     }
   }
 
+#ifdef BSR_STAMPS
+  st2 = __builtin_amdgcn_s_memtime();
+#endif
   // epilogue: lane (pixel r of tile mt, q) holds channels 4q .. 4q+3
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * q);
 #pragma unroll
@@ -196,39 +231,42 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     f32x4 v = acc[mt] + b4;
     if (p.act) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * kLeakyAlpha;
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * kLeakyAlpha);
     }
     const size_t pix = row_pix + (mt % 2) * 16 + r;
     if (!TAIL) {
       *reinterpret_cast<f32x4*>(p.out + pix * p.out_cs + 4 * q) = v;
     } else {
       // clr_conv2: y2^T[c2][px] = sum_c W2^T[c2][c] * y1^T[c][px]; register e of v is channel c = 4q + e (k index q)
-      f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 a2 = tb2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.tail_w[(4 * q + e) * 16 + r], v[e], a2, 0, 0, 0);
-      const f32x4 bb2 = *reinterpret_cast<const f32x4*>(p.tail_w + 256 + 4 * q);
-      a2 += bb2;
+      for (int e = 0; e < 4; ++e) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tw2[e], v[e], a2, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a2[e] = a2[e] >= 0.f ? a2[e] : a2[e] * kLeakyAlpha;
+      for (int e = 0; e < 4; ++e) a2[e] = fmaxf(a2[e], a2[e] * kLeakyAlpha);
       // clr_conv3: rows c3 = 0..2 (lanes r < 3 carry the weights, the rest multiply by 0)
       f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float w3 = r < 3 ? p.tail_w[272 + (4 * q + e) * 3 + r] : 0.f;
-        a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3, a2[e], a3, 0, 0, 0);
-      }
+      for (int e = 0; e < 4; ++e) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(r < 3 ? tw3[e] : 0.f, a2[e], a3, 0, 0, 0);
       if (q == 0) {   // rows 0..2 = R,G,B of pixel r
 #pragma clang fp contract(off)
-        const float cr = a3[0] + p.tail_w[320], cg = a3[1] + p.tail_w[321], cb = a3[2] + p.tail_w[322];
+        const float cr = a3[0] + tb3[0], cg = a3[1] + tb3[1], cb = a3[2] + tb3[2];
         p.con_rgb[pix * 3 + 0] = cr;
         p.con_rgb[pix * 3 + 1] = cg;
         p.con_rgb[pix * 3 + 2] = cb;
         const float g1 = (cr * 0.2989f + cg * 0.5870f) + cb * 0.1140f;
-        const float g0 = (p.inputs[pix * 3] * 0.2989f + p.inputs[pix * 3 + 1] * 0.5870f) + p.inputs[pix * 3 + 2] * 0.1140f;
+        const float g0 = (tin[mt][0] * 0.2989f + tin[mt][1] * 0.5870f) + tin[mt][2] * 0.1140f;
         p.dif[pix] = g1 - g0;
       }
     }
   }
+#ifdef BSR_STAMPS
+  if (p.stamps != nullptr && lane == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime(), rt3 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+    d[0] = st1 - st0; d[1] = st2 - st1; d[2] = rt3 - rt0; d[3] = st3 - st2;
+  }
+#endif
 }
 
 template <int KH, int KW, bool GS, bool TAIL, int RW>

@@ -3,6 +3,7 @@
 #define BSR_STAMPS 1
 #include "../blindshadowremoval_amd/csrc/igemm_conv.h"
 #include "../blindshadowremoval_amd/csrc/gemm_nloop.h"
+#include "../blindshadowremoval_amd/csrc/conv_n16.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -55,6 +56,40 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   return 0;
 }
 
+template <int KH, int KW, bool GS, bool TAIL, int RW>
+int run_n16(const char* name, int B, int H, int W) {
+  using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
+  size_t npx = (size_t)B * H * W;
+  float *d_in, *d_out, *d_w, *d_b, *d_gs, *d_wgs, *d_tail, *d_inp, *d_rgb, *d_dif;
+  CK(hipMalloc(&d_in, npx * 64 * 4)); CK(hipMalloc(&d_out, npx * 16 * 4)); CK(hipMalloc(&d_w, 2 * C::W_FLOATS * 4)); CK(hipMalloc(&d_b, 64));
+  CK(hipMalloc(&d_gs, npx * 4)); CK(hipMalloc(&d_wgs, 1024)); CK(hipMalloc(&d_tail, 2048)); CK(hipMalloc(&d_inp, npx * 12)); CK(hipMalloc(&d_rgb, npx * 12)); CK(hipMalloc(&d_dif, npx * 4));
+  std::vector<float> h_in(npx * 64), h_w(2 * C::W_FLOATS);
+  for (auto& v : h_in) v = (float)rand() / RAND_MAX - 0.5f;
+  for (auto& v : h_w) v = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+  CK(hipMemcpy(d_in, h_in.data(), npx * 64 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_w, h_w.data(), 2 * C::W_FLOATS * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(d_b, 0, 64)); CK(hipMemset(d_gs, 0, npx * 4)); CK(hipMemset(d_wgs, 0, 1024)); CK(hipMemset(d_tail, 0, 2048)); CK(hipMemset(d_inp, 0, npx * 12));
+  ConvN16Args a{};
+  a.in = d_in; a.in_cs = 64; a.H = H; a.W = W; a.w = d_w; a.bias = d_b; a.out = d_out; a.out_cs = 16; a.act = 1; a.pad_t = (KH - 1) / 2; a.pad_l = (KW - 1) / 2;
+  a.gs = d_gs; a.w_gs = d_wgs; a.tail_w = d_tail; a.inputs = d_inp; a.con_rgb = d_rgb; a.dif = d_dif;
+  size_t nblk = (size_t)(W / 32) * (H / C::TH) * B;
+  unsigned long long* d_st; CK(hipMalloc(&d_st, nblk * 16 * 8)); a.stamps = d_st;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e9;
+  for (int it = 0; it < 5; ++it) {
+    CK(hipEventRecord(e0)); CK((launch_conv_n16<KH, KW, GS, TAIL, RW>(a, B, 0))); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it > 0) best = std::min(best, ms);
+  }
+  std::vector<unsigned long long> st(nblk * 16);
+  CK(hipMemcpy(st.data(), d_st, nblk * 16 * 8, hipMemcpyDeviceToHost));
+  double pro = 0, loop = 0, epi = 0, rt = 0;
+  for (size_t i = 0; i < nblk * 4; ++i) { pro += st[i * 4]; loop += st[i * 4 + 1]; rt += st[i * 4 + 2]; epi += st[i * 4 + 3]; }
+  double nw = nblk * 4.0;
+  double mf = 2.0 * KH * KW * 2 * 4 * (2 * RW);
+  printf("%-12s %7.1f us  %6.1f TFLOP/s | blocks %zu | per wave: prologue %.0f  loop %.0f (%.1f cyc/MFMA)  epilogue %.0f | clock %.2f GHz, lifetime %.1f us\n", name, best * 1e3,
+         2.0 * npx * KH * KW * 64 * 16 / best / 1e9, nblk, pro / nw, loop / nw, loop / nw / mf, epi / nw, (pro + loop + epi) / rt * 0.1, rt / nw * 0.01);
+  return 0;
+}
+
 int run_gemm(const char* name, int pixels, int N, int nsplit, bool res) {
   const int K = 128, n_pad = ((N + 31) / 32 + 3) * 32;
   size_t n_in = (size_t)pixels * K, n_out = (size_t)pixels * N, n_w = (size_t)4 * n_pad * 36;
@@ -88,6 +123,10 @@ int run_gemm(const char* name, int pixels, int N, int nsplit, bool res) {
 
 int main(int argc, char** argv) {
   if (argc > 1) g_mode = atoi(argv[1]);
+  if (run_n16<3, 3, true, true, 2>("clr_conv1", 32, 256, 256)) return 1;
+  if (run_n16<3, 3, true, true, 1>("clr_conv1/rw1", 32, 256, 256)) return 1;
+  if (run_n16<7, 1, false, false, 2>("heads", 32, 256, 256)) return 1;
+  if (run_n16<7, 1, false, false, 1>("heads/rw1", 32, 256, 256)) return 1;
   if (run_gemm("c3q", 32768, 672, 2, false)) return 1;
   if (run_gemm("c3q/split1", 32768, 672, 1, false)) return 1;
   if (run_gemm("w", 32768, 288, 2, true)) return 1;
