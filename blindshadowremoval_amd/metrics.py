@@ -1,0 +1,42 @@
+"""Image-quality metrics the reference prints at test time (host side):
+`tf.image.psnr` / `tf.image.ssim` as used in /root/reference/train_test_GSC.py:724-725 (UCB) and
+/root/reference/train_with_TSM.py:681-682, and the ROC AUC of train_with_TSM.py:701 (`fsrnet.roc_auc_score`).
+
+`ssim` follows tf.image.ssim's defaults: 11x11 Gaussian window with sigma 1.5, k1 = 0.01, k2 = 0.03, 'VALID' filtering,
+per-channel SSIM maps averaged over space and channels.  Inputs are NHWC torch tensors (any device)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def psnr(a: torch.Tensor, b: torch.Tensor, max_val: float = 1.0) -> torch.Tensor:
+    """tf.image.psnr: 20 log10(max) - 10 log10(mean squared error) over the last three dims -> [B]."""
+    mse = ((a.double() - b.double()) ** 2).mean(dim=(-3, -2, -1))
+    return (20.0 * torch.log10(torch.tensor(float(max_val), dtype=torch.float64)) - 10.0 * torch.log10(mse)).float()
+
+
+def _gauss_window(size: int = 11, sigma: float = 1.5) -> torch.Tensor:
+    x = torch.arange(size, dtype=torch.float64) - (size - 1) / 2.0
+    g = torch.exp(-(x ** 2) / (2.0 * sigma ** 2))
+    g = g / g.sum()
+    return torch.outer(g, g)
+
+
+def ssim(a: torch.Tensor, b: torch.Tensor, max_val: float = 1.0, filter_size: int = 11, filter_sigma: float = 1.5,
+         k1: float = 0.01, k2: float = 0.03) -> torch.Tensor:
+    """tf.image.ssim -> [B]."""
+    assert a.shape == b.shape and a.dim() == 4
+    x = a.double().permute(0, 3, 1, 2)
+    y = b.double().permute(0, 3, 1, 2)
+    c = x.shape[1]
+    w = _gauss_window(filter_size, filter_sigma).to(x.device).reshape(1, 1, filter_size, filter_size).repeat(c, 1, 1, 1)
+
+    def filt(t):
+        return F.conv2d(t, w, groups=c)
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    mx, my = filt(x), filt(y)
+    sxx, syy, sxy = filt(x * x) - mx * mx, filt(y * y) - my * my, filt(x * y) - mx * my
+    lum = (2 * mx * my + c1) / (mx * mx + my * my + c1)
+    cs = (2 * sxy + c2) / (sxx + syy + c2)
+    return (lum * cs).mean(dim=(1, 2, 3)).float()
