@@ -23,29 +23,41 @@ GFLOP_3X3_PER_IMAGE = 11.017    # 3x3 conv + transposed 3x3 ("3x3-conv path", SU
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
 
 
-def cpu_baseline(weights, seconds_budget=20.0):
+def cpu_baseline(weights, seconds_budget=25.0):
     """Oracle (torch-CPU restatement of the reference's TF graph; TF itself is not installable here) timed on
-    the host cores of this box, bounded sample of the same synthetic workload."""
+    the host cores of this box, bounded sample of the same synthetic workload.  The thread count is the best of a
+    short sweep (oneDNN does not scale monotonically on a 2-socket host); `cores` reports the count actually used."""
     import torch
     from oracle.gsc_oracle import GeneratorOracle
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores // 2 if cores > 16 else cores, 128))      # physical cores on a 2-thread/core host
-    torch.set_num_threads(threads)
     oracle = GeneratorOracle(weights)
     torch.manual_seed(0)
     b = 8
     inp, uv = torch.rand(b, 256, 256, 3), torch.rand(b, 256, 256, 3)
-    oracle(inp[:2], uv[:2])                      # warm-up (oneDNN primitive creation)
-    times = []
     t_all = time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
+
+    def run_once():
         t0 = time.perf_counter()
         oracle(inp, uv)
-        times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+    best_threads, best_t = 1, float("inf")
+    for threads in sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2)}):
+        torch.set_num_threads(threads)
+        run_once()                               # warm-up (oneDNN primitive creation for this thread count)
+        t = run_once()
+        if t < best_t:
+            best_threads, best_t = threads, t
+        if time.perf_counter() - t_all > seconds_budget * 0.6:
+            break
+    torch.set_num_threads(best_threads)
+    times = [best_t]
+    while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
+        times.append(run_once())
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(b / med, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "%d forwards of %d synthetic 256x256 images, median (oracle-CPU torch/oneDNN fp32, proxy for the TF2-CPU path)" % (len(times), b)}
+    return {"value": round(b / med, 3), "unit": "images/sec", "cores": best_threads, "kind": "port",
+            "sample": "%d forwards of %d synthetic 256x256 images, median (oracle-CPU torch/oneDNN fp32, proxy for the TF2-CPU path; "
+                      "thread count = best of a sweep on a %d-thread host)" % (len(times), b, cores)}
 
 
 def main():
