@@ -73,7 +73,7 @@ constexpr Variant kTSM{true, 291, 312, 288, 291, 312, 877, 888, 874};
 constexpr int CS_CF = 64;    // f = clr_up3 output; the gs channel of cat[gs, f] (model.py:267) is read from the gs output
 
 struct Plan {  // float offsets into the workspace for a (B,H,W) problem
-  size_t xr, x1, c3, c2, xa, t1, t2, y3[6], qkv, att[6], r[6], xh, ybuf, qh, f1, f2, cf, c1, probe, reg32, share, total;
+  size_t x1, c3, c2, xa, t1, t2, y3[6], qkv, att[6], r[6], xh, ybuf, qh, f1, f2, cf, probe, reg32, share, total;
 };
 
 Plan make_plan(size_t B, size_t H, size_t W, const Variant& v = kGSC) {
@@ -85,7 +85,6 @@ Plan make_plan(size_t B, size_t H, size_t W, const Variant& v = kGSC) {
     return o;
   };
   const size_t px = B * H * W, cells = px / 64;
-  p.xr = take(0);      // (the im2row buffer of the first version; the stem kernel reads the image directly)
   p.x1 = take(px * 32);
   p.c3 = take(px / 4 * 128);
   p.c2 = take(px / 16 * 160);
@@ -102,7 +101,6 @@ Plan make_plan(size_t B, size_t H, size_t W, const Variant& v = kGSC) {
   p.f1 = take(px / 16 * 128);
   p.f2 = take(px / 4 * 96);
   p.cf = take(px * CS_CF);
-  p.c1 = take(px * 16);
   p.probe = take(cells * 2);
   p.reg32 = take(v.tsm ? cells * 4 : 0);
   p.share = take(v.tsm ? cells * 2 * v.c_r : 0);
@@ -570,7 +568,6 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
   else if (nm == "f1") src = {p.f1, H / 4, W / 4, 128, 0, 128};
   else if (nm == "f2") src = {p.f2, H / 2, W / 2, 96, 0, 96};
   else if (nm == "f") src = {p.cf, H, W, CS_CF, 0, 64};
-  else if (nm == "c1") src = {p.c1, H, W, 16, 0, 16};
   else return fail(BSR_ERR_STATE, std::string("bsr_probe: unknown probe '") + name + "'");
   const size_t npix = (size_t)B * src.hh * src.ww;
   shape4[0] = B; shape4[1] = src.hh; shape4[2] = src.ww; shape4[3] = src.c;

@@ -149,14 +149,18 @@ class Generator:
         """Intermediate of the last forward as a dense NHWC tensor (see bsr_probe in include/bsr_hip.h)."""
         if self._shape is None:
             raise RuntimeError("probe() needs a forward first")
-        B, H, W = self._shape
         shape = (ctypes.c_int * 4)()
         with torch.cuda.device(self._device):
             stream = torch.cuda.current_stream().cuda_stream
-            dst = torch.empty(B * H * W * 64, dtype=torch.float32, device="cuda:%d" % self._device)   # largest probe: 64 ch at full res
+            # first call with zero capacity only reports the shape (the copy is refused with BSR_ERR_ARG) ...
+            rc = self._lib.bsr_probe(self._handle, name.encode(), ctypes.c_void_p(8), 0, ctypes.byref(shape), stream)
+            if rc not in (0, 1) or shape[0] == 0:
+                _lib.check(rc if rc else 4, "bsr_probe")
+            n = shape[0] * shape[1] * shape[2] * shape[3]
+            dst = torch.empty(n, dtype=torch.float32, device="cuda:%d" % self._device)
+            # ... the second one copies into an exactly sized tensor
             _lib.check(self._lib.bsr_probe(self._handle, name.encode(), dst.data_ptr(), dst.numel(), ctypes.byref(shape), stream), "bsr_probe")
-        n = shape[0] * shape[1] * shape[2] * shape[3]
-        return dst[:n].reshape(shape[0], shape[1], shape[2], shape[3]).clone()
+        return dst.reshape(shape[0], shape[1], shape[2], shape[3])
 
     def set_timing(self, enable: bool) -> None:
         _lib.check(self._lib.bsr_set_timing(self._handle, 1 if enable else 0), "bsr_set_timing")

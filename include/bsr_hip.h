@@ -62,7 +62,8 @@ int bsr_reserve(bsr_handle* h, int B, int H, int W);
 
 /* Test hook: copy a named intermediate of the LAST forward (dense NHWC, real channel count) into dst
  * (device pointer, capacity cap_floats).  shape4 receives [B,H,W,C].  Names: x1 x2 x3 x0 res0..res5 up1 up2
- * y d32 bmask xh f1 f2 f c1 att<i> y3_<i>. */
+ * y d32 bmask xh f1 f2 f att<i> y3_<i>.  shape4 is filled even when cap_floats is too small (BSR_ERR_ARG), so a caller can
+ * size its buffer with a first call of capacity 0. */
 int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream);
 
 /* Per-kernel-class device time (ms) of the last forward run with timing enabled; classes are indexed
