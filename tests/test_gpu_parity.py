@@ -192,3 +192,24 @@ def test_tsm_variant_matches_oracle(frame, share):
         gen.__class__.__mro__[1].__call__(gen, inp[:1], uv[:1])
     with pytest.raises(ValueError):
         gen(inp, uv, reg, 3, True)
+
+
+def test_edge_inputs(gen_w):
+    """Empty batch is rejected; non-contiguous / channel-sliced inputs give the same bits as contiguous ones; a batch
+    larger than the bench's (B = 48) reproduces the rows of smaller batches bit for bit (workspace regrowth included)."""
+    gen, _ = gen_w
+    with pytest.raises((ValueError, RuntimeError)):
+        gen(torch.rand(0, 256, 256, 3), torch.rand(0, 256, 256, 3))
+    torch.manual_seed(17)
+    packed = torch.rand(3, 256, 256, 16).cuda()                      # the loader's 16-channel layout: img = [..., 0:3], uv = [..., 6:9]
+    img_v, uv_v = packed[..., 0:3], packed[..., 6:9]                 # strided views, not contiguous
+    assert not img_v.is_contiguous()
+    a = gen(img_v, uv_v)
+    b = gen(img_v.contiguous(), uv_v.contiguous())
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    big_in, big_uv = torch.rand(48, 256, 256, 3).cuda(), torch.rand(48, 256, 256, 3).cuda()
+    big = [t.clone() for t in gen(big_in, big_uv)]
+    small = gen(big_in[40:44].contiguous(), big_uv[40:44].contiguous())
+    for x, y in zip(big, small):
+        assert torch.equal(x[40:44], y)
