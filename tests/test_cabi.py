@@ -52,3 +52,15 @@ def test_create_rejects_bad_blobs_before_touching_the_gpu(lib):
         _lib.check(rc, "bsr_create")
     assert lib.bsr_forward(None, None, None, 1, 256, 256, None, None, None, None, None) == 1
     assert lib.bsr_debug_attention(None, None, 1, 1024, None) == 1
+
+
+def test_header_is_plain_c():
+    """include/bsr_hip.h must be consumable by a C compiler (the boundary is a C ABI, no C++ / torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    res = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "bsr_hip.h")],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
