@@ -20,6 +20,7 @@ namespace bsr {
 constexpr int kAttD = 128;        // C/2 of the 257-channel NonLocalBlock (/root/reference/model.py:10-12)
 constexpr int kAttKT = 32;        // keys per LDS stage
 constexpr int kAttLdK = kAttD + 4;
+constexpr float kRescaleThreshold = 8.f;   // log2 units
 constexpr int kAttStageFloats = kAttKT * kAttLdK + kAttKT * kAttD;
 constexpr int kAttSmemBytes = 2 * kAttStageFloats * 4;
 
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float*
   f32x4 qf[kAttD / 8];
 #pragma unroll
   for (int g = 0; g < kAttD / 8; ++g)
-    qf[g] = *reinterpret_cast<const f32x4*>(base + (size_t)q * (3 * kAttD) + g * 8 + 4 * h);
+    qf[g] = *reinterpret_cast<const f32x4*>(base + (size_t)q * (3 * kAttD) + g * 8 + 4 * h) * 1.4426950408889634f;   // log2(e): softmax in base 2
 
   f32x16 o[4];
 #pragma unroll
@@ -91,25 +92,32 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float*
       for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[g][j], s, 0, 0, 0);
     }
 
-    // online softmax for this lane's query: 16 keys here + 16 in lane^32
+    // online softmax for this lane's query: 16 keys here + 16 in lane^32.  Logits are in the log2 domain (theta was
+    // pre-scaled by log2 e), so P = exp2(s - m) is one v_exp_f32 per element.  The running maximum is only raised — and O^T, l
+    // rescaled — when some query's tile maximum exceeds it by more than kRescaleThreshold (P <= 2^8 stays far inside
+    // fp32 range): fp32 VALU work cannot hide under the matrix pipe on gfx950, so the 64 rescale multiplies are skipped
+    // on almost every tile.
     float mx = s[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float scale = __expf(m_run - m_new);      // exp(-inf) = 0 on the first tile
+    if (__any(mx > m_run + kRescaleThreshold)) {          // wave-uniform branch
+      const float m_new = fmaxf(m_run, mx);
+      const float scale = __builtin_amdgcn_exp2f(m_run - m_new);           // exp2(-inf) = 0 on the first tile; 1 for lanes whose max did not move
+      l_run *= scale;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= scale;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      s[i] = __expf(s[i] - m_new);
+      s[i] = __builtin_amdgcn_exp2f(s[i] - m_run);
       psum += s[i];
     }
-    l_run = l_run * scale + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[dt][i] *= scale;
+    l_run += psum;
 
     // O^T += g^T . P^T : register i of s holds key (i&3) + 8*(i>>2) + 4h
 #pragma unroll
