@@ -149,15 +149,19 @@ def main():
                 a[0] += ms / n_rep
                 a[1] = n
         gen.set_timing(False)
-        t33 = (acc["conv3x3"][0] + acc["convT3x3"][0]) * 1e-3
-        n33 = acc["conv3x3"][1] + acc["convT3x3"][1]
-        achieved = GFLOP_3X3_PER_IMAGE * B / t33 / 1e3            # TFLOP/s
+        t33 = (acc["conv3x3"][0] + acc["convT3x3"][0] + acc["convT3x3_ni2"][0]) * 1e-3
+        n33 = acc["conv3x3"][1] + acc["convT3x3"][1] + acc["convT3x3_ni2"][1]
+        path_tflops = GFLOP_3X3_PER_IMAGE * B / t33 / 1e3         # the whole 3x3-conv path
+        # the dominant kernel: igemm_conv_kernel<3,3,1,true,4,32,4,1,1,2,32,1> = up2, up3, clr_up3 (SURVEY Appendix C MMACs)
+        dom_gflop = 2e-3 * (377.49 + 1207.96 + 905.97) * B       # algorithmic GFLOP of its 3 launches
+        t_dom, n_dom = acc["convT3x3_ni2"][0] * 1e-3, acc["convT3x3_ni2"][1]
+        achieved = dom_gflop / t_dom / 1e3                        # TFLOP/s
         t_all = sum(v[0] for v in acc.values()) * 1e-3
         traffic = None          # HBM bytes of the same launches, from the committed PMC passes (tools/pmc_traffic.py)
         tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if os.path.isfile(tpath) and B == 32:
             with open(tpath) as ft:
-                traffic = json.load(ft).get("path_3x3_hbm_bytes_per_forward")
+                traffic = json.load(ft).get("dominant_kernel_hbm_bytes_per_launch")
         result = {
             "metric": "images/sec at 256x256 batch inference (GSC generator forward)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,11 +174,13 @@ def main():
                        "collective": ("all_gather(con_rgb|dif) per step, async" if distributed and not args.no_gather else "none")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per forward of the same 3x3-path launches (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r1_pmc_traffic.csv); "
-                                         "algorithmic activation bytes of these layers (each input read once, each output written once): 3.61e9 per 32-image forward",
-                         "kernel": "igemm_conv_kernel (3x3 + stride-2 3x3 + transposed 3x3 layers)",
-                         "launches_per_forward": n33, "avg_launch_ms": round(t33 * 1e3 / n33, 4),
-                         "algorithmic_gflop_per_forward": round(GFLOP_3X3_PER_IMAGE * B, 2),
+                         "traffic_note": "HBM bytes per launch of the same kernel (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r1_pmc_traffic.csv); "
+                                         "algorithmic activation bytes of its launches (input read once, output written once): 5.87e8 per launch on average",
+                         "kernel": "igemm_conv_kernel<3,3,1,true,4,32,4,1,1,2,32,1> (transposed 3x3: up2, up3, clr_up3) — the largest single kernel, 24 % of the forward",
+                         "launches_per_forward": n_dom, "avg_launch_ms": round(t_dom * 1e3 / n_dom, 4),
+                         "algorithmic_gflop_per_launch": round(dom_gflop / n_dom, 2),
+                         "path_3x3": {"achieved": round(path_tflops, 2), "frac": round(path_tflops / PEAK_F32_MFMA_TFLOPS, 4), "launches": n33,
+                                      "ms": round(t33 * 1e3, 4), "algorithmic_gflop": round(GFLOP_3X3_PER_IMAGE * B, 2)},
                          "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all / 1e3, 2),
                          "class_ms": {k: round(v[0], 4) for k, v in acc.items()}},
         }

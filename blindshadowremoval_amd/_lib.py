@@ -9,8 +9,8 @@ from typing import Optional
 from .build import LIB_PATH
 
 ABI_VERSION = 1
-NUM_CLASSES = 6
-CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue")
+NUM_CLASSES = 7
+CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue", "convT3x3_ni2")
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -54,7 +54,7 @@ struct LayerW {
   int nchunk = 0, taps = 0, n_pad = 0, ldp = 0;
 };
 
-enum KClass { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2, K_ATT = 3, K_CONV7 = 4, K_GLUE = 5 };
+enum KClass { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2, K_ATT = 3, K_CONV7 = 4, K_GLUE = 5, K_CONVT_NI2 = 6 };
 
 constexpr int C_RES = 257;   // ResBottleneck width (/root/reference/model.py:226)
 constexpr int CS_RES = 264;  // channel stride of its 257-wide tensors (multiple of the 24-wide K chunk)
@@ -489,8 +489,8 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
 
   // greyscale decoder: up1..3 = ConvT (model.py:243-245)
   L.conv<3, 3, 1, true, 1, 24, 1>(K_CONVT, "up1", ws + p.r[2], V.cs_r, 0, V.cs_r, H8, W8, ws + p.c2, 160, 0, 96, 1);
-  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
-  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
   // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
   L.conv16<7, 1, false, false, 2>(K_CONV7, "heads", ws + p.ybuf, 64, H, W, ws + p.qh, 16, 0, nullptr, nullptr, nullptr, nullptr);
   glue_begin();
@@ -511,7 +511,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   // colour decoder (model.py:264-269)
   L.conv<3, 3, 1, true, 2, 24, 1>(K_CONVT, "clr_up1", ws + p.r[5], V.cs_h, 0, V.cs_h, H8, W8, ws + p.f1, 128, 0, 128, 1);
   L.conv<3, 3, 1, true, 1, 32, 1>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1);
-  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
   // clr_conv1 (3x3 over cat[gs, f]) + clr_conv2 + clr_conv3 + dif, one kernel (model.py:267-269,288)
   L.conv16<3, 3, true, true, 2>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, H, W, nullptr, 0, 1, gs, inputs, con_rgb, dif);
   if (L.rc == BSR_OK) h->ran = true;

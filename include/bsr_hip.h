@@ -67,10 +67,11 @@ int bsr_reserve(bsr_handle* h, int B, int H, int W);
 int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream);
 
 /* Per-kernel-class device time (ms) of the last forward run with timing enabled; classes are indexed
- * 0: conv3x3 (+stride-2), 1: transposed 3x3, 2: conv1x1, 3: attention, 4: conv7 (stem + heads), 5: glue.
+ * 0: conv3x3 (+stride-2), 1: transposed 3x3 (all but class 6), 2: conv1x1, 3: attention, 4: conv7 (stem + heads), 5: glue,
+ * 6: the dominant kernel instantiation igemm_conv_kernel<3,3,1,true,4,32,4,1,1,2,32,1> (up2, up3, clr_up3).
  * bsr_set_timing(h, 1) makes every following forward record HIP events around each launch on the
  * forward's stream (adds host overhead; off by default). */
-#define BSR_NUM_CLASSES 6
+#define BSR_NUM_CLASSES 7
 int bsr_set_timing(bsr_handle* h, int enable);
 int bsr_get_timing(bsr_handle* h, float ms_per_class[BSR_NUM_CLASSES], int launches_per_class[BSR_NUM_CLASSES]);
 

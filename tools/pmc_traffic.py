@@ -38,8 +38,10 @@ m["hbm_MB_per_forward"] = m["read_MB_per_forward"] + m["write_MB_per_forward"]
 out = m[["launches_per_forward", "read_MB_per_forward", "write_MB_per_forward", "hbm_MB_per_forward"]].round(1)
 out.to_csv(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.csv"))
 is33 = out.index.str.contains("<3, 3")          # the 3x3 / stride-2 3x3 / transposed 3x3 launches (roofline kernel class)
+dom = out[out.index.str.contains("<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32")]
 summary = {
     "batch": 32,
+    "dominant_kernel_hbm_bytes_per_launch": float(dom["hbm_MB_per_forward"].sum() * 1e6 / max(dom["launches_per_forward"].sum(), 1)),
     "path_3x3_hbm_bytes_per_forward": float(out.loc[is33, "hbm_MB_per_forward"].sum() * 1e6),
     "path_3x3_launches": int(out.loc[is33, "launches_per_forward"].sum()),
     "all_kernels_hbm_bytes_per_forward": float(out["hbm_MB_per_forward"].sum() * 1e6),
