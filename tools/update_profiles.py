@@ -33,9 +33,10 @@ for _, r in d.sort_values("us/fwd", ascending=False).iterrows():
 rows.append("| **sum** | %g | | **%.0f** |" % (d["launches/fwd"].sum(), d["us/fwd"].sum()))
 rf = b["roofline"]
 head = ("* `%s_bench_n1.json` — `python bench.py` (N = 1, %d steps, %d warm-up): **%.0f images/s**, %.2f ms per 32-image forward; "
-        "3x3-conv path **%.1f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 MFMA peak**, all kernels %.1f TFLOP/s; CPU oracle %s images/s on %s host threads.\n"
+        "dominant kernel (`igemm_conv_kernel<3,3,1,true,…,2,32,1>`: up2, up3, clr_up3) **%.1f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 MFMA peak** "
+        "(avg launch %.4f ms — compare the rocprofv3 average below), whole 3x3-conv path %.1f TFLOP/s (%.1f %%), all kernels %.1f TFLOP/s; CPU oracle %s images/s on %s host threads.\n"
         "* `%s_kernel_stats.csv` — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (%d forwards). Per forward:\n\n"
-        % (tag, b["steps"], b["warmup"], b["value"], b["ms_per_step"], rf["achieved"], 100 * rf["frac"], rf["all_kernels_tflops"],
+        % (tag, b["steps"], b["warmup"], b["value"], b["ms_per_step"], rf["achieved"], 100 * rf["frac"], rf["avg_launch_ms"], rf["path_3x3"]["achieved"], 100 * rf["path_3x3"]["frac"], rf["all_kernels_tflops"],
            (b.get("cpu_baseline") or {}).get("value"), (b.get("cpu_baseline") or {}).get("cores"), tag, nfwd))
 block = "<!-- BEGIN %s TABLE -->\n%s%s\n<!-- END %s TABLE -->" % (tag, head, "\n".join(rows), tag)
 readme = os.path.join(ROOT, "profiles", "README.md")
