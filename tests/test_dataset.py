@@ -87,3 +87,36 @@ def test_config1_end_to_end(tmp_path, golden_dir):
     ref = test_step_ffhq(GeneratorOracle(w), torch.from_numpy(row)[None])
     for a, b in zip(res[0][1], ref):
         assert float((a.cpu() - b).abs().max()) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_config3_ucb_miniature(tmp_path, golden_dir):
+    """BASELINE config 3 in miniature: two UCB items (committed as data fixtures) through the UCB loader (ground truth from the
+    sibling gt tree) and FSRNet.test at batch 16; PSNR / SSIM of the HIP outputs against the oracle's ("PSNR vs ref")."""
+    import torch
+    from blindshadowremoval_amd import metrics as M
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    from blindshadowremoval_amd.weights import init_weights
+    from oracle.gsc_oracle import GeneratorOracle
+    cfg = Config(0)
+    cfg.CHECKPOINT_DIR = str(tmp_path)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    w = init_weights(1)
+    ds = D.Dataset(cfg, "test", ucb=True)
+    assert len(ds.name_list) == 2
+    res = FSRNet(cfg, weights=w).test(ds, batch=16)
+    assert len(res) == 2
+    ds2 = D.Dataset(cfg, "test", ucb=True)
+    rows = torch.from_numpy(np.concatenate([next(ds2.feed)[0][0] for _ in range(2)], axis=0))      # [2,256,256,16]
+    assert not torch.equal(rows[..., 0:3], rows[..., 3:6])                                          # gt differs from the shadowed input
+    img, gt, uv, reg, face = torch.split(rows, [3, 3, 3, 6, 1], dim=3)
+    oracle = GeneratorOracle(w)
+    ref_gs, ref_rgb, _, ref_dif = oracle(img, uv)
+    hip_rgb = torch.cat([r[1][2] for r in res]).cpu()
+    hip_gs = torch.cat([r[1][1] for r in res]).cpu()
+    assert float((hip_rgb - ref_rgb).abs().max()) <= 1e-3 and float((hip_gs - ref_gs).abs().max()) <= 1e-3
+    psnr = M.psnr(hip_rgb.clamp(0, 1), ref_rgb.clamp(0, 1))
+    ssim = M.ssim(hip_rgb.clamp(0, 1), ref_rgb.clamp(0, 1))
+    assert float(psnr.min()) > 80.0 and float(ssim.min()) > 0.99999
+    # the metric the reference prints for UCB (train_test_GSC.py:724-725): prediction vs ground truth — finite numbers on this input
+    assert torch.isfinite(M.psnr(hip_rgb.clamp(0, 1), gt)).all() and torch.isfinite(M.ssim(hip_rgb.clamp(0, 1), gt)).all()
