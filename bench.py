@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 18.104        # 9 052.06 MMAC per 256x256 image
 GFLOP_3X3_PER_IMAGE = 11.017    # 3x3 conv + transposed 3x3 ("3x3-conv path")
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: BF16/F16 MFMA dense (only used for the opt-in --dtype f16 line)
 
 
 def cpu_baseline(weights, seconds_budget=25.0):
@@ -67,6 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+                    help="f32 = the measured path (BASELINE configs[1]); f16 = opt-in fp16 MFMA on the 3x3-conv path (configs[3])")
     ap.add_argument("--no-gather", action="store_true", help="skip the output all-gather (N>1)")
     args = ap.parse_args()
 
@@ -88,7 +91,7 @@ def main():
 
     B = args.batch
     weights = init_weights(1)
-    gen = Generator(device=local_rank).load_weights(weights)
+    gen = Generator(device=local_rank, dtype=args.dtype).load_weights(weights)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     inp = torch.rand(B, 256, 256, 3, generator=g).to(dev)       # synthetic, resident in HBM before timing
     uv = torch.rand(B, 256, 256, 3, generator=g).to(dev)
@@ -157,29 +160,32 @@ def main():
         t_dom, n_dom = acc["convT3x3_ni2"][0] * 1e-3, acc["convT3x3_ni2"][1]
         achieved = dom_gflop / t_dom / 1e3                        # TFLOP/s
         t_all = sum(v[0] for v in acc.values()) * 1e-3
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_F16_MFMA_TFLOPS
         traffic = None          # HBM bytes of the same launches, from the committed PMC passes (tools/pmc_traffic.py)
         tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.isfile(tpath) and B == 32:
+        if os.path.isfile(tpath) and B == 32 and args.dtype == "f32":
             with open(tpath) as ft:
                 traffic = json.load(ft).get("dominant_kernel_hbm_bytes_per_launch")
         result = {
             "metric": "images/sec at 256x256 batch inference (GSC generator forward)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=32 synthetic 256x256x3 per GPU, full GSC generator fp32 "
-                                   "(seeded random-init weights in the ckpt-94 variable layout)",
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[1]: batch=32 synthetic 256x256x3 per GPU, full GSC generator fp32 "
+                                    "(seeded random-init weights in the ckpt-94 variable layout)" if args.dtype == "f32" else
+                                    "BASELINE configs[3]: batch=32 synthetic 256x256x3 per GPU, fp16 MFMA (fp32 accumulate/storage) on the "
+                                    "3x3-conv path, fp32 elsewhere; NOT the headline configuration"),
                        "images_per_gpu_per_step": B, "global_batch": world * B, "height": 256, "width": 256,
                        "parallelism": "dp%d" % world,
                        "collective": ("all_gather(con_rgb|dif) per step, async" if distributed and not args.no_gather else "none")},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per launch of the same kernel (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r1_pmc_traffic.csv); "
                                          "algorithmic activation bytes of its launches (input read once, output written once): 5.87e8 per launch on average",
                          "kernel": "igemm_conv_kernel<3,3,1,true,4,32,4,1,1,2,32,1> (transposed 3x3: up2, up3, clr_up3) — the largest single kernel, 24 % of the forward",
                          "launches_per_forward": n_dom, "avg_launch_ms": round(t_dom * 1e3 / n_dom, 4),
                          "algorithmic_gflop_per_launch": round(dom_gflop / n_dom, 2),
-                         "path_3x3": {"achieved": round(path_tflops, 2), "frac": round(path_tflops / PEAK_F32_MFMA_TFLOPS, 4), "launches": n33,
+                         "path_3x3": {"achieved": round(path_tflops, 2), "frac": round(path_tflops / peak, 4), "launches": n33,
                                       "ms": round(t33 * 1e3, 4), "algorithmic_gflop": round(GFLOP_3X3_PER_IMAGE * B, 2)},
                          "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all / 1e3, 2),
                          "class_ms": {k: round(v[0], 4) for k, v in acc.items()}},

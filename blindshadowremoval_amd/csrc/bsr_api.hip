@@ -115,6 +115,7 @@ struct bsr_handle {
   float* d_blob = nullptr;
   std::unordered_map<std::string, LayerW> layers;
   Variant var = kGSC;
+  bool f16 = false;              // BSR_DTYPE_F16: fp16 MFMA on the 3x3 / stride-2 / transposed 3x3 layers (igemm kernels), fp32 elsewhere
   float head_bias[2] = {0.f, 0.f};
   const float* tail_w = nullptr;
   const float* clr_gs_w = nullptr;
@@ -207,7 +208,10 @@ struct Launcher {
       return;
     }
     begin(cls);
-    check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
+    if (h->f16 && (KH == 3 && KW == 3))
+      check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB, (KH == 3 && KW == 3)>(a, h->B, s), name);
+    else
+      check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB, false>(a, h->B, s), name);
     end();
   }
   // 1x1 conv as a resident-activation GEMM (K = NCH*32) over all N
@@ -289,7 +293,7 @@ size_t bsr_workspace_bytes(int B, int H, int W) {
 int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t nbytes, int dtype) {
   if (out == nullptr || packed_weights == nullptr) return fail(BSR_ERR_ARG, "bsr_create: null argument");
   *out = nullptr;
-  if (dtype != BSR_DTYPE_F32) return fail(BSR_ERR_ARG, "bsr_create: only BSR_DTYPE_F32 is implemented");
+  if (dtype != BSR_DTYPE_F32 && dtype != BSR_DTYPE_F16) return fail(BSR_ERR_ARG, "bsr_create: dtype must be BSR_DTYPE_F32 or BSR_DTYPE_F16");
   if (nbytes < sizeof(BlobHeader)) return fail(BSR_ERR_BLOB, "bsr_create: blob shorter than its header");
   const uint8_t* blob = static_cast<const uint8_t*>(packed_weights);
   BlobHeader hd;
@@ -300,6 +304,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   HIP_TRY(hipSetDevice(device));
   bsr_handle* h = new bsr_handle();
   h->device = device;
+  h->f16 = dtype == BSR_DTYPE_F16;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {

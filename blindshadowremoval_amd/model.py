@@ -23,7 +23,10 @@ from .tf_bundle import latest_checkpoint, load_generator_weights
 
 
 class Generator:
-    def __init__(self, downsize: int = 1, n_res: int = 6, device: Optional[int] = None):
+    def __init__(self, downsize: int = 1, n_res: int = 6, device: Optional[int] = None, dtype: str = "f32"):
+        if dtype not in ("f32", "f16"):
+            raise ValueError("dtype must be 'f32' (the measured path) or 'f16' (fp16 MFMA on the 3x3-conv path, BASELINE config 4)")
+        self.dtype = dtype
         if n_res != 6:
             raise ValueError("the GSC generator has n_res=6 (/root/reference/model.py:199)")
         self.n_res = n_res
@@ -44,7 +47,7 @@ class Generator:
         blob = pack_generator(weights)
         handle = ctypes.c_void_p()
         buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
-        _lib.check(lib.bsr_create(ctypes.byref(handle), dev, ctypes.cast(buf, ctypes.c_void_p), len(blob), 0), "bsr_create")
+        _lib.check(lib.bsr_create(ctypes.byref(handle), dev, ctypes.cast(buf, ctypes.c_void_p), len(blob), 1 if self.dtype == "f16" else 0), "bsr_create")
         self.close()
         self._lib, self._handle, self._device = lib, handle, dev
         return self

@@ -31,12 +31,14 @@ typedef struct bsr_handle bsr_handle;
 #define BSR_ERR_STATE 4    /* probe requested before any forward, unknown probe name, ... */
 
 #define BSR_DTYPE_F32 0
+#define BSR_DTYPE_F16 1     /* BASELINE config 4: fp16 MFMA (fp32 accumulate, fp32 storage) on the 3x3-conv path; the rest stays fp32 */
 
 /* Replaces Generator() construction + tf.train.Checkpoint(generator=...).restore(...)
  * (/root/reference/train_test_GSC.py:120, :143-148, :365, :845).
  * packed_weights: HOST pointer to the blob written by blindshadowremoval_amd.pack.pack_generator()
  * (BatchNorm folded, MFMA-friendly layout); it is copied to the device, the caller may free it.
- * dtype: BSR_DTYPE_F32 (the arithmetic type of the path). */
+ * dtype: BSR_DTYPE_F32 (the arithmetic type of the measured path) or BSR_DTYPE_F16 (same blob; operands of the 3x3 / stride-2 /
+ * transposed 3x3 convolutions are rounded to fp16 in registers and contracted with v_mfma_f32_32x32x8_f16). */
 int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t nbytes, int dtype);
 
 /* Replaces Generator.call(inputs, uv, reg, chuck, training=False) (/root/reference/model.py:228-290).

@@ -16,7 +16,7 @@ TOL = 1e-3          # north_star: outputs within 1e-3 per pixel, fp32
 FLIP_TOL = 2e-5
 
 
-def run_and_compare(gen, weights, inp, uv, tol=TOL, want_probes=()):
+def run_and_compare(gen, weights, inp, uv, tol=TOL, want_probes=(), flip_tol=FLIP_TOL):
     dev = "cuda:%d" % gen._device if gen._device is not None else "cuda"
     out = [t.cpu() for t in gen(inp.to(dev), uv.to(dev))]
     d32 = gen.probe("d32").cpu()
@@ -28,7 +28,7 @@ def run_and_compare(gen, weights, inp, uv, tol=TOL, want_probes=()):
     flips = bmask != pr["bmask"]
     nflip = int(flips.sum())
     if nflip:
-        assert float((pr["d32"][flips] - 0.1).abs().max()) < FLIP_TOL, "bmask differs away from the threshold"
+        assert float((pr["d32"][flips] - 0.1).abs().max()) < flip_tol, "bmask differs away from the threshold"
         pr = {}
         ref = oracle(inp, uv, probes=pr, bmask_override=bmask)
     errs = {}
