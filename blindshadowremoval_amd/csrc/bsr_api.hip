@@ -58,6 +58,7 @@ enum KClass { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2, K_ATT = 3, K_CONV7 = 4, K_G
 
 constexpr int C_RES = 257;   // ResBottleneck width (/root/reference/model.py:226)
 constexpr int CS_RES = 264;  // channel stride of its 257-wide tensors (multiple of the 24-wide K chunk)
+constexpr int CS_Y3X = 288;  // y3x = conv3 output + block input, all 9 channel tiles kept (TSM inputs are wider than 257: model_with_TSM.py:105-113)
 
 // Channel plan of the bottleneck trunk.  GSC (/root/reference/model.py:238,259): xa = cat[x 96 | uv 3], blocks 0-2 are 257
 // wide, xh = cat[x_hole 257 | bmask | uv 3].  TSM (/root/reference/model_with_TSM.py:272,293) inserts the ShareLayer output:
@@ -91,7 +92,7 @@ Plan make_plan(size_t B, size_t H, size_t W, const Variant& v = kGSC) {
   p.xa = take(cells * v.cs_a);
   p.t1 = take(cells * 128);
   p.t2 = take(cells * 128);
-  for (int i = 0; i < 6; ++i) p.y3[i] = take(cells * CS_RES);
+  for (int i = 0; i < 6; ++i) p.y3[i] = take(cells * CS_Y3X);
   p.qkv = take(cells * 384);
   for (int i = 0; i < 6; ++i) p.att[i] = take(cells * 128);
   for (int i = 0; i < 6; ++i) p.r[i] = take(cells * (i < 3 ? v.cs_r : v.cs_h));
@@ -472,15 +473,16 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     // conv3+BN (128 -> 257 = y3) and theta|phi|g (257 -> 3x128, no activation in between: model.py:101,33-46) as ONE
     // K = 128 GEMM: the qkv weights are composed offline with conv3's (pack.py), N = [y3 288 | qkv 384]
     snprintf(nm, sizeof nm, "res%d.c3q", i);
-    L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_RES, 288 + 384, 0, nullptr, 0, 0, nullptr, 0, 0, ws + p.qkv, 384, 288, CS_RES);
+    // The y3 output also absorbs the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
+    L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, nullptr, 0, 0, ws + p.qkv, 384, 288, CS_Y3X);
     if (L.rc == BSR_OK) {
       L.begin(K_ATT);
       L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
       L.end();
     }
-    // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113)
+    // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att)))
     snprintf(nm, sizeof nm, "res%d.w", i);
-    L.gemm<3, 4>(K_CONV1, nm, ws + p.att[i], 128, ncell, r_out, o_cs, o_cs < 288 ? o_cs : 288, 1, x, x_cs, x_cs, y3, CS_RES, CS_RES);
+    L.gemm<3, 4>(K_CONV1, nm, ws + p.att[i], 128, ncell, r_out, o_cs, o_cs < 288 ? o_cs : 288, 1, y3, CS_Y3X, CS_Y3X);
     if (x_c > 288 && L.rc == BSR_OK) {      // the block output keeps the wider of x / y (model.py:105-113): channels the GEMM does not cover
       glue_begin();
       hipLaunchKernelGGL(bsr::lrelu_copy_kernel, dim3((unsigned)((ncell * (x_c - 288) + 255) / 256)), dim3(256), 0, s, x, x_cs, r_out, o_cs, 288, x_c, ncell);
@@ -563,7 +565,7 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
   else if (nm == "x0") src = {p.xa, H / 8, W / 8, h->var.cs_a, 0, h->var.c_a};
   else if ((i = res_idx("res")) >= 0) src = {p.r[i], H / 8, W / 8, i < 3 ? h->var.cs_r : h->var.cs_h, 0, i < 3 ? h->var.c_r : h->var.c_h};
   else if ((i = res_idx("att")) >= 0) src = {p.att[i], H / 8, W / 8, 128, 0, 128};
-  else if ((i = res_idx("y3_")) >= 0) src = {p.y3[i], H / 8, W / 8, CS_RES, 0, C_RES};
+  else if ((i = res_idx("y3x")) >= 0) src = {p.y3[i], H / 8, W / 8, CS_Y3X, 0, CS_Y3X};
   else if (nm == "up1") src = {p.c2, H / 4, W / 4, 160, 0, 96};
   else if (nm == "up2") src = {p.c3, H / 2, W / 2, 128, 0, 64};
   else if (nm == "y") src = {p.ybuf, H, W, 64, 0, 64};

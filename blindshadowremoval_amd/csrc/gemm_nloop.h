@@ -26,7 +26,7 @@ struct GemmNLoopCfg {
 
 // ConvArgs use: in/in_cs/in_coff (K = NCH*32 channels), pixels flattened (multiple of 128),
 // w packed [NCH][1][n_pad][36] with n_pad >= 32 * (tiles + NI - 1), bias[n_pad], out/out_cs/out_coff/n_store
-// (+ out2/n_split/n_store1), act, res1/res2.  tiles_x = tiles per blockIdx.y range.
+// (+ out2/n_split/n_store1), act, res1 (ONE residual, channels [0, res1_c); res2 is not supported here).  tiles_x = tiles per blockIdx.y range.
 template <int NI, int NCH>
 __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   using C = GemmNLoopCfg<NI, NCH>;
@@ -45,8 +45,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   const int tiles_total = (p.n_store + 31) / 32;
   const int t0 = blockIdx.y * p.tiles_x;                      // this block's tile range [t0, t1)
   const int t1 = min(t0 + p.tiles_x, tiles_total);
-  const int ngroups = (t1 - t0 + NI - 1) / NI;
+  // Group schedule.  The grid is exactly one wave of workgroups (2 per CU, one of each blockIdx.y range), which all
+  // start together: with identical schedules the two workgroups of a CU stay in lockstep and reach their epilogues (VALU +
+  // stores + residual latency, no MFMA) at the same time, leaving the matrix pipe idle.  Odd ranges therefore run their
+  // SHORT group first ((ntiles-1) % NI + 1 tiles), which shifts their epilogues into the partner's MFMA phases.
+  const int ntiles = t1 - t0;
+  const int first = (blockIdx.y & 1) ? (ntiles - 1) % NI + 1 : NI;      // tiles in group 0
+  const int ngroups = ntiles <= first ? 1 : 1 + (ntiles - first + NI - 1) / NI;
   const int nsteps = ngroups * NCH;
+  auto group_tile0 = [&](int ng) { return t0 + (ng == 0 ? 0 : first + (ng - 1) * NI); };
 
   int b_base[NI];
 #pragma unroll
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   }
   auto fetch_w = [&](int s, f32x4 (&regs)[C::W_PER_THREAD]) {      // step s = (group, chunk)
     const int ng = s / NCH, ch = s % NCH;
-    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)ch * p.n_pad + (size_t)(t0 + ng * NI) * 32) * LDP);
+    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)ch * p.n_pad + (size_t)group_tile0(ng) * 32) * LDP);
 #pragma unroll
     for (int i = 0; i < C::W_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + w_off[i]);
   };
@@ -104,12 +111,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   const size_t tile_pix = pix0 + wave * 32;                   // this wave's 32 consecutive pixels
 
   for (int ng = 0; ng < ngroups; ++ng) {
-    const int tg = t0 + ng * NI;                              // first tile of this group
-    const int nvalid = min(NI, t1 - tg);                      // tiles of this group that exist (uniform)
+    const int tg = group_tile0(ng);                           // first tile of this group
+    const int nvalid = ng == 0 ? min(first, ntiles) : min(NI, t1 - tg);     // tiles of this group that exist (uniform)
     f32x16 acc[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const float b = s_bias[min(ng * NI + ni, t1 - t0 - 1) * 32 + r];
+      const float b = s_bias[min(tg - t0 + ni, ntiles - 1) * 32 + r];
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[ni][i] = b;
     }
@@ -156,21 +163,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
       const bool second = p.out2 != nullptr && nt >= p.n_split;
       const bool n_ok = second ? n < p.n_store : (p.out2 != nullptr ? n < p.n_store1 : n < p.n_store);
       f32x16 v = acc[ni];
-      if (has_res) {
-        const bool ok1 = n < p.res1_c, ok2 = n < p.res2_c;
-        const float m1 = ok1 ? 1.f : 0.f, m2 = ok2 ? 1.f : 0.f;
+      if (has_res && nt < p.res1_c) {                        // ONE residual (res1, channels [0, res1_c)); uniform per tile
+        const bool ok1 = n < p.res1_c;
+        const float m1 = ok1 ? 1.f : 0.f;
         const unsigned l1 = (unsigned)(4 * h) * (unsigned)p.res1_cs + (unsigned)(ok1 ? r : 0);
-        const unsigned l2 = (unsigned)(4 * h) * (unsigned)p.res2_cs + (unsigned)(ok2 ? r : 0);
-        const int nt1 = nt < p.res1_c ? nt : 0, nt2 = nt < p.res2_c ? nt : 0;
-        float r1[16], r2[16];
+        float r1[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = (i & 3) + 8 * (i >> 2);
-          r1[i] = (p.res1 + (tile_pix + k) * p.res1_cs + nt1)[l1];
-          r2[i] = (p.res2 + (tile_pix + k) * p.res2_cs + nt2)[l2];
+          r1[i] = (p.res1 + (tile_pix + k) * p.res1_cs + nt)[l1];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] += r1[i] * m1 + r2[i] * m2;
+        for (int i = 0; i < 16; ++i) v[i] += r1[i] * m1;
       }
       if (p.act) {
 #pragma unroll
@@ -212,7 +216,7 @@ inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, int nsplit,
   }
   const int tiles_total = (a.n_store + 31) / 32;
   a.tiles_x = (tiles_total + nsplit - 1) / nsplit;            // tiles per blockIdx.y range
-  if (a.tiles_x > C::MAX_TILES) return hipErrorInvalidValue;
+  if (a.tiles_x > C::MAX_TILES || a.res2 != nullptr) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)(total_pixels / C::BM), nsplit), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }

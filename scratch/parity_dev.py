@@ -14,7 +14,7 @@ t = time.time(); ref = GeneratorOracle(w)(inp, uv, probes=pr); print("oracle s",
 gen = Generator().load_weights(w)
 out = gen(inp.cuda(), uv.cuda())
 torch.cuda.synchronize()
-names = {"x1": "x1", "x2": "x2", "x3": "x3", "x0": "x0", "y3_0": "res_stack/0/y3", "att0": "res_stack/0/non_local/att", "res0": "res0",
+names = {"x1": "x1", "x2": "x2", "x3": "x3", "x0": "x0", "att0": "res_stack/0/non_local/att", "res0": "res0",
          "res1": "res1", "res2": "res2", "up1": "up1", "up2": "up2", "y": "y", "d32": "d32", "bmask": "bmask", "res3": "res3",
          "att5": "res_stack/5/non_local/att", "res5": "res5", "f": "f"}
 for k, rk in names.items():
