@@ -177,9 +177,7 @@ struct Launcher {
   // KH,KW,S,TR,TH,TW,WM,WN,MI,NI,CC,PF_IN
   template <int KH, int KW, int S, bool TR, int NI, int CC, int INB>
   void conv(int cls, const char* name, const float* in, int in_cs, int in_coff, int k_pad, int H, int W, float* out, int out_cs,
-            int out_coff, int n_store, int act, const float* res1 = nullptr, int res1_cs = 0, int res1_c = 0,
-            const float* res2 = nullptr, int res2_cs = 0, int res2_c = 0, float* out2 = nullptr, int out2_cs = 0, int n_split = 0,
-            int n_store1 = 0) {
+            int out_coff, int n_store, int act) {
     if (rc != BSR_OK) return;
     using C = bsr::ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
     LayerW l;
@@ -200,9 +198,6 @@ struct Launcher {
     a.pad_t = pad_before(H, KH, S);
     a.pad_l = pad_before(W, KW, S);
     a.act = act;
-    a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c;
-    a.res2 = res2; a.res2_cs = res2_cs; a.res2_c = res2_c;
-    a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
     const int mh = TR ? H : a.Ho, mw = TR ? W : a.Wo;
     if (mh % 4 != 0 || mw % 32 != 0) {
       rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': feature map is not a multiple of the 4x32 tile");
@@ -218,7 +213,7 @@ struct Launcher {
   // 1x1 conv as a resident-activation GEMM (K = NCH*32) over all N
   template <int NI, int NCH>
   void gemm(int cls, const char* name, const float* in, int in_cs, size_t pixels, float* out, int out_cs, int n_store, int act,
-            const float* res1 = nullptr, int res1_cs = 0, int res1_c = 0, const float* res2 = nullptr, int res2_cs = 0, int res2_c = 0,
+            const float* res1 = nullptr, int res1_cs = 0, int res1_c = 0,
             float* out2 = nullptr, int out2_cs = 0, int n_split = 0, int n_store1 = 0) {
     if (rc != BSR_OK) return;
     using C = bsr::GemmNLoopCfg<NI, NCH>;
@@ -231,7 +226,7 @@ struct Launcher {
     bsr::ConvArgs a{};
     a.in = in; a.in_cs = in_cs; a.in_coff = 0; a.out = out; a.out_cs = out_cs; a.out_coff = 0;
     a.w = l.w; a.bias = l.b; a.nchunk = l.nchunk; a.n_pad = l.n_pad; a.n_store = n_store; a.act = act;
-    a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c; a.res2 = res2; a.res2_cs = res2_cs; a.res2_c = res2_c;
+    a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c;
     a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
     begin(cls);
     check(bsr::launch_gemm_nloop<NI, NCH>(a, pixels, kNSplit, s), name);
@@ -474,7 +469,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     // K = 128 GEMM: the qkv weights are composed offline with conv3's (pack.py), N = [y3 288 | qkv 384]
     snprintf(nm, sizeof nm, "res%d.c3q", i);
     // The y3 output also absorbs the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
-    L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, nullptr, 0, 0, ws + p.qkv, 384, 288, CS_Y3X);
+    L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
     if (L.rc == BSR_OK) {
       L.begin(K_ATT);
       L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");

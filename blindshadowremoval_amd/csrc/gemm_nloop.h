@@ -26,7 +26,7 @@ struct GemmNLoopCfg {
 
 // ConvArgs use: in/in_cs/in_coff (K = NCH*32 channels), pixels flattened (multiple of 128),
 // w packed [NCH][1][n_pad][36] with n_pad >= 32 * (tiles + NI - 1), bias[n_pad], out/out_cs/out_coff/n_store
-// (+ out2/n_split/n_store1), act, res1 (ONE residual, channels [0, res1_c); res2 is not supported here).  tiles_x = tiles per blockIdx.y range.
+// (+ out2/n_split/n_store1), act, res1 (one residual, channels [0, res1_c)).  tiles_x = tiles per blockIdx.y range.
 template <int NI, int NCH>
 __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   using C = GemmNLoopCfg<NI, NCH>;
@@ -216,7 +216,7 @@ inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, int nsplit,
   }
   const int tiles_total = (a.n_store + 31) / 32;
   a.tiles_x = (tiles_total + nsplit - 1) / nsplit;            // tiles per blockIdx.y range
-  if (a.tiles_x > C::MAX_TILES || a.res2 != nullptr) return hipErrorInvalidValue;
+  if (a.tiles_x > C::MAX_TILES) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)(total_pixels / C::BM), nsplit), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }

@@ -91,45 +91,6 @@ __global__ void bmask_xhole_kernel(const float* __restrict__ gs, const float* __
   }
 }
 
-// clr_conv2 (1x1 16->16 + BN + LeakyReLU) and clr_conv3 (1x1 16->3), then
-// dif = gray(con_rgb) - gray(inputs)  (model.py:268-269,288).  wt: [16*16 w2 (k-major: w2[k*16+n])][16 b2][16*3 w3 (w3[k*3+n])][3 b3].
-__global__ void color_tail_kernel(const float* __restrict__ c1, const float* __restrict__ wt, const float* __restrict__ inputs,
-                                  float* __restrict__ con_rgb, float* __restrict__ dif, size_t npix) {
-  __shared__ float sw[16 * 16 + 16 + 48 + 3];
-  for (int i = threadIdx.x; i < 16 * 16 + 16 + 48 + 3; i += blockDim.x) sw[i] = wt[i];
-  __syncthreads();
-  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= npix) return;
-  float x[16];
-#pragma unroll
-  for (int k4 = 0; k4 < 4; ++k4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(c1 + pix * 16 + k4 * 4);
-    x[k4 * 4 + 0] = v[0];
-    x[k4 * 4 + 1] = v[1];
-    x[k4 * 4 + 2] = v[2];
-    x[k4 * 4 + 3] = v[3];
-  }
-  float y[16];
-#pragma unroll
-  for (int n = 0; n < 16; ++n) {
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a = fmaf(x[k], sw[k * 16 + n], a);
-    a += sw[256 + n];
-    y[n] = a >= 0.f ? a : a * kLeakyAlpha;
-  }
-  float o[3];
-#pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a = fmaf(y[k], sw[272 + k * 3 + n], a);
-    o[n] = a + sw[272 + 48 + n];
-    con_rgb[pix * 3 + n] = o[n];
-  }
-  dif[pix] = gray3(o[0], o[1], o[2]) - gray3(inputs[pix * 3], inputs[pix * 3 + 1], inputs[pix * 3 + 2]);
-}
-
 // ---- TSM ShareLayer (/root/reference/model_with_TSM.py:199-229) = offset warp -> group max|mean -> tile -> inverse warp ----
 // tf_batch_map_offsets (/root/reference/warp.py:134-165): offsets = resize(reg, [S,S]) * S (centre-2x2 mean for the exact
 // 8x reduction), channels 0:2; coords = offsets + (i, j); clamp to [0, S-1]; corners floor / ceil; lerp along axis 0

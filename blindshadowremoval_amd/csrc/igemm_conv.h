@@ -42,15 +42,14 @@ struct ConvArgs {
   const float* bias;    // [n_pad]
   int nchunk, n_pad;
   int n_store;          // channels [0, n_store) are written
+  int pad_t, pad_l;     // TF SAME pad-before (rows, cols); unused for transposed
+  int act;              // 1: LeakyReLU(0.3)
+  // --- used by gemm_nloop_kernel only ---
   float* out2;          // optional second destination: channels [n_split, n_store) go to out2[.., n - n_split]
   int out2_cs, n_split; // (n_split is a multiple of 32; channels [n_store1, n_split) of the first range are dropped)
   int n_store1;         // with out2: channels [0, n_store1) go to `out`
-  int pad_t, pad_l;     // TF SAME pad-before (rows, cols); unused for transposed
-  int act;              // 1: LeakyReLU(0.3)
-  const float* res1;    // optional residuals, NHWC at the OUTPUT resolution, added before the activation
+  const float* res1;    // optional residual, NHWC at the output resolution, added before the activation
   int res1_cs, res1_c;  // channel stride; channels [0,res1_c) are read
-  const float* res2;
-  int res2_cs, res2_c;
   int tiles_x, tiles_y; // M tiles per image
 #ifdef BSR_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
@@ -335,15 +334,11 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   // ---- epilogue: bias (+ residuals) + LeakyReLU, NHWC store (32 consecutive channels per half-wave) ----
   // With TW == 32 a wave's 32 pixels are one tile row, so every element address is a wave-uniform base plus a
   // 32-bit lane offset plus a compile-time multiple of the pixel stride: no 64-bit per-element arithmetic.
-  // Residual loads are unconditional (clamped channel, masked value) and issued 16 at a time ahead of the
-  // arithmetic: a per-element branch would make hipcc wait for every load separately.
   static_assert(TW == 32, "epilogue assumes one tile row per 32-pixel MFMA tile");
   constexpr int SX = TR ? 2 : 1;
   const size_t blk_pix = (size_t)img * p.Ho * p.Wo + (size_t)(SX * y0) * p.Wo + SX * x0;
-  const bool has_res = p.res1 != nullptr;      // res1 and res2 come together (NonLocal residual + block skip)
-  // per-lane constant parts (elements): register 0 of this lane is pixel column SX*4*h, channel r of the tile
+  // per-lane constant part (elements): register 0 of this lane is pixel column SX*4*h, channel r of the tile
   const unsigned lane_out = (unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r;
-  const unsigned lane_out2 = (unsigned)(SX * 4 * h) * (unsigned)p.out2_cs + (unsigned)r;
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
@@ -351,31 +346,11 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int nt = n0 + (wn * NI + ni) * 32;           // first channel of this 32-wide tile (uniform)
-        const int n = nt + r;
-        const bool second = p.out2 != nullptr && nt >= p.n_split;            // uniform per tile
-        const bool n_ok = second ? n < p.n_store : (p.out2 != nullptr ? n < p.n_store1 : n < p.n_store);
+        const bool n_ok = nt + r < p.n_store;
         const int ty = wm * MI + mi;
         // wave-uniform pixel index of this tile's register-0 row, relative to the block origin
         const size_t tile_pix = blk_pix + (size_t)(SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0);
         f32x16 v = acc[ph][mi][ni];
-        if (has_res) {
-          const bool ok1 = n < p.res1_c, ok2 = n < p.res2_c;
-          const float m1 = ok1 ? 1.f : 0.f, m2 = ok2 ? 1.f : 0.f;
-          const unsigned l1 = (unsigned)(SX * 4 * h) * (unsigned)p.res1_cs + (unsigned)(ok1 ? r : 0);
-          const unsigned l2 = (unsigned)(SX * 4 * h) * (unsigned)p.res2_cs + (unsigned)(ok2 ? r : 0);
-          const int nt1 = nt < p.res1_c ? nt : 0, nt2 = nt < p.res2_c ? nt : 0;
-          float r1[16], r2[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int k = SX * ((i & 3) + 8 * (i >> 2));
-            const float* b1 = p.res1 + (tile_pix + k) * p.res1_cs + nt1;      // uniform
-            const float* b2 = p.res2 + (tile_pix + k) * p.res2_cs + nt2;
-            r1[i] = b1[l1];
-            r2[i] = b2[l2];
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] += r1[i] * m1 + r2[i] * m2;
-        }
         if (p.act) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], v[i] * kLeakyAlpha);       // LeakyReLU(0.3) = max(x, 0.3x)
@@ -384,12 +359,11 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int k = SX * ((i & 3) + 8 * (i >> 2));
-            float* ob = second ? p.out2 + (tile_pix + k) * p.out2_cs + (nt - p.n_split)
-                               : p.out + (tile_pix + k) * p.out_cs + p.out_coff + nt;   // uniform
+            float* ob = p.out + (tile_pix + k) * p.out_cs + p.out_coff + nt;   // uniform
 #if defined(BSR_EPI_SKIP)
             if (v[i] == 12345.678f) ob[lane_out] = v[i];
 #else
-            ob[second ? lane_out2 : lane_out] = v[i];
+            ob[lane_out] = v[i];
 #endif
           }
         }

@@ -128,7 +128,7 @@ def clr_gs_weights(w: Dict[str, np.ndarray]) -> np.ndarray:
 
 
 def tail_weights(w: Dict[str, np.ndarray]) -> np.ndarray:
-    """clr_conv2 (folded, k-major [16][16]) | bias[16] | clr_conv3 [16][3] | bias[3] for color_tail_kernel."""
+    """clr_conv2 (folded, k-major [16][16]) | bias[16] | clr_conv3 [16][3] | bias[3] for the fused tail of conv_n16_kernel (csrc/conv_n16.h)."""
     k2, b2 = fold_bn(w["clr_conv2/conv/kernel"].reshape(1, 16, 16), w["clr_conv2/conv/bias"], _bn(w, "clr_conv2/bnorm"))
     k3 = w["clr_conv3/conv/kernel"].reshape(16, 3).astype(np.float64)
     return np.concatenate([k2.reshape(-1), b2, k3.reshape(-1), w["clr_conv3/conv/bias"].astype(np.float64)]).astype(np.float32)

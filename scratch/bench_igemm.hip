@@ -102,7 +102,7 @@ int run_gemm(const char* name, int pixels, int N, int nsplit, bool res) {
   CK(hipMemset(d_b, 0, n_pad * 4)); CK(hipMemset(d_r, 0, n_out * 4));
   ConvArgs a{};
   a.in = d_in; a.in_cs = K; a.out = d_out; a.out_cs = N; a.w = d_w; a.bias = d_b; a.nchunk = 4; a.n_pad = n_pad; a.n_store = N; a.act = 1;
-  if (res) { a.res1 = d_r; a.res1_cs = N; a.res1_c = N; a.res2 = d_r; a.res2_cs = N; a.res2_c = N; }
+  if (res) { a.res1 = d_r; a.res1_cs = N; a.res1_c = N < 288 ? N : 288; }
   size_t nblk = (size_t)(pixels / 128) * nsplit;
   unsigned long long* d_st; CK(hipMalloc(&d_st, nblk * 16 * 8)); a.stamps = d_st;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -123,6 +123,14 @@ int run_gemm(const char* name, int pixels, int N, int nsplit, bool res) {
 
 int main(int argc, char** argv) {
   if (argc > 1) g_mode = atoi(argv[1]);
+  if (argc > 2 && argv[2][0] == 'g') {            // only the resident-activation GEMMs
+    if (run_gemm("c3q", 32768, 672, 2, false)) return 1;
+    if (run_gemm("c3q+res", 32768, 672, 2, true)) return 1;
+    if (run_gemm("c3q/split1", 32768, 672, 1, false)) return 1;
+    if (run_gemm("w", 32768, 288, 2, true)) return 1;
+    if (run_gemm("w/nores", 32768, 288, 2, false)) return 1;
+    return 0;
+  }
   if (run_n16<3, 3, true, true, 2>("clr_conv1", 32, 256, 256)) return 1;
   if (run_n16<3, 3, true, true, 1>("clr_conv1/rw1", 32, 256, 256)) return 1;
   if (run_n16<7, 1, false, false, 2>("heads", 32, 256, 256)) return 1;
