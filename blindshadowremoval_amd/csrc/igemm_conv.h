@@ -31,6 +31,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kLeakyAlpha = 0.3f;   // tf.keras.layers.LeakyReLU default (/root/reference/model.py:130,161)
 
+// LeakyReLU(0.3) = max(x, 0.3 x).  fmaxf() costs three VALU instructions per element under the default IEEE mode (multiply,
+// a canonicalising v_max x,x, the v_max); spelled out it is one v_pk_mul_f32 per PAIR plus one v_max_f32 per element.
+// VALU time in an epilogue is not hidden: it runs beside a co-resident wave's MFMA stream and is starved by it.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 leaky_relu2(f32x2 x) {
+  f32x2 t, r;
+  const f32x2 k = {kLeakyAlpha, kLeakyAlpha};
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(k));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(x[0]), "v"(t[0]));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(x[1]), "v"(t[1]));
+  return r;
+}
+__device__ __forceinline__ float leaky_relu(float x) {
+  float t = x * kLeakyAlpha, r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
+  return r;
+}
+// Epilogue addressing through a raw buffer resource: buffer_store_dword v_data, v_lane_off, s[rsrc], s_uniform_off offen.
+// The wave-uniform part of an element's address is a 32-bit SGPR byte offset from a per-workgroup base, the per-lane part one
+// constant VGPR: no vector address arithmetic at all per element, and a lane whose offset has bit 31 set falls outside
+// num_records and is dropped by the hardware (masking without touching exec).
+constexpr unsigned kLaneOff = 0x80000000u;          // voffset of a lane that must not store / load
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);   // raw, stride 0, 2 GiB window
+}
+
 struct ConvArgs {
   const float* in;      // NHWC activations, channel stride in_cs, first channel in_coff
   int in_cs, in_coff;
@@ -104,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   // cycles).  They run at raised priority; the MFMA main loop runs at priority 0.
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // tells the compiler the wave index is uniform: SGPR address math
   const int h = lane >> 5, r = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -337,8 +364,9 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   static_assert(TW == 32, "epilogue assumes one tile row per 32-pixel MFMA tile");
   constexpr int SX = TR ? 2 : 1;
   const size_t blk_pix = (size_t)img * p.Ho * p.Wo + (size_t)(SX * y0) * p.Wo + SX * x0;
-  // per-lane constant part (elements): register 0 of this lane is pixel column SX*4*h, channel r of the tile
-  const unsigned lane_out = (unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r;
+  // per-lane constant part (bytes): register 0 of this lane is pixel column SX*4*h, channel r of its tile
+  const unsigned lane_out = ((unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r) * 4u;
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.out + blk_pix * p.out_cs + p.out_coff);      // this workgroup's output origin
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
@@ -346,26 +374,27 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int nt = n0 + (wn * NI + ni) * 32;           // first channel of this 32-wide tile (uniform)
-        const bool n_ok = nt + r < p.n_store;
+        const unsigned voff = nt + r < p.n_store ? lane_out : kLaneOff;
         const int ty = wm * MI + mi;
-        // wave-uniform pixel index of this tile's register-0 row, relative to the block origin
-        const size_t tile_pix = blk_pix + (size_t)(SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0);
+        // wave-uniform element offset of this tile's register-0 row, relative to the workgroup origin
+        const unsigned tile_off = (unsigned)((SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0)) * (unsigned)p.out_cs + (unsigned)nt;
         f32x16 v = acc[ph][mi][ni];
         if (p.act) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], v[i] * kLeakyAlpha);       // LeakyReLU(0.3) = max(x, 0.3x)
-        }
-        if (n_ok) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int k = SX * ((i & 3) + 8 * (i >> 2));
-            float* ob = p.out + (tile_pix + k) * p.out_cs + p.out_coff + nt;   // uniform
-#if defined(BSR_EPI_SKIP)
-            if (v[i] == 12345.678f) ob[lane_out] = v[i];
-#else
-            ob[lane_out] = v[i];
-#endif
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 y = leaky_relu2(f32x2{v[i], v[i + 1]});
+            v[i] = y[0];
+            v[i + 1] = y[1];
           }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = SX * ((i & 3) + 8 * (i >> 2));
+          const unsigned soff = (tile_off + (unsigned)k * (unsigned)p.out_cs) * 4u;      // uniform
+#if defined(BSR_EPI_SKIP)
+          if (v[i] == 12345.678f)
+#endif
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, voff, soff, 0);
         }
       }
 #ifdef BSR_STAMPS
