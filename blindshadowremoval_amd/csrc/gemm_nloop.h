@@ -105,10 +105,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   st1 = __builtin_amdgcn_s_memtime();
 #endif
 
+  // Epilogue addressing through raw buffer resources (igemm_conv.h): per element one 32-bit SGPR offset from this wave's
+  // pixel-0 row and one constant per-lane VGPR offset.
   const bool has_res = p.res1 != nullptr;
-  const unsigned lane_out = (unsigned)(4 * h) * (unsigned)p.out_cs + (unsigned)r;
-  const unsigned lane_out2 = (unsigned)(4 * h) * (unsigned)p.out2_cs + (unsigned)r;
-  const size_t tile_pix = pix0 + wave * 32;                   // this wave's 32 consecutive pixels
+  const size_t tile_pix = pix0 + (size_t)__builtin_amdgcn_readfirstlane(wave) * 32;      // this wave's 32 consecutive pixels
+  const unsigned lane_out = ((unsigned)(4 * h) * (unsigned)p.out_cs + (unsigned)r) * 4u;
+  const unsigned lane_out2 = ((unsigned)(4 * h) * (unsigned)p.out2_cs + (unsigned)r) * 4u;
+  const unsigned lane_res = (unsigned)(4 * h) * (unsigned)p.res1_cs * 4u;
+  const __amdgpu_buffer_rsrc_t rsrc_out = make_rsrc(p.out + tile_pix * p.out_cs + p.out_coff);
+  const __amdgpu_buffer_rsrc_t rsrc_out2 = make_rsrc(p.out2 != nullptr ? p.out2 + tile_pix * p.out2_cs : p.out);
+  const __amdgpu_buffer_rsrc_t rsrc_res = make_rsrc(has_res ? p.res1 + tile_pix * p.res1_cs : p.in);
 
   for (int ng = 0; ng < ngroups; ++ng) {
     const int tg = group_tile0(ng);                           // first tile of this group
@@ -164,29 +170,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
       const bool n_ok = second ? n < p.n_store : (p.out2 != nullptr ? n < p.n_store1 : n < p.n_store);
       f32x16 v = acc[ni];
       if (has_res && nt < p.res1_c) {                        // ONE residual (res1, channels [0, res1_c)); uniform per tile
-        const bool ok1 = n < p.res1_c;
-        const float m1 = ok1 ? 1.f : 0.f;
-        const unsigned l1 = (unsigned)(4 * h) * (unsigned)p.res1_cs + (unsigned)(ok1 ? r : 0);
+        const unsigned l1 = n < p.res1_c ? lane_res + (unsigned)r * 4u : kLaneOff;      // out-of-range lanes read 0
         float r1[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = (i & 3) + 8 * (i >> 2);
-          r1[i] = (p.res1 + (tile_pix + k) * p.res1_cs + nt)[l1];
+          r1[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_res, l1, ((unsigned)k * (unsigned)p.res1_cs + (unsigned)nt) * 4u, 0));
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] += r1[i] * m1;
+        for (int i = 0; i < 16; ++i) v[i] += r1[i];
       }
       if (p.act) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], v[i] * kLeakyAlpha);
-      }
-      if (n_ok) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int k = (i & 3) + 8 * (i >> 2);
-          float* ob = second ? p.out2 + (tile_pix + k) * p.out2_cs + (nt - p.n_split) : p.out + (tile_pix + k) * p.out_cs + p.out_coff + nt;
-          ob[second ? lane_out2 : lane_out] = v[i];
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2 y = leaky_relu2(f32x2{v[i], v[i + 1]});
+          v[i] = y[0];
+          v[i + 1] = y[1];
         }
+      }
+      const unsigned voff = n_ok ? (second ? lane_out2 : lane_out) : kLaneOff;
+      const unsigned cs = second ? (unsigned)p.out2_cs : (unsigned)p.out_cs;
+      const unsigned c0 = second ? (unsigned)(nt - p.n_split) : (unsigned)nt;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = (i & 3) + 8 * (i >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), second ? rsrc_out2 : rsrc_out, voff, ((unsigned)k * cs + c0) * 4u, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
