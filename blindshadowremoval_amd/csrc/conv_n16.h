@@ -231,7 +231,11 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     f32x4 v = acc[mt] + b4;
     if (p.act) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * kLeakyAlpha);
+      for (int e = 0; e < 4; e += 2) {
+        const f32x2 y = leaky_relu2(f32x2{v[e], v[e + 1]});
+        v[e] = y[0];
+        v[e + 1] = y[1];
+      }
     }
     const size_t pix = row_pix + (mt % 2) * 16 + r;
     if (!TAIL) {
@@ -242,7 +246,11 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tw2[e], v[e], a2, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a2[e] = fmaxf(a2[e], a2[e] * kLeakyAlpha);
+      for (int e = 0; e < 4; e += 2) {
+        const f32x2 y = leaky_relu2(f32x2{a2[e], a2[e + 1]});
+        a2[e] = y[0];
+        a2[e + 1] = y[1];
+      }
       // clr_conv3: rows c3 = 0..2 (lanes r < 3 carry the weights, the rest multiply by 0)
       f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

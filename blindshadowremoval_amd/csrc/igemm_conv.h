@@ -32,22 +32,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float kLeakyAlpha = 0.3f;   // tf.keras.layers.LeakyReLU default (/root/reference/model.py:130,161)
 
 // LeakyReLU(0.3) = max(x, 0.3 x).  fmaxf() costs three VALU instructions per element under the default IEEE mode (multiply,
-// a canonicalising v_max x,x, the v_max); spelled out it is one v_pk_mul_f32 per PAIR plus one v_max_f32 per element.
+// a canonicalising v_max x,x, the v_max); as the median of {x, 0.3x, FLT_MAX} it is one v_med3_f32, and the multiply of a
+// register pair is one v_pk_mul_f32.  (No inline asm: the hazard recogniser must see these instructions next to MFMAs.)
 // VALU time in an epilogue is not hidden: it runs beside a co-resident wave's MFMA stream and is starved by it.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 leaky_relu2(f32x2 x) {
-  f32x2 t, r;
-  const f32x2 k = {kLeakyAlpha, kLeakyAlpha};
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(k));
-  asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(x[0]), "v"(t[0]));
-  asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(x[1]), "v"(t[1]));
-  return r;
+  const f32x2 t = x * kLeakyAlpha;
+  return f32x2{__builtin_amdgcn_fmed3f(x[0], t[0], 3.4028234664e38f), __builtin_amdgcn_fmed3f(x[1], t[1], 3.4028234664e38f)};
 }
-__device__ __forceinline__ float leaky_relu(float x) {
-  float t = x * kLeakyAlpha, r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
-  return r;
-}
+__device__ __forceinline__ float leaky_relu(float x) { return __builtin_amdgcn_fmed3f(x, x * kLeakyAlpha, 3.4028234664e38f); }
 // Epilogue addressing through a raw buffer resource: buffer_store_dword v_data, v_lane_off, s[rsrc], s_uniform_off offen.
 // The wave-uniform part of an element's address is a 32-bit SGPR byte offset from a per-workgroup base, the per-lane part one
 // constant VGPR: no vector address arithmetic at all per element, and a lane whose offset has bit 31 set falls outside

@@ -87,15 +87,23 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
   }
 
   __builtin_amdgcn_s_setprio(3);
-  const unsigned lane_out = (unsigned)(4 * h) * 32u + (unsigned)r;
+  // raw-buffer stores (igemm_conv.h): SGPR offset per element, one constant lane offset
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane_out = ((unsigned)(4 * h) * 32u + (unsigned)r) * 4u;
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.out + (((size_t)img * p.H + y0 + wave_u * RW) * p.W + x0) * 32);
 #pragma unroll
   for (int mi = 0; mi < RW; ++mi) {
-    const size_t row_pix = ((size_t)img * p.H + y0 + wave * RW + mi) * p.W + x0;
+    f32x16 v = acc[mi];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const f32x2 y = leaky_relu2(f32x2{v[i], v[i + 1]});
+      v[i] = y[0];
+      v[i + 1] = y[1];
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int k = (i & 3) + 8 * (i >> 2);
-      const float v = acc[mi][i];
-      (p.out + (row_pix + k) * 32)[lane_out] = fmaxf(v, v * kLeakyAlpha);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, lane_out, ((unsigned)(mi * p.W + k) * 32u) * 4u, 0);
     }
   }
 }
