@@ -47,7 +47,7 @@ struct ConvN16Cfg {
   static constexpr int GS_FLOATS = GS ? (TH + 2) * (TW + 2) + 2 : 0;
   static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS + GS_FLOATS) * 4;
   static constexpr int IN_V4 = IH * IW * (CC / 4);
-  static constexpr int IN_PER_THREAD = (IN_V4 + 255) / 256;
+  static constexpr int IN_PER_THREAD = IH + 1;                   // one float4 per tile row + one halo-column load
   static constexpr int W_V4 = W_FLOATS / 4;
   static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
 };
@@ -75,30 +75,39 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
   const float* in_img = p.in + (size_t)img * p.H * p.W * p.in_cs;
 
-  auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD], unsigned& okmask) {
-    okmask = 0u;
+  // Input-tile staging with NO per-load vector arithmetic (it would run beside the co-resident workgroup's MFMA stream, where
+  // VALU instructions starve): thread t owns float4 column c4 = t & 7 of pixel column t >> 3 and walks the IH tile rows; the
+  // row part of the address is a wave-uniform SGPR offset of a raw buffer load, out-of-image columns carry the kLaneOff
+  // lane offset (the load returns 0 = TF SAME zero padding), out-of-image rows are a uniform branch.  The KW-1 halo columns
+  // right of the 32 are one more load for the first HALO_V4 threads.
+  constexpr int HALO_W = IW - 32, HALO_V4 = C::IH * HALO_W * 8;
+  static_assert(HALO_V4 <= 256 && (HALO_W == 0 || HALO_W == 2), "halo pass: one load per thread, power-of-two index math");
+  const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(in_img + ((ptrdiff_t)iy0 * p.W + ix0) * p.in_cs);
+  const int c4 = tid & 7, pxm = tid >> 3;
+  const bool colm_ok = ix0 + pxm >= 0 && ix0 + pxm < p.W;
+  const unsigned voff_m = colm_ok ? (unsigned)(pxm * p.in_cs + c4 * 4) * 4u : kLaneOff;
+  const unsigned lds_m = (unsigned)(pxm * LDP + c4 * 4) * 4u;
+  const int hrow = HALO_W ? (tid >> 4) : 0, hcol = 32 + ((tid >> 3) & 1);
+  const bool halo_ok = HALO_W && tid < HALO_V4 && iy0 + hrow >= 0 && iy0 + hrow < p.H && ix0 + hcol >= 0 && ix0 + hcol < p.W;
+  const unsigned voff_h = halo_ok ? (unsigned)((hrow * p.W + hcol) * p.in_cs + c4 * 4) * 4u : kLaneOff;
+  const unsigned lds_h = (unsigned)((hrow * IW + hcol) * LDP + c4 * 4) * 4u;
+  auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
 #pragma unroll
-    for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-      int idx = tid + i * 256;
-      idx = idx < C::IN_V4 ? idx : C::IN_V4 - 1;
-      const int pix = idx / 8, c4 = idx % 8;
-      const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-      regs[i] = *reinterpret_cast<const f32x4*>(in_img + ((size_t)iyc * p.W + ixc) * p.in_cs + ch * 32 + c4 * 4);
-      okmask |= (ok ? 1u : 0u) << i;
-    }
-  };
-  auto store_in = [&](const f32x4 (&regs)[C::IN_PER_THREAD], unsigned okmask) {
-#pragma unroll
-    for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < C::IN_V4) {
-        f32x4 v = regs[i];
-        if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(s_in + (idx / 8) * LDP + (idx % 8) * 4) = v;
+    for (int row = 0; row < C::IH; ++row) {
+      const int iy = iy0 + row;
+      if (iy >= 0 && iy < p.H) {
+        regs[row] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff_m, (unsigned)((row * p.W) * p.in_cs + ch * 32) * 4u, 0));
+      } else {
+        regs[row] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    if (HALO_W) regs[C::IH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff_h, (unsigned)(ch * 32) * 4u, 0));
+  };
+  auto store_in = [&](const f32x4 (&regs)[C::IN_PER_THREAD]) {
+    char* base = reinterpret_cast<char*>(s_in);
+#pragma unroll
+    for (int row = 0; row < C::IH; ++row) *reinterpret_cast<f32x4*>(base + lds_m + row * IW * LDP * 4) = regs[row];
+    if (HALO_W && tid < HALO_V4) *reinterpret_cast<f32x4*>(base + lds_h) = regs[C::IH];
   };
   auto fetch_w = [&](int ch, f32x4 (&regs)[C::W_PER_THREAD]) {
     const float* src = p.w + (size_t)ch * C::W_FLOATS;
@@ -119,19 +128,22 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 
   f32x4 in_regs[C::IN_PER_THREAD];
   f32x4 w_regs[C::W_PER_THREAD];
-  unsigned in_ok = 0u;
-  fetch_in(0, in_regs, in_ok);
+  fetch_in(0, in_regs);
   fetch_w(0, w_regs);
-  if (GS) {   // (TH+2) x (TW+2) halo tile of the gs channel, zero outside the image
-    constexpr int NG = (TH + 2) * (TW + 2);
-    for (int i = tid; i < NG; i += 256) {
-      const int gy = y0 - 1 + i / (TW + 2), gx = x0 - 1 + i % (TW + 2);
-      const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      const float v = p.gs[((size_t)img * p.H + min(max(gy, 0), p.H - 1)) * p.W + min(max(gx, 0), p.W - 1)];
-      s_gs[i] = ok ? v : 0.f;
-    }
+  if (GS) {   // (TH+2) x (TW+2) halo tile of the gs channel, zero outside the image: shift-only index math, masked buffer loads
+    const __amdgpu_buffer_rsrc_t gs_rsrc = make_rsrc(p.gs + ((ptrdiff_t)img * p.H + (y0 - 1)) * p.W + (x0 - 1));
+    auto gs_elem = [&](int row, int col, bool active) {
+      const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+      const bool ok = active && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gs_rsrc, ok ? (unsigned)(row * p.W + col) * 4u : kLaneOff, 0, 0));
+      if (active) s_gs[row * (TW + 2) + col] = v;
+    };
+    static_assert(TH + 2 <= 16, "gs tile: two 8-row passes");
+    gs_elem(tid >> 5, tid & 31, true);                                     // rows 0..7, columns 0..31
+    gs_elem(8 + (tid >> 5), tid & 31, 8 + (tid >> 5) < TH + 2);             // rows 8..TH+1
+    gs_elem(tid >> 1, 32 + (tid & 1), (tid >> 1) < TH + 2);                 // columns 32, 33
   }
-  store_in(in_regs, in_ok);
+  store_in(in_regs);
   store_w(w_regs);
   __syncthreads();
 
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {
     if (ch == 0) {
-      fetch_in(1, in_regs, in_ok);
+      fetch_in(1, in_regs);
       fetch_w(1, w_regs);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     }
     if (ch == 0) {
       __syncthreads();
-      store_in(in_regs, in_ok);
+      store_in(in_regs);
       store_w(w_regs);
       __syncthreads();
     }
