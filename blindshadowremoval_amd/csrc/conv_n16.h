@@ -32,7 +32,7 @@ struct ConvN16Args {
   const float* inputs;  // TAIL: [B,H,W,3]
   float* con_rgb;       // TAIL: [B,H,W,3]
   float* dif;           // TAIL: [B,H,W,1]
-  int tiles_x, tiles_y;
+  int tiles_x, tiles_y, batch;   // filled by the launcher
 #ifdef BSR_STAMPS
   unsigned long long* stamps;
 #endif
@@ -62,18 +62,27 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   float* s_gs = s_w + C::W_FLOATS;
 
 #ifdef BSR_STAMPS
-  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st_epi = 0, rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  int bid = blockIdx.x;
-  const int tile_x = bid % p.tiles_x;
-  bid /= p.tiles_x;
-  const int tile_y = bid % p.tiles_y;
-  const int img = bid / p.tiles_y;
-  const int y0 = tile_y * TH, x0 = tile_x * TW;
-  const int iy0 = y0 - p.pad_t, ix0 = x0 - p.pad_l;
-  const float* in_img = p.in + (size_t)img * p.H * p.W * p.in_cs;
+
+  // PERSISTENT workgroups: the grid is two workgroups per CU and each walks tiles blockIdx.x, +gridDim.x, ...  With N = 16
+  // the layer moves ~1 staged byte per 300 flop, so a one-tile workgroup spent as long waiting for its first tile as
+  // computing (measured: prologue 19-24k cycles vs 25k of MFMA loop); here the NEXT (tile, chunk) is always in flight in
+  // registers while the current one is multiplied, across tile boundaries too, and only the first tile pays the latency.
+  struct Tile { int img, y0, x0; };
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int ntiles = tiles_per_img * p.batch;
+  auto decode = [&](int t) {
+    Tile d;
+    d.x0 = (t % p.tiles_x) * TW;
+    t /= p.tiles_x;
+    d.y0 = (t % p.tiles_y) * TH;
+    d.img = t / p.tiles_y;
+    return d;
+  };
 
   // Input-tile staging with NO per-load vector arithmetic (it would run beside the co-resident workgroup's MFMA stream, where
   // VALU instructions starve): thread t owns float4 column c4 = t & 7 of pixel column t >> 3 and walks the IH tile rows; the
@@ -82,26 +91,29 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   // right of the 32 are one more load for the first HALO_V4 threads.
   constexpr int HALO_W = IW - 32, HALO_V4 = C::IH * HALO_W * 8;
   static_assert(HALO_V4 <= 256 && (HALO_W == 0 || HALO_W == 2), "halo pass: one load per thread, power-of-two index math");
-  const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(in_img + ((ptrdiff_t)iy0 * p.W + ix0) * p.in_cs);
   const int c4 = tid & 7, pxm = tid >> 3;
-  const bool colm_ok = ix0 + pxm >= 0 && ix0 + pxm < p.W;
-  const unsigned voff_m = colm_ok ? (unsigned)(pxm * p.in_cs + c4 * 4) * 4u : kLaneOff;
   const unsigned lds_m = (unsigned)(pxm * LDP + c4 * 4) * 4u;
   const int hrow = HALO_W ? (tid >> 4) : 0, hcol = 32 + ((tid >> 3) & 1);
-  const bool halo_ok = HALO_W && tid < HALO_V4 && iy0 + hrow >= 0 && iy0 + hrow < p.H && ix0 + hcol >= 0 && ix0 + hcol < p.W;
-  const unsigned voff_h = halo_ok ? (unsigned)((hrow * p.W + hcol) * p.in_cs + c4 * 4) * 4u : kLaneOff;
   const unsigned lds_h = (unsigned)((hrow * IW + hcol) * LDP + c4 * 4) * 4u;
-  auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
+  auto fetch_in = [&](const Tile& d, int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
+    const int iy0 = d.y0 - p.pad_t, ix0 = d.x0 - p.pad_l;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.in + (((ptrdiff_t)d.img * p.H + iy0) * p.W + ix0) * p.in_cs);
+    const bool colm_ok = ix0 + pxm >= 0 && ix0 + pxm < p.W;
+    const unsigned voff_m = colm_ok ? (unsigned)(pxm * p.in_cs + c4 * 4) * 4u : kLaneOff;
 #pragma unroll
     for (int row = 0; row < C::IH; ++row) {
       const int iy = iy0 + row;
       if (iy >= 0 && iy < p.H) {
-        regs[row] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff_m, (unsigned)((row * p.W) * p.in_cs + ch * 32) * 4u, 0));
+        regs[row] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_m, (unsigned)((row * p.W) * p.in_cs + ch * 32) * 4u, 0));
       } else {
         regs[row] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    if (HALO_W) regs[C::IH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff_h, (unsigned)(ch * 32) * 4u, 0));
+    if (HALO_W) {
+      const bool halo_ok = tid < HALO_V4 && iy0 + hrow >= 0 && iy0 + hrow < p.H && ix0 + hcol >= 0 && ix0 + hcol < p.W;
+      const unsigned voff_h = halo_ok ? (unsigned)((hrow * p.W + hcol) * p.in_cs + c4 * 4) * 4u : kLaneOff;
+      regs[C::IH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_h, (unsigned)(ch * 32) * 4u, 0));
+    }
   };
   auto store_in = [&](const f32x4 (&regs)[C::IN_PER_THREAD]) {
     char* base = reinterpret_cast<char*>(s_in);
@@ -125,35 +137,38 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
       if (idx < C::W_V4) *reinterpret_cast<f32x4*>(s_w + idx * 4) = regs[i];
     }
   };
+  // (TH+2) x (TW+2) halo tile of the gs channel, zero outside the image: shift-only index math, masked buffer loads.
+  // Three elements per thread: rows 0..7 x columns 0..31, rows 8..TH+1 x columns 0..31, columns 32..33.
+  static_assert(!GS || TH + 2 <= 16, "gs tile: two 8-row passes");
+  const int g_row[3] = {tid >> 5, 8 + (tid >> 5), tid >> 1};
+  const int g_col[3] = {tid & 31, tid & 31, 32 + (tid & 1)};
+  const bool g_act[3] = {true, 8 + (tid >> 5) < TH + 2, (tid >> 1) < TH + 2};
+  auto fetch_gs = [&](const Tile& d, float (&regs)[3]) {
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.gs + ((ptrdiff_t)d.img * p.H + (d.y0 - 1)) * p.W + (d.x0 - 1));
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int gy = d.y0 - 1 + g_row[e], gx = d.x0 - 1 + g_col[e];
+      const bool ok = g_act[e] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      regs[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? (unsigned)(g_row[e] * p.W + g_col[e]) * 4u : kLaneOff, 0, 0));
+    }
+  };
+  auto store_gs = [&](const float (&regs)[3]) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      if (g_act[e]) s_gs[g_row[e] * (TW + 2) + g_col[e]] = regs[e];
+  };
 
+  // ---- prologue: first tile's chunk 0 ----
+  int tile = blockIdx.x;
+  Tile cur = decode(tile);
   f32x4 in_regs[C::IN_PER_THREAD];
   f32x4 w_regs[C::W_PER_THREAD];
-  fetch_in(0, in_regs);
+  float gs_regs[3] = {0.f, 0.f, 0.f};
+  fetch_in(cur, 0, in_regs);
   fetch_w(0, w_regs);
-  if (GS) {   // (TH+2) x (TW+2) halo tile of the gs channel, zero outside the image: shift-only index math, masked buffer loads
-    const __amdgpu_buffer_rsrc_t gs_rsrc = make_rsrc(p.gs + ((ptrdiff_t)img * p.H + (y0 - 1)) * p.W + (x0 - 1));
-    auto gs_elem = [&](int row, int col, bool active) {
-      const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-      const bool ok = active && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gs_rsrc, ok ? (unsigned)(row * p.W + col) * 4u : kLaneOff, 0, 0));
-      if (active) s_gs[row * (TW + 2) + col] = v;
-    };
-    static_assert(TH + 2 <= 16, "gs tile: two 8-row passes");
-    gs_elem(tid >> 5, tid & 31, true);                                     // rows 0..7, columns 0..31
-    gs_elem(8 + (tid >> 5), tid & 31, 8 + (tid >> 5) < TH + 2);             // rows 8..TH+1
-    gs_elem(tid >> 1, 32 + (tid & 1), (tid >> 1) < TH + 2);                 // columns 32, 33
-  }
-  store_in(in_regs);
-  store_w(w_regs);
-  __syncthreads();
-
-#ifdef BSR_STAMPS
-  st1 = __builtin_amdgcn_s_memtime();
-#endif
-  // fused-tail operands are fetched now, so their latency hides under the MFMA loop instead of serialising the epilogue:
-  // clr_conv2 A operand W2^T[c2 = r][c = 4q + e], clr_conv3 A operand W3^T[c3 = r < 3][c = 4q + e], biases, and (lanes q == 0) the
-  // input pixels for the final grayscale difference
-  float tw2[4], tw3[4], tin[MT][3];
+  if (GS) fetch_gs(cur, gs_regs);
+  // fused-tail weights: clr_conv2 A operand W2^T[c2 = r][c = 4q + e], clr_conv3 A operand W3^T[c3 = r < 3][c = 4q + e], biases
+  float tw2[4], tw3[4];
   f32x4 tb2 = {0.f, 0.f, 0.f, 0.f};
   float tb3[3] = {0.f, 0.f, 0.f};
   if (TAIL) {
@@ -165,126 +180,151 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     tb2 = *reinterpret_cast<const f32x4*>(p.tail_w + 256 + 4 * q);
 #pragma unroll
     for (int c = 0; c < 3; ++c) tb3[c] = p.tail_w[320 + c];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const size_t pix = ((size_t)img * p.H + y0 + wave * RW + mt / 2) * p.W + x0 + (mt % 2) * 16 + r;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) tin[mt][c] = p.inputs[pix * 3 + c];
-    }
   }
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * q);
+  f32x4 wg = {0.f, 0.f, 0.f, 0.f};
+  if (GS) wg = *reinterpret_cast<const f32x4*>(p.w_gs + r * 16 + 4 * q);
+  store_in(in_regs);
+  store_w(w_regs);
+  if (GS) store_gs(gs_regs);
+  __syncthreads();
+#ifdef BSR_STAMPS
+  st1 = __builtin_amdgcn_s_memtime();
+#endif
 
   // this wave: tile rows wave*RW .. wave*RW+RW-1, two 16-pixel MFMA tiles per row
   int x_base[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) x_base[mt] = ((wave * RW + mt / 2) * IW + (mt % 2) * 16 + r) * LDP + 4 * q;
   const int w_base = r * LDP + 4 * q;
-  f32x4 acc[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
-    if (ch == 0) {
-      fetch_in(1, in_regs);
-      fetch_w(1, w_regs);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 wf[2], xf[2][MT];
-    wf[0] = *reinterpret_cast<const f32x4*>(s_w + w_base);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xf[0][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt]);
-#pragma unroll
-    for (int i = 0; i < T * 2; ++i) {        // (tap, 16-channel group) steps, fragments read one step ahead
-      const int cur = i & 1, nxt = cur ^ 1;
-      if (i + 1 < T * 2) {
-        const int t = (i + 1) / 2, g = (i + 1) % 2;
-        wf[nxt] = *reinterpret_cast<const f32x4*>(s_w + w_base + t * 16 * LDP + g * 16);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          xf[nxt][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt] + ((t / KW) * IW + (t % KW)) * LDP + g * 16);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cur][j], xf[cur][mt][j], acc[mt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ch == 0) {
-      __syncthreads();
-      store_in(in_regs);
-      store_w(w_regs);
-      __syncthreads();
-    }
-  }
-
-  if (GS) {   // the gs channel: K group k = 4q + j <-> tap (k/3, k%3), k < 9
-    const f32x4 wg = *reinterpret_cast<const f32x4*>(p.w_gs + r * 16 + 4 * q);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = 4 * q + j;
-      const int kk = k < 9 ? k : 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const bool has_next = tile + (int)gridDim.x < ntiles;
+    const Tile nxt = decode(has_next ? tile + (int)gridDim.x : tile);
+    float tin[MT][3];
+    if (TAIL) {   // the input pixels for the final grayscale difference (lanes q == 0 use them), latency hidden by the MFMA loop
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const float xv = s_gs[(wave * RW + mt / 2 + kk / 3) * (TW + 2) + (mt % 2) * 16 + r + kk % 3];
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j], k < 9 ? xv : 0.f, acc[mt], 0, 0, 0);
+        const size_t pix = ((size_t)cur.img * p.H + cur.y0 + wave * RW + mt / 2) * p.W + cur.x0 + (mt % 2) * 16 + r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tin[mt][c] = p.inputs[pix * 3 + c];
       }
     }
-  }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      // the next (tile, chunk) goes into registers now and into LDS after this chunk's MFMAs
+      if (ch == 0) {
+        fetch_in(cur, 1, in_regs);
+        fetch_w(1, w_regs);
+      } else if (has_next) {
+        fetch_in(nxt, 0, in_regs);
+        fetch_w(0, w_regs);
+        if (GS) fetch_gs(nxt, gs_regs);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 wf[2], xf[2][MT];
+      wf[0] = *reinterpret_cast<const f32x4*>(s_w + w_base);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[0][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt]);
+#pragma unroll
+      for (int i = 0; i < T * 2; ++i) {        // (tap, 16-channel group) steps, fragments read one step ahead
+        const int cu = i & 1, nx = cu ^ 1;
+        if (i + 1 < T * 2) {
+          const int t = (i + 1) / 2, g = (i + 1) % 2;
+          wf[nx] = *reinterpret_cast<const f32x4*>(s_w + w_base + t * 16 * LDP + g * 16);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            xf[nx][mt] = *reinterpret_cast<const f32x4*>(s_in + x_base[mt] + ((t / KW) * IW + (t % KW)) * LDP + g * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cu][j], xf[cu][mt][j], acc[mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ch == 1 && GS) {   // the gs channel: K group k = 4q + j <-> tap (k/3, k%3), k < 9
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 4 * q + j;
+          const int kk = k < 9 ? k : 0;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float xv = s_gs[(wave * RW + mt / 2 + kk / 3) * (TW + 2) + (mt % 2) * 16 + r + kk % 3];
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j], k < 9 ? xv : 0.f, acc[mt], 0, 0, 0);
+          }
+        }
+      }
+      if (ch == 0 || has_next) {
+        __syncthreads();
+        store_in(in_regs);
+        store_w(w_regs);
+        if (ch == 1 && GS) store_gs(gs_regs);
+        __syncthreads();
+      }
+    }
 
 #ifdef BSR_STAMPS
-  st2 = __builtin_amdgcn_s_memtime();
+    const unsigned long long se0 = __builtin_amdgcn_s_memtime();
 #endif
-  // epilogue: lane (pixel r of tile mt, q) holds channels 4q .. 4q+3
-  const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * q);
+    // epilogue: lane (pixel r of tile mt, q) holds channels 4q .. 4q+3
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const size_t row_pix = ((size_t)img * p.H + y0 + wave * RW + mt / 2) * p.W + x0;
-    f32x4 v = acc[mt] + b4;
-    if (p.act) {
+    for (int mt = 0; mt < MT; ++mt) {
+      const size_t row_pix = ((size_t)cur.img * p.H + cur.y0 + wave * RW + mt / 2) * p.W + cur.x0;
+      f32x4 v = acc[mt] + b4;
+      if (p.act) {
 #pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        const f32x2 y = leaky_relu2(f32x2{v[e], v[e + 1]});
-        v[e] = y[0];
-        v[e + 1] = y[1];
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 y = leaky_relu2(f32x2{v[e], v[e + 1]});
+          v[e] = y[0];
+          v[e + 1] = y[1];
+        }
       }
-    }
-    const size_t pix = row_pix + (mt % 2) * 16 + r;
-    if (!TAIL) {
-      *reinterpret_cast<f32x4*>(p.out + pix * p.out_cs + 4 * q) = v;
-    } else {
-      // clr_conv2: y2^T[c2][px] = sum_c W2^T[c2][c] * y1^T[c][px]; register e of v is channel c = 4q + e (k index q)
-      f32x4 a2 = tb2;
+      const size_t pix = row_pix + (mt % 2) * 16 + r;
+      if (!TAIL) {
+        *reinterpret_cast<f32x4*>(p.out + pix * p.out_cs + 4 * q) = v;
+      } else {
+        // clr_conv2: y2^T[c2][px] = sum_c W2^T[c2][c] * y1^T[c][px]; register e of v is channel c = 4q + e (k index q)
+        f32x4 a2 = tb2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tw2[e], v[e], a2, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tw2[e], v[e], a2, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        const f32x2 y = leaky_relu2(f32x2{a2[e], a2[e + 1]});
-        a2[e] = y[0];
-        a2[e + 1] = y[1];
-      }
-      // clr_conv3: rows c3 = 0..2 (lanes r < 3 carry the weights, the rest multiply by 0)
-      f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 y = leaky_relu2(f32x2{a2[e], a2[e + 1]});
+          a2[e] = y[0];
+          a2[e + 1] = y[1];
+        }
+        // clr_conv3: rows c3 = 0..2 (lanes r < 3 carry the weights, the rest multiply by 0)
+        f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(r < 3 ? tw3[e] : 0.f, a2[e], a3, 0, 0, 0);
-      if (q == 0) {   // rows 0..2 = R,G,B of pixel r
+        for (int e = 0; e < 4; ++e) a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(r < 3 ? tw3[e] : 0.f, a2[e], a3, 0, 0, 0);
+        if (q == 0) {   // rows 0..2 = R,G,B of pixel r
 #pragma clang fp contract(off)
-        const float cr = a3[0] + tb3[0], cg = a3[1] + tb3[1], cb = a3[2] + tb3[2];
-        p.con_rgb[pix * 3 + 0] = cr;
-        p.con_rgb[pix * 3 + 1] = cg;
-        p.con_rgb[pix * 3 + 2] = cb;
-        const float g1 = (cr * 0.2989f + cg * 0.5870f) + cb * 0.1140f;
-        const float g0 = (tin[mt][0] * 0.2989f + tin[mt][1] * 0.5870f) + tin[mt][2] * 0.1140f;
-        p.dif[pix] = g1 - g0;
+          const float cr = a3[0] + tb3[0], cg = a3[1] + tb3[1], cb = a3[2] + tb3[2];
+          p.con_rgb[pix * 3 + 0] = cr;
+          p.con_rgb[pix * 3 + 1] = cg;
+          p.con_rgb[pix * 3 + 2] = cb;
+          const float g1 = (cr * 0.2989f + cg * 0.5870f) + cb * 0.1140f;
+          const float g0 = (tin[mt][0] * 0.2989f + tin[mt][1] * 0.5870f) + tin[mt][2] * 0.1140f;
+          p.dif[pix] = g1 - g0;
+        }
       }
     }
+#ifdef BSR_STAMPS
+    st_epi += __builtin_amdgcn_s_memtime() - se0;
+#endif
+    cur = nxt;
   }
 #ifdef BSR_STAMPS
   if (p.stamps != nullptr && lane == 0) {
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long st3 = __builtin_amdgcn_s_memtime(), rt3 = __builtin_amdgcn_s_memrealtime();
     unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
-    d[0] = st1 - st0; d[1] = st2 - st1; d[2] = rt3 - rt0; d[3] = st3 - st2;
+    d[0] = st1 - st0; d[1] = st3 - st1 - st_epi; d[2] = rt3 - rt0; d[3] = st_epi;
   }
 #endif
 }
@@ -294,14 +334,24 @@ inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream) 
   using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
   auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW>;
   static bool attr_set = false;
-  if (!attr_set && C::SMEM_BYTES > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
+  static int resident = 0;                 // workgroups the device holds at once (2 per CU: LDS-bound)
+  if (!attr_set) {
+    if (C::SMEM_BYTES > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
+      if (e != hipSuccess) return e;
+    }
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
+    resident = 2 * cus;
     attr_set = true;
   }
   a.tiles_x = a.W / C::TW;
   a.tiles_y = a.H / C::TH;
-  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * batch), dim3(256), C::SMEM_BYTES, stream, a);
+  a.batch = batch;
+  const int ntiles = a.tiles_x * a.tiles_y * batch;
+  hipLaunchKernelGGL(kern, dim3(ntiles < resident ? ntiles : resident), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }
 
