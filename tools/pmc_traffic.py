@@ -19,7 +19,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 
 
 def load(d, name):
-    c = pd.read_csv(sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv")))[-1])
+    c = pd.read_csv(max(glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv")), key=os.path.getmtime))
     c = c[(c["Counter_Name"] == name) & ~c["Kernel_Name"].str.contains("fillBuffer")]
     ids = sorted(c["Dispatch_Id"].unique())
     assert len(ids) % 2 == 0, "expected exactly two forwards"

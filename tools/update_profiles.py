@@ -14,7 +14,7 @@ import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, bench_json, prof_dir = sys.argv[1], sys.argv[2], sys.argv[3]
-stats = sorted(glob.glob(os.path.join(ROOT, prof_dir, "*", "*kernel_stats.csv")))[-1]
+stats = max(glob.glob(os.path.join(ROOT, prof_dir, "*", "*kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(ROOT, bench_json), os.path.join(ROOT, "profiles", tag + "_bench_n1.json"))
 b = json.load(open(os.path.join(ROOT, bench_json)))
