@@ -9,8 +9,9 @@ Differences from the reference, all deliberate:
   reference runs the generator on all 10 rows and keeps row 0 (train_test_GSC.py:866-871, utils.py:231).  Rows are
   independent at inference, so by default only row 0 of each element is computed and rows of several elements are
   batched into one forward (``batch`` argument); ``all_rows=True`` reproduces the reference's 10-row forward;
-* ``test`` returns the generator outputs of the UCB path; the ~320 lines of dataset-specific numpy/cv2
-  post-processing behind it (train_test_GSC.py:424-748) are host code outside the hot path.
+* ``test`` batches the generator over several UCB items and then applies the reference's per-image post-processing
+  (train_test_GSC.py:424-748: mask heuristics, connected components, composite, SSIM / PSNR) on the host — ``ucb_post.py``;
+  the seven mask images per item are read from ``Config.UCB_MASK_ROOT`` (the reference reads them from the working directory).
 """
 from __future__ import annotations
 
@@ -35,6 +36,7 @@ class Config(object):
     FIG_SIZE = 128
     BATCH_SIZE = 1
     CHECKPOINT_DIR = './log/test'
+    UCB_MASK_ROOT = '.'              # parent of the UCB_input_images_*_masks_* folders (train_test_GSC.py:372,386-392)
 
     def __init__(self, gpu_idx: Optional[int] = None):
         if gpu_idx is not None:
@@ -141,13 +143,35 @@ class FSRNet(object):
         return {}, [im.to(dev), gs, con_rgb, mask_pred, gt.to(dev), face.to(dev)]
 
     # -- loops ------------------------------------------------------------------------------
-    def _loop(self, dataset, batch: int, ucb: bool):
+    def _ucb_masks(self) -> List[Dict[str, str]]:
+        """Per-item mask file paths in the reference's order: the sorted listing of the with-hair folder, the same file name in
+        the other six (train_test_GSC.py:372,386-392)."""
+        from .ucb_post import MASK_DIRS
+        root = self.config.UCB_MASK_ROOT
+        first = os.path.join(root, MASK_DIRS["face_hair"])
+        if not os.path.isdir(first):
+            raise FileNotFoundError("FSRNet.test needs the UCB mask folders under Config.UCB_MASK_ROOT (%s is missing)" % first)
+        return [{k: os.path.join(root, d, f) for k, d in MASK_DIRS.items()} for f in sorted(os.listdir(first))]
+
+    @staticmethod
+    def _read_masks(paths: Dict[str, str]) -> Dict[str, np.ndarray]:
+        from PIL import Image
+        out = {}
+        for k, path in paths.items():
+            a = np.asarray(Image.open(path).convert("L"), np.float64) / 255.0          # cv2.imread(...)/255.0, 3 equal channels
+            out[k] = np.repeat(a[:, :, None], 3, axis=2)
+        return out
+
+    def _loop(self, dataset, batch: int, ucb: bool, postprocess: bool = True):
         self._restore()
         start = time.time()
         names = list(dataset.name_list)
         num_list = len(names)
         results = []
-        pending: List[Tuple[int, str, torch.Tensor]] = []
+        pending: List[Tuple[int, str, torch.Tensor, object]] = []
+        mask_files = self._ucb_masks() if ucb and postprocess else None
+        if mask_files is not None and len(mask_files) < num_list:
+            raise ValueError("FSRNet.test: %d items but only %d mask files" % (num_list, len(mask_files)))
 
         def flush():
             if not pending:
@@ -156,21 +180,33 @@ class FSRNet(object):
             im, gt, uv, reg, face = torch.split(rows, list(SPLIT_FFHQ), dim=3)
             dev = "cuda:%d" % self.gen._device
             gs, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg, chuck=4 if ucb else 1, training=False)
-            for j, (step, name, _) in enumerate(pending):
+            if ucb and postprocess:
+                con_h, mask_h = con_rgb.cpu().numpy(), mask_pred.cpu().numpy()
+            for j, (step, name, _, box) in enumerate(pending):
                 sl = slice(j, j + 1)
-                if ucb:
+                losses: Dict[str, float] = {}
+                if ucb and postprocess:                                        # train_test_GSC.py:424-748 on the host
+                    from .ucb_post import ucb_postprocess
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        losses, f = ucb_postprocess(im[j].numpy(), gt[j].numpy(), con_h[j], mask_h[j], np.asarray(box).reshape(-1)[:4],
+                                                    self._read_masks(mask_files[step]))
+                    figs = [torch.from_numpy(a) for a in f]
+                    shown = figs
+                elif ucb:
                     figs = [im[sl].to(dev), gs[sl], con_rgb[sl], mask_pred[sl], gt[sl].to(dev), face[sl].to(dev)]
+                    shown = [figs[0], torch.clamp(figs[2], 0, 1), figs[3] * figs[5] * 2]
                 else:
                     figs = [im[sl].to(dev), torch.clamp(con_rgb[sl], 0, 1), mask_pred[sl] * face[sl].to(dev) * 2]
-                self.log.display({}, 0, step, False, num_list)
-                self.log.save_img(figs[:3] if not ucb else [figs[0], torch.clamp(figs[2], 0, 1), figs[3] * figs[5] * 2], name)
-                results.append((name, figs))
+                    shown = figs
+                self.log.display(losses, 0, step, False, num_list)
+                self.log.save_img(shown, name)
+                results.append((name, figs) if not (ucb and postprocess) else (name, figs, losses))
             pending.clear()
 
         for step, img_name in enumerate(names):
             element = next(dataset.feed)
             img = element[0]
-            pending.append((step, _name(img_name), img))
+            pending.append((step, _name(img_name), img, element[1] if len(element) > 1 else None))
             if len(pending) >= batch:
                 flush()
         flush()
@@ -187,9 +223,10 @@ class FSRNet(object):
         and ``.name_list`` (dataset.py:29-30)."""
         return self._loop(dataset_val, batch, ucb=False)
 
-    def test(self, dataset_val, batch: int = 16):
-        """train_test_GSC.py:360-408 (generator part; see module docstring)."""
-        return self._loop(dataset_val, batch, ucb=True)
+    def test(self, dataset_val, batch: int = 16, postprocess: bool = True):
+        """train_test_GSC.py:360-408 + test_step :411-748.  Returns [(name, figs, {'ssim','psnr'})] with the reference's seven
+        figures per item; ``postprocess=False`` returns the raw generator outputs [(name, [img, gs, con_rgb, dif, gt, face])]."""
+        return self._loop(dataset_val, batch, ucb=True, postprocess=postprocess)
 
 
 def roc_auc_score(labels: np.ndarray, scores: np.ndarray) -> float:

@@ -104,7 +104,7 @@ def test_config3_ucb_miniature(tmp_path, golden_dir):
     w = init_weights(1)
     ds = D.Dataset(cfg, "test", ucb=True)
     assert len(ds.name_list) == 2
-    res = FSRNet(cfg, weights=w).test(ds, batch=16)
+    res = FSRNet(cfg, weights=w).test(ds, batch=16, postprocess=False)
     assert len(res) == 2
     ds2 = D.Dataset(cfg, "test", ucb=True)
     rows = torch.from_numpy(np.concatenate([next(ds2.feed)[0][0] for _ in range(2)], axis=0))      # [2,256,256,16]
@@ -120,3 +120,19 @@ def test_config3_ucb_miniature(tmp_path, golden_dir):
     assert float(psnr.min()) > 80.0 and float(ssim.min()) > 0.99999
     # the metric the reference prints for UCB (train_test_GSC.py:724-725): prediction vs ground truth — finite numbers on this input
     assert torch.isfinite(M.psnr(hip_rgb.clamp(0, 1), gt)).all() and torch.isfinite(M.ssim(hip_rgb.clamp(0, 1), gt)).all()
+
+    # the whole UCB step (generator + the reference's host post-processing, train_test_GSC.py:411-748) against the same
+    # post-processing applied to the ORACLE's generator outputs: identical shadow masks, SSIM / PSNR within 1e-3
+    from blindshadowremoval_amd.ucb_post import ucb_postprocess
+    from ucb_cases import ITEMS, load_masks
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    full = FSRNet(cfg, weights=w).test(D.Dataset(cfg, "test", ucb=True), batch=16)
+    ds3 = D.Dataset(cfg, "test", ucb=True)
+    for j, (name, figs, losses) in enumerate(full):
+        box = np.asarray(next(ds3.feed)[1]).reshape(-1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ref_losses, ref_figs = ucb_postprocess(img[j].numpy(), gt[j].numpy(), ref_rgb[j].numpy(), ref_dif[j].numpy(), box, load_masks(ITEMS[j]))
+        assert len(figs) == 7 and figs[4].shape == (1, 256, 256, 3)
+        assert int((figs[4].numpy() != ref_figs[4]).sum()) <= 3 * 4          # at most a few pixels may sit on a threshold
+        for k in ("ssim", "psnr"):
+            assert np.isfinite(losses[k]) and abs(losses[k] - ref_losses[k]) < 1e-3 * max(1.0, abs(ref_losses[k]))

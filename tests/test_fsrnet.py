@@ -70,8 +70,10 @@ def test_testFFHQ_on_sample_matches_oracle(golden_dir, tmp_path):
     for a, b in zip(figs10, figs1):
         assert torch.equal(a[:1], b)
     # UCB loop head (generator outputs)
-    res = fsr.test(OneSampleDataset(golden_dir), batch=4)
+    res = fsr.test(OneSampleDataset(golden_dir), batch=4, postprocess=False)
     assert len(res) == 1 and res[0][1][1].shape == (1, 256, 256, 1)
+    with pytest.raises(FileNotFoundError, match="UCB mask folders"):        # the full UCB step needs the seven mask folders
+        fsr.test(OneSampleDataset(golden_dir), batch=4)
 
 
 @pytest.mark.gpu

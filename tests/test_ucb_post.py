@@ -1,0 +1,42 @@
+"""the UCB post-processing restatement (blindshadowremoval_amd/ucb_post.py) against the outputs of the
+reference's own `FSRNet.test_step` code (tests/golden/ucb_post_9156.npz, tools/make_ucb_post_fixture.py) on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from blindshadowremoval_amd.ucb_post import resize_bilinear, ucb_postprocess
+from ucb_cases import GOLDEN, cases
+
+FIX = np.load(os.path.join(GOLDEN, "ucb_post_9156.npz"))
+
+
+def test_fixture_covers_small_and_large_detections():
+    det = {k: int(FIX[k].sum()) for k in FIX.files if k.endswith("_detected")}
+    assert len(det) == 10 and any(v < 2000 for v in det.values()) and any(v > 20000 for v in det.values())
+
+
+@pytest.mark.parametrize("case", list(cases()), ids=lambda c: c[0])
+def test_matches_reference_code(case):
+    key, row, box, masks, con, dif = case
+    with np.errstate(invalid="ignore", divide="ignore"):      # the reference divides by an empty mask's area in the all-rejected case
+        losses, figs = ucb_postprocess(row[..., 0:3], row[..., 3:6], con, dif, box, masks)
+    assert len(figs) == 7 and all(f.shape == (1, 256, 256, 3) and f.dtype == np.float32 for f in figs)
+    detected = figs[4][0, :, :, 0]
+    assert set(np.unique(detected)) <= {0.0, 1.0}
+    np.testing.assert_array_equal(detected.astype(np.uint8), FIX[key + "_detected"])      # every threshold / component decision
+    if key + "_out" in FIX.files:
+        np.testing.assert_allclose(figs[1][0], FIX[key + "_out"].astype(np.float32), atol=1e-3)   # fixture stored as fp16
+    assert abs(losses["ssim"] - float(FIX[key + "_ssim"])) < 1e-4
+    assert abs(losses["psnr"] - float(FIX[key + "_psnr"])) < 1e-3
+    # composite only inside the detected mask (train_test_GSC.py:714)
+    outside = detected == 0
+    np.testing.assert_allclose(figs[1][0][outside], np.clip(figs[0][0][outside], 0, 1), atol=1e-6)
+
+
+def test_resize_is_tf_half_pixel_bilinear():
+    x = np.arange(16, dtype=np.float32).reshape(4, 4, 1)
+    y = resize_bilinear(x, 2)                        # 2x down-sampling: sample points at 0.5, 2.5 -> plain 2x2 means
+    np.testing.assert_allclose(y[:, :, 0], [[2.5, 4.5], [10.5, 12.5]])
+    z = resize_bilinear(x, 8)                        # up-sampling clamps at the border
+    assert z.shape == (8, 8, 1) and z[0, 0, 0] == 0.0 and z[-1, -1, 0] == 15.0
