@@ -12,7 +12,7 @@ benchmarks and parity tests use ``init_weights(seed)``.
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Dict, Tuple
+from typing import Dict, Tuple  # noqa: F401 (Tuple: string annotations)
 
 import numpy as np
 

@@ -7,8 +7,6 @@ two correct fp32 implementations and changes the output by O(1) downstream, so p
   2. every cell whose bmask differs has |d32_oracle - 0.1| < ``flip_tol`` (a legitimate flip);
   3. the four outputs agree to ``tol`` with the oracle run on the SAME mask.
 """
-import numpy as np
-import torch
 
 from oracle.gsc_oracle import GeneratorOracle
 

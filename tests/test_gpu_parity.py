@@ -1,9 +1,7 @@
 """-m gpu parity tests: the HIP path, called through the C ABI (ctypes -> libbsr_hip.so), against the CPU
 oracle on the same seeded inputs.  Tolerance: 1e-3 absolute per pixel in fp32 (BASELINE.json north_star);
 measured agreement is ~1e-5."""
-import ctypes
 
-import numpy as np
 import pytest
 import torch
 
