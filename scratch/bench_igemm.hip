@@ -128,6 +128,15 @@ int run_gemm(const char* name, int pixels, int N, int nsplit, bool res) {
 
 int main(int argc, char** argv) {
   if (argc > 1) g_mode = atoi(argv[1]);
+  if (argc > 2 && argv[2][0] == 's') {            // the stride-2 encoder convs
+    if (run<3, 3, 2, false, 2, 16, 1>("down1", 32, 256, 256, 32, 64)) return 1;
+    if (run<3, 3, 2, false, 2, 32, 1>("down1/cc32", 32, 256, 256, 32, 64)) return 1;
+    if (run<3, 3, 2, false, 2, 16, 1>("down2", 32, 128, 128, 64, 64)) return 1;
+    if (run<3, 3, 2, false, 2, 32, 1>("down2/cc32", 32, 128, 128, 64, 64)) return 1;
+    if (run<3, 3, 2, false, 3, 16, 1>("down3", 32, 64, 64, 64, 96)) return 1;
+    if (run<3, 3, 2, false, 1, 16, 1>("down3/ni1", 32, 64, 64, 64, 96)) return 1;
+    return 0;
+  }
   if (argc > 2 && argv[2][0] == 'n') {            // only the 16-channel kernels
     if (run_n16<3, 3, true, true, 2>("clr_conv1", 32, 256, 256)) return 1;
     if (run_n16<7, 1, false, false, 2>("heads", 32, 256, 256)) return 1;
