@@ -24,7 +24,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: BF16/F16 MFMA dense (only used for the opt-in --dtype f16 line)
 
 
-def cpu_baseline(weights, seconds_budget=25.0):
+def cpu_baseline(weights, seconds_budget=25.0, gen=None, device=None):
     """Oracle (torch-CPU restatement of the reference's TF graph; TF itself is not installable here) timed on
     the host cores of this box, bounded sample of the same synthetic workload.  The thread count is the best of a
     short sweep (oneDNN does not scale monotonically on a 2-socket host); `cores` reports the count actually used."""
@@ -56,9 +56,23 @@ def cpu_baseline(weights, seconds_budget=25.0):
         times.append(run_once())
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(b / med, 3), "unit": "images/sec", "cores": best_threads, "kind": "port",
-            "sample": "%d forwards of %d synthetic 256x256 images, median (oracle-CPU torch/oneDNN fp32, proxy for the TF2-CPU path; "
-                      "thread count = best of a sweep on a %d-thread host)" % (len(times), b, cores)}
+    out = {"value": round(b / med, 3), "unit": "images/sec", "cores": best_threads, "kind": "port",
+           "sample": "%d forwards of %d synthetic 256x256 images, median (oracle-CPU torch/oneDNN fp32, proxy for the TF2-CPU path; "
+                     "thread count = best of a sweep on a %d-thread host)" % (len(times), b, cores)}
+    if gen is not None:
+        # the checker role of the oracle (BASELINE metric: "... PSNR vs TF2 ref"): the HIP outputs of the same sample against it,
+        # compared given the same 32x32 threshold mask (SURVEY F7 protocol, tests/parity_util.py)
+        hip = [t.cpu() for t in gen(inp.to(device), uv.to(device))]
+        bmask = gen.probe("bmask").cpu()
+        pr = {}
+        oracle(inp, uv, probes=pr)
+        flips = int((bmask != pr["bmask"]).sum())
+        ref = oracle(inp, uv, bmask_override=bmask)
+        err = max(float((a - r).abs().max()) for a, r in zip(hip, ref))
+        mse = float(((hip[1].double().clamp(0, 1) - ref[1].double().clamp(0, 1)) ** 2).mean())
+        out["parity"] = {"max_abs_err": err, "psnr_db_con_rgb": (round(-10.0 * __import__("math").log10(mse), 2) if mse > 0 else None),
+                         "bmask_flips": flips, "sample": "the %d images of the CPU sample, all four outputs" % b}
+    return out
 
 
 def main():
@@ -191,7 +205,7 @@ def main():
                          "class_ms": {k: round(v[0], 4) for k, v in acc.items()}},
         }
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(weights)
+            result["cpu_baseline"] = cpu_baseline(weights, gen=gen, device=dev)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
