@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — images/sec of the GSC generator batched forward at 256x256 on N MI355X (BASELINE.json).
 
-A step = one forward of the hot path over one synthetic batch of 32 images per GPU (BASELINE config 2:
+A step = one forward of the hot path over one synthetic batch of 32 images per GPU (BASELINE configs[1]:
 "Batch=32 synthetic 256x256x3, full GSC generator fp32"), inputs already resident in HBM.  For N > 1 the
 batch shards one-process-per-GPU (weak scaling: 32 images per rank) and each step ends with the RCCL
 all-gather that re-assembles the consumed outputs (con_rgb + dif) on every rank, overlapped with the next
 step's compute.  Rank 0 prints ONE JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--dtype f32|f16] [--workload gsc256|tsm512]
+                    [--no-cpu-baseline] [--loop ffhq|ucb]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this process a LAUNCHER: it starts N rank
+processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set) before anything touches
+the GPU, relays rank 0's JSON line and exits non-zero if any rank fails.  Under `torch.distributed.run` the
+ranks already exist and the launcher is skipped.  `--backend gloo --stub` runs the same rank logic on CPU
+with a stand-in generator (tests/test_bench_cpu.py): it checks the launcher, sharding, all-gather overlap
+bookkeeping and the JSON contract, and is labelled `"stub": true` — never a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,45 +33,166 @@ GFLOP_3X3_PER_IMAGE = 11.017    # 3x3 conv + transposed 3x3 ("3x3-conv path", SU
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: BF16/F16 MFMA dense (only used for the opt-in --dtype f16 line)
 
+# Algorithmic MMAC per 256x256 image of every launch of the forward, by the layer name bsr_timing_entry reports
+# (fused launches carry the sum of the reference layers they compute).
+_RES_CONV1 = (12.98, 33.69, 33.69, 34.21, 34.21, 34.21)
+LAYER_MMAC = {"conv1": 308.28, "down1": 301.99, "down2": 150.99, "down3": 56.62, "up1": 227.38, "up2": 377.49, "up3": 1207.96,
+              "heads": 2 * 205.52, "clr_up1": 307.89, "clr_up2": 452.98, "clr_up3": 905.97, "clr_conv1": 613.42 + 16.78 + 3.15}
+for _i in range(6):
+    LAYER_MMAC["res%d.conv1" % _i] = _RES_CONV1[_i]
+    LAYER_MMAC["res%d.conv2" % _i] = 150.99
+    LAYER_MMAC["res%d.c3q" % _i] = 4 * 33.69            # conv3 + theta | phi | g (composed offline into one K = 128 GEMM)
+    LAYER_MMAC["res%d.attention" % _i] = 2 * 134.22
+    LAYER_MMAC["res%d.w" % _i] = 33.69
+# the "3x3-conv path" of north_star / SURVEY §8d: 3x3, stride-2 3x3 and transposed 3x3 layers (clr_conv1's launch also carries the fused 1x1 tail)
+LAYERS_3X3 = (["down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3", "clr_conv1"] + ["res%d.conv2" % i for i in range(6)])
+# kernel instantiation -> the layers it runs (csrc/bsr_api.hip launch table)
+KERNEL_GROUPS = {
+    "igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=2,CC=32> (transposed 3x3: up2, up3, clr_up3)": ["up2", "up3", "clr_up3"],
+    "igemm_conv_kernel<3,3,1,TR,...> other instantiations (up1, clr_up1, clr_up2)": ["up1", "clr_up1", "clr_up2"],
+    "igemm_conv_kernel<3,3,1> (res*.conv2)": ["res%d.conv2" % i for i in range(6)],
+    "igemm_conv_kernel<3,3,2> (down1-3)": ["down1", "down2", "down3"],
+    "nonlocal_attention_kernel": ["res%d.attention" % i for i in range(6)],
+    "gemm_nloop_kernel (res*.c3q, res*.w)": ["res%d.%s" % (i, n) for i in range(6) for n in ("c3q", "w")],
+    "igemm_conv_kernel<1,1,1> (res*.conv1)": ["res%d.conv1" % i for i in range(6)],
+    "conv_n16_kernel<3,3,GS,TAIL> (clr_conv1 + clr_conv2 + clr_conv3 + dif)": ["clr_conv1"],
+    "conv_n16_kernel<7,1> (heads conv2|conv3)": ["heads"],
+    "stem7_kernel (conv1)": ["conv1"],
+}
 
-def cpu_baseline(weights, seconds_budget=25.0, gen=None, device=None):
-    """Oracle (torch-CPU restatement of the reference's TF graph; TF itself is not installable here) timed on
-    the host cores of this box, bounded sample of the same synthetic workload.  The thread count is the best of a
-    short sweep (oneDNN does not scale monotonically on a 2-socket host); `cores` reports the count actually used."""
+
+# ----------------------------------------------------------------------------------------------- launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv, check_devices: bool) -> int:
+    """Start n rank processes of this script and relay rank 0's stdout.  Runs BEFORE this process touches the GPU
+    (torch.cuda.device_count() does not initialise it); never exec()s."""
+    if check_devices:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible: refusing to fall back to fewer ranks\n" % (n, have))
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    rc = 0
+    out0 = b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                    for q in pending:
+                        procs[q].terminate()        # exact PIDs of our own children
+            if pending:
+                if 0 in pending and procs[0].stdout is not None:
+                    # rank 0 prints one short line at the very end: read it without blocking the poll loop for long
+                    import select
+                    rd, _, _ = select.select([procs[0].stdout], [], [], 0.2)
+                    if rd:
+                        chunk = os.read(procs[0].stdout.fileno(), 1 << 16)
+                        out0 += chunk
+                else:
+                    time.sleep(0.2)
+        rest = procs[0].stdout.read() if procs[0].stdout is not None else b""
+        out0 += rest or b""
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    if rc == 0 and not out0.strip():
+        sys.stderr.write("bench.py: rank 0 printed nothing\n")
+        rc = 1
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------- cpu baseline
+def physical_cores() -> int:
+    """Physical cores of the host (lscpu: sockets x cores per socket); falls back to os.cpu_count()."""
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        vals = {}
+        for line in txt.splitlines():
+            k, _, v = line.partition(":")
+            vals[k.strip()] = v.strip()
+        n = int(vals["Socket(s)"]) * int(vals["Core(s) per socket"])
+        if n > 0:
+            return n
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(weights, gen=None, device=None, budget_s=75.0):
+    """Oracle (torch-CPU restatement of the reference's TF graph; TF itself is not installable here) timed on the host
+    cores of this box on BOUNDED samples of the same synthetic workload: 1 thread, all physical cores
+    (lscpu) and a short sweep in between (oneDNN does not scale monotonically on a 2-socket host).  `value` is the best
+    point, `cores` the thread count that produced it; every point is listed."""
     import torch
     from oracle.gsc_oracle import GeneratorOracle
-    cores = os.cpu_count() or 1
+    logical, phys = os.cpu_count() or 1, physical_cores()
     oracle = GeneratorOracle(weights)
     torch.manual_seed(0)
-    b = 8
-    inp, uv = torch.rand(b, 256, 256, 3), torch.rand(b, 256, 256, 3)
+    inp32, uv32 = torch.rand(32, 256, 256, 3), torch.rand(32, 256, 256, 3)
     t_all = time.perf_counter()
+    points = []
 
-    def run_once():
-        t0 = time.perf_counter()
-        oracle(inp, uv)
-        return time.perf_counter() - t0
-    best_threads, best_t = 1, float("inf")
-    for threads in sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2)}):
+    def measure(threads, b, max_runs, share):
+        """median of up to max_runs forwards of the first b images after one warm-up, inside `share` of the budget"""
         torch.set_num_threads(threads)
-        run_once()                               # warm-up (oneDNN primitive creation for this thread count)
-        t = run_once()
-        if t < best_t:
-            best_threads, best_t = threads, t
-        if time.perf_counter() - t_all > seconds_budget * 0.6:
+        t_start = time.perf_counter()
+        ts = []
+        for i in range(max_runs + 1):
+            t0 = time.perf_counter()
+            oracle(inp32[:b], uv32[:b])
+            dt = time.perf_counter() - t0
+            if i > 0 or max_runs == 0:
+                ts.append(dt)
+            if time.perf_counter() - t_start > share * budget_s and ts:
+                break
+        ts.sort()
+        med = ts[len(ts) // 2]
+        points.append({"threads": threads, "batch": b, "forwards": len(ts), "images_per_sec": round(b / med, 3)})
+
+    measure(1, 2, 2, 0.15)                                  # 1 thread: ~1 image/s, so a 2-image sample
+    sweep = sorted({max(2, phys // 8), max(2, phys // 4), max(2, phys // 2)} - {1, phys})
+    for th in sweep:
+        if time.perf_counter() - t_all > 0.5 * budget_s:
             break
-    torch.set_num_threads(best_threads)
-    times = [best_t]
-    while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
-        times.append(run_once())
-    times.sort()
-    med = times[len(times) // 2]
-    out = {"value": round(b / med, 3), "unit": "images/sec", "cores": best_threads, "kind": "port",
-           "sample": "%d forwards of %d synthetic 256x256 images, median (oracle-CPU torch/oneDNN fp32, proxy for the TF2-CPU path; "
-                     "thread count = best of a sweep on a %d-thread host)" % (len(times), b, cores)}
+        measure(th, 8, 2, 0.1)
+    measure(phys, 32, 3, 0.3)                               # all physical cores on the full configs[1] batch
+    best = max(points, key=lambda p: p["images_per_sec"])
+    out = {"value": best["images_per_sec"], "unit": "images/sec", "cores": best["threads"], "kind": "port",
+           "physical_cores": phys, "logical_cpus": logical, "points": points,
+           "sample": "oracle-CPU (torch/oneDNN fp32 restatement of model.py, proxy for the TF2-CPU path) on synthetic 256x256 images: "
+                     "1 thread x 2 images, a thread sweep x 8 images, all %d physical cores (lscpu) x the 32-image configs[1] batch; "
+                     "median forward per point, best point reported" % phys}
     if gen is not None:
-        # the checker role of the oracle (BASELINE metric: "... PSNR vs TF2 ref"): the HIP outputs of the same sample against it,
+        # the checker role of the oracle (BASELINE metric: "... PSNR vs TF2 ref"): the HIP outputs of an 8-image sample against it,
         # compared given the same 32x32 threshold mask (SURVEY F7 protocol, tests/parity_util.py)
+        import math
+        torch.set_num_threads(best["threads"])
+        inp, uv = inp32[:8], uv32[:8]
         hip = [t.cpu() for t in gen(inp.to(device), uv.to(device))]
         bmask = gen.probe("bmask").cpu()
         pr = {}
@@ -70,57 +201,151 @@ def cpu_baseline(weights, seconds_budget=25.0, gen=None, device=None):
         ref = oracle(inp, uv, bmask_override=bmask)
         err = max(float((a - r).abs().max()) for a, r in zip(hip, ref))
         mse = float(((hip[1].double().clamp(0, 1) - ref[1].double().clamp(0, 1)) ** 2).mean())
-        out["parity"] = {"max_abs_err": err, "psnr_db_con_rgb": (round(-10.0 * __import__("math").log10(mse), 2) if mse > 0 else None),
-                         "bmask_flips": flips, "sample": "the %d images of the CPU sample, all four outputs" % b}
+        out["parity"] = {"max_abs_err": err, "psnr_db_con_rgb": (round(-10.0 * math.log10(mse), 2) if mse > 0 else None),
+                         "bmask_flips": flips, "sample": "8 images of the CPU sample, all four outputs"}
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
-                    help="f32 = the measured path (BASELINE configs[1]); f16 = opt-in fp16 MFMA on the 3x3-conv path (configs[3])")
-    ap.add_argument("--no-gather", action="store_true", help="skip the output all-gather (N>1)")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------------- stub generator (CPU tests only)
+class _StubGenerator:
+    """Stand-in for the HIP generator so the rank logic (launcher, sharding, double-buffered all-gather, JSON contract)
+    runs on a CPU box over gloo.  NOT a fallback of the product path: bench lines produced with it carry "stub": true."""
 
+    def __call__(self, inputs, uv, out=None):
+        import torch
+        g0 = inputs.mean(dim=3, keepdim=True)
+        res = (g0, inputs * 0.5 + uv * 0.5, torch.cat([g0, g0 * 0, -g0], 3), g0 - uv[..., :1])
+        if out is not None:
+            for o, r in zip(out, res):
+                o.copy_(r)
+            return out
+        return res
+
+
+# ----------------------------------------------------------------------------------------------- roofline from per-launch events
+def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
+    """HIP events around every launch of a few extra forwards on the forward's stream (bsr_set_timing): per-layer device time ->
+    the dominant kernel instantiation's achieved TFLOP/s, the 3x3-conv path's, and every kernel group's fraction of the peak."""
+    import torch
+    gen.set_timing(True)
+    layer_ms = {}
+    for _ in range(n_rep):
+        run_once()
+        torch.cuda.synchronize()
+        for name, ms, _cls in gen.get_launch_timing():
+            layer_ms[name] = layer_ms.get(name, 0.0) + ms / n_rep
+    gen.set_timing(False)
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F16_MFMA_TFLOPS
+    groups = {}
+    for gname, layers in KERNEL_GROUPS.items():
+        ms = sum(layer_ms.get(n, 0.0) for n in layers)
+        if ms <= 0:
+            continue
+        gflop = 2e-3 * sum(LAYER_MMAC[n] for n in layers) * B
+        groups[gname] = {"ms": round(ms, 4), "launches": len(layers), "tflops": round(gflop / ms, 2), "frac": round(gflop / ms / peak, 4),
+                         "gflop": gflop}
+    dom_name = max(groups, key=lambda k: groups[k]["ms"])
+    dom = groups[dom_name]
+    t33 = sum(layer_ms.get(n, 0.0) for n in LAYERS_3X3)
+    path = GFLOP_3X3_PER_IMAGE * B / t33
+    t_all = sum(layer_ms.values())
+    glue_ms = sum(ms for n, ms in layer_ms.items() if n not in LAYER_MMAC)
+    rf = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+          "kernel": dom_name + " — the largest kernel instantiation, %.0f %% of the forward's device time" % (100 * dom["ms"] / t_all),
+          "launches_per_forward": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+          "algorithmic_gflop_per_launch": round(dom["gflop"] / dom["launches"], 2),
+          "path_3x3": {"achieved": round(path, 2), "frac": round(path / peak, 4), "launches": len(LAYERS_3X3), "ms": round(t33, 4),
+                       "algorithmic_gflop": round(GFLOP_3X3_PER_IMAGE * B, 2)},
+          "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all, 2), "all_kernels_ms": round(t_all, 4),
+          "kernel_groups": {k: {kk: vv for kk, vv in v.items() if kk != "gflop"} for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
+          "glue_ms": round(glue_ms, 4)}
+    return rf, dom_name
+
+
+def attach_traffic(rf, dom_name, B, dtype):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py; separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs as MI355X_MICROARCH.md prescribes).  The figure is only reported while the kernel sources
+    still hash to what the passes were taken on; otherwise null."""
+    from blindshadowremoval_amd.build import source_sha16
+    sha = source_sha16()
+    for tag in ("r2", "r1"):
+        tpath = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")
+        if not os.path.isfile(tpath):
+            continue
+        with open(tpath) as ft:
+            t = json.load(ft)
+        if B == t.get("batch") and dtype == "f32" and t.get("kernel_src_sha16") == sha and t.get("dominant_kernel", dom_name) == dom_name:
+            rf["traffic"] = t.get("dominant_kernel_hbm_bytes_per_launch")
+            rf["traffic_note"] = ("HBM bytes per launch of the same kernel (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/%s_pmc_traffic.csv, "
+                                  "taken on kernel sources %s = this build); algorithmic activation bytes per launch: %s" % (tag, sha, t.get("dominant_kernel_algorithmic_bytes_per_launch")))
+            return
+        rf["traffic_note"] = ("profiles/%s_pmc_traffic.json was measured on kernel sources %s / batch %s, this build is %s / batch %d: not reported"
+                              % (tag, t.get("kernel_src_sha16"), t.get("batch"), sha, B))
+        return
+
+
+# ----------------------------------------------------------------------------------------------- one rank
+def run_rank(args):
     import torch
     import torch.distributed as dist
-    from blindshadowremoval_amd import Generator, init_weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    distributed = world > 1 or os.environ.get("BSR_BENCH_FORCE_DIST") == "1"      # the latter exercises the RCCL path on one GPU
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    on_gpu = not args.stub
+    distributed = world > 1 or os.environ.get("BSR_BENCH_FORCE_DIST") == "1"      # the latter exercises the collective path on one rank
+    if on_gpu:
+        if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no GPU %d (visible: %d)" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     B = args.batch
-    weights = init_weights(1)
-    gen = Generator(device=local_rank, dtype=args.dtype).load_weights(weights)
+    tsm = args.workload == "tsm512"
+    HW = 512 if tsm else 256
+    weights = None
+    if args.stub:
+        gen = _StubGenerator()
+    else:
+        from blindshadowremoval_amd import Generator, GeneratorTSM, init_weights
+        weights = init_weights(1, variant="tsm" if tsm else "gsc")
+        gen = (GeneratorTSM if tsm else Generator)(device=local_rank, dtype=args.dtype).load_weights(weights)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    inp = torch.rand(B, 256, 256, 3, generator=g).to(dev)       # synthetic, resident in HBM before timing
-    uv = torch.rand(B, 256, 256, 3, generator=g).to(dev)
-    outs = [tuple(torch.empty((B, 256, 256, c), device=dev) for c in (1, 3, 3, 1)) for _ in range(2)]
-    packed = [torch.empty((B, 256, 256, 4), device=dev) for _ in range(2)]          # con_rgb | dif: what callers consume
-    gathered = [torch.empty((world * B, 256, 256, 4), device=dev) for _ in range(2)] if distributed else None
+    inp = torch.rand(B, HW, HW, 3, generator=g).to(dev)       # synthetic, resident in HBM before timing
+    uv = torch.rand(B, HW, HW, 3, generator=g).to(dev)
+    reg = ((torch.rand(B, HW, HW, 6, generator=g) - 0.5) * 0.2).to(dev) if tsm else None
+    outs = [tuple(torch.empty((B, HW, HW, c), device=dev) for c in (1, 3, 3, 1)) for _ in range(2)]
+    packed = [torch.empty((B, HW, HW, 4), device=dev) for _ in range(2)]          # con_rgb | dif: what callers consume
+    gathered = [torch.empty((world * B, HW, HW, 4), device=dev) for _ in range(2)] if distributed else None
     pending = [None, None]
 
-    def step(i):
+    def forward(slot):
+        if tsm:
+            return gen(inp, uv, reg, 2, True)           # frame = 2 (image + mirror pairs, train_with_TSM.py:676)
+        return gen(inp, uv, out=outs[slot])
+
+    def step(i, gather=True):
         slot = i & 1
         if pending[slot] is not None:           # buffers of step i-2 are free once its gather completed
             pending[slot].wait()
             pending[slot] = None
-        o = gen(inp, uv, out=outs[slot])
-        if distributed and not args.no_gather:
+        o = forward(slot)
+        if distributed and gather and not args.no_gather:
             torch.cat((o[1], o[3]), dim=3, out=packed[slot])
             pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
 
@@ -130,89 +355,136 @@ def main():
                 pending[s].wait()
                 pending[s] = None
 
+    def timed(nsteps, fn):
+        """barrier + synchronize on both sides, MAX over ranks (the contract's timed region)"""
+        if distributed:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            fn(i)
+        drain()
+        sync()
+        if distributed:
+            dist.barrier()
+        sync()
+        own = time.perf_counter() - t0
+        mx = own
+        if distributed:
+            t = torch.tensor([own], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mx = float(t.item())
+        return mx, own
+
     for i in range(args.warmup):
         step(i)
     drain()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, own = timed(args.steps, step)                  # THE timed region: exactly K steps
+    reps = [elapsed] + [timed(args.steps, step)[0] for _ in range(max(0, args.repeats - 1))]
+    extra = {}
+    if distributed and not args.no_gather:
+        t_nog, _ = timed(args.steps, lambda i: step(i, gather=False))
+
+        def gather_only(i):
+            slot = i & 1
+            if pending[slot] is not None:
+                pending[slot].wait()
+            pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
+        t_g, _ = timed(args.steps, gather_only)
+        owns = [None] * world
+        dist.all_gather_object(owns, own)
+        extra = {"allgather": {"bytes_per_rank": packed[0].numel() * 4, "ms_alone": round(t_g / args.steps * 1e3, 4),
+                               "ms_per_step_without_gather": round(t_nog / args.steps * 1e3, 4),
+                               "ms_exposed_per_step": round((elapsed - t_nog) / args.steps * 1e3, 4)},
+                 "per_rank_images_per_sec": [round(B * args.steps / o, 2) for o in owns]}
 
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        # roofline of the dominant kernel (igemm_conv_kernel on the 3x3 / transposed-3x3 layers): HIP events around
-        # every launch of a few extra forwards on the same stream (event overhead stays out of `value`)
-        gen.set_timing(True)
-        acc, n_rep = {}, 3
-        for _ in range(n_rep):
-            gen(inp, uv, out=outs[0])
-            torch.cuda.synchronize()
-            for k, (ms, n) in gen.get_timing().items():
-                a = acc.setdefault(k, [0.0, 0])
-                a[0] += ms / n_rep
-                a[1] = n
-        gen.set_timing(False)
-        t33 = (acc["conv3x3"][0] + acc["convT3x3"][0] + acc["convT3x3_ni2"][0]) * 1e-3
-        n33 = acc["conv3x3"][1] + acc["convT3x3"][1] + acc["convT3x3_ni2"][1]
-        path_tflops = GFLOP_3X3_PER_IMAGE * B / t33 / 1e3         # the whole 3x3-conv path
-        # the dominant kernel: igemm_conv_kernel<3,3,1,true,4,32,4,1,1,2,32,1> = up2, up3, clr_up3 (SURVEY Appendix C MMACs)
-        dom_gflop = 2e-3 * (377.49 + 1207.96 + 905.97) * B       # algorithmic GFLOP of its 3 launches
-        t_dom, n_dom = acc["convT3x3_ni2"][0] * 1e-3, acc["convT3x3_ni2"][1]
-        achieved = dom_gflop / t_dom / 1e3                        # TFLOP/s
-        t_all = sum(v[0] for v in acc.values()) * 1e-3
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_F16_MFMA_TFLOPS
-        traffic = None          # HBM bytes of the same launches, from the committed PMC passes (tools/pmc_traffic.py)
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.isfile(tpath) and B == 32 and args.dtype == "f32":
-            with open(tpath) as ft:
-                traffic = json.load(ft).get("dominant_kernel_hbm_bytes_per_launch")
+        rs = sorted(r / args.steps * 1e3 for r in reps)
+        cfg = {"workload": None, "images_per_gpu_per_step": B, "global_batch": world * B, "height": HW, "width": HW,
+               "parallelism": "dp%d" % world,
+               "collective": ("all_gather(con_rgb|dif) per step, async, double-buffered" if distributed and not args.no_gather else "none")}
+        if tsm:
+            cfg["workload"] = ("BASELINE configs[4] per-rank shape: TSM generator (model_with_TSM.py), %d frames of 512x512 per GPU per step, "
+                               "frame=2 groups, seeded random-init weights in the ckpt-110 variable layout" % B)
+        elif args.dtype == "f32":
+            cfg["workload"] = ("BASELINE configs[1]: batch=32 synthetic 256x256x3 per GPU, full GSC generator fp32 "
+                               "(seeded random-init weights in the ckpt-94 variable layout)")
+        else:
+            cfg["workload"] = ("BASELINE configs[3]: batch=32 synthetic 256x256x3 per GPU, fp16 MFMA (fp32 accumulate/storage) on the "
+                               "3x3-conv path, fp32 elsewhere; NOT the headline configuration")
+        cfg.update(extra)
         result = {
-            "metric": "images/sec at 256x256 batch inference (GSC generator forward)",
+            "metric": "images/sec at 256x256 batch inference (GSC generator forward)" if not tsm else "images/sec at 512x512 (TSM generator forward)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: batch=32 synthetic 256x256x3 per GPU, full GSC generator fp32 "
-                                    "(seeded random-init weights in the ckpt-94 variable layout)" if args.dtype == "f32" else
-                                    "BASELINE configs[3]: batch=32 synthetic 256x256x3 per GPU, fp16 MFMA (fp32 accumulate/storage) on the "
-                                    "3x3-conv path, fp32 elsewhere; NOT the headline configuration"),
-                       "images_per_gpu_per_step": B, "global_batch": world * B, "height": 256, "width": 256,
-                       "parallelism": "dp%d" % world,
-                       "collective": ("all_gather(con_rgb|dif) per step, async" if distributed and not args.no_gather else "none")},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch of the same kernel (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r1_pmc_traffic.csv); "
-                                         "algorithmic activation bytes of its launches (input read once, output written once): 5.87e8 per launch on average",
-                         "kernel": "igemm_conv_kernel<3,3,1,true,4,32,4,1,1,2,32,1> (transposed 3x3: up2, up3, clr_up3) — the largest single kernel, 24 % of the forward",
-                         "launches_per_forward": n_dom, "avg_launch_ms": round(t_dom * 1e3 / n_dom, 4),
-                         "algorithmic_gflop_per_launch": round(dom_gflop / n_dom, 2),
-                         "path_3x3": {"achieved": round(path_tflops, 2), "frac": round(path_tflops / peak, 4), "launches": n33,
-                                      "ms": round(t33 * 1e3, 4), "algorithmic_gflop": round(GFLOP_3X3_PER_IMAGE * B, 2)},
-                         "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all / 1e3, 2),
-                         "class_ms": {k: round(v[0], 4) for k, v in acc.items()}},
+            "dtype": args.dtype, "data": "synthetic", "config": cfg,
+            "repeats": {"n": len(rs), "ms_per_step_min": round(rs[0], 4), "ms_per_step_median": round(rs[len(rs) // 2], 4),
+                        "ms_per_step_all": [round(r, 4) for r in rs], "note": "`value` is the FIRST timed region of exactly K steps; the others repeat it"},
         }
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(weights, gen=gen, device=dev)
-        else:
+        if args.stub:
+            result["stub"] = True
+            result["roofline"] = None
             result["cpu_baseline"] = None
+        else:
+            if tsm:
+                result["roofline"] = None
+            else:
+                rf, dom_name = roofline_from_events(gen, lambda: forward(0), B, args.dtype)
+                attach_traffic(rf, dom_name, B, args.dtype)
+                result["roofline"] = rf
+            if not args.no_cpu_baseline and world == 1 and not tsm:
+                result["cpu_baseline"] = cpu_baseline(weights, gen=gen, device=dev)
+            else:
+                result["cpu_baseline"] = None
+            if args.loop and world == 1:
+                from blindshadowremoval_amd.loop_bench import loop_bench
+                result["loop"] = loop_bench(args.loop, gen)
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 8 for --workload tsm512)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each; `value` comes from the first")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+                    help="f32 = the measured path (BASELINE configs[1]); f16 = opt-in fp16 MFMA on the 3x3-conv path (configs[3])")
+    ap.add_argument("--workload", choices=("gsc256", "tsm512"), default="gsc256",
+                    help="gsc256 = BASELINE configs[1]/[3]; tsm512 = the per-rank shape of configs[4] (TSM generator, 512x512 frames)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the output all-gather (N>1)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo only with --stub (CPU test of the rank logic)")
+    ap.add_argument("--stub", action="store_true", help="CPU stand-in generator: tests the launcher / sharding / JSON contract, measures nothing")
+    ap.add_argument("--loop", choices=("ffhq", "ucb"), default=None,
+                    help="also time the end-to-end FSRNet.testFFHQ / FSRNet.test loop (host prep + H2D + forward + post + PNG) on the shipped fixtures")
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = 8 if args.workload == "tsm512" else 32
+    if args.backend == "gloo" and not args.stub:
+        ap.error("--backend gloo needs --stub: the product path has no CPU fallback")
+    if args.stub and args.backend != "gloo":
+        ap.error("--stub runs on CPU: pass --backend gloo")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher: nothing in this process has touched (or will touch) the GPU
+        sys.exit(launch_ranks(args.gpus, argv, check_devices=not args.stub))
+    return run_rank(args)
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ from typing import Optional
 
 from .build import LIB_PATH
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_CLASSES = 7
 CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue", "convT3x3_ni2")
 
@@ -16,7 +16,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_debug_attention", "bsr_destroy", "bsr_last_error", "bsr_abi_version")
+           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_destroy", "bsr_last_error", "bsr_abi_version")
 
 
 def load() -> ctypes.CDLL:
@@ -51,6 +51,12 @@ def load() -> ctypes.CDLL:
     lib.bsr_set_timing.restype = c_i
     lib.bsr_get_timing.argtypes = [c_v, ctypes.POINTER(ctypes.c_float * NUM_CLASSES), ctypes.POINTER(c_i * NUM_CLASSES)]
     lib.bsr_get_timing.restype = c_i
+    lib.bsr_timing_launches.argtypes = [c_v]
+    lib.bsr_timing_launches.restype = c_i
+    lib.bsr_timing_entry.argtypes = [c_v, c_i, ctypes.c_char_p, c_sz, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_i)]
+    lib.bsr_timing_entry.restype = c_i
+    lib.bsr_handle_workspace_bytes.argtypes = [c_v, c_i, c_i, c_i]
+    lib.bsr_handle_workspace_bytes.restype = c_sz
     lib.bsr_debug_attention.argtypes = [c_v, c_v, c_i, c_i, c_v]
     lib.bsr_debug_attention.restype = c_i
     lib.bsr_destroy.argtypes = [c_v]

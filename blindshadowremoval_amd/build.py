@@ -8,7 +8,23 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbsr_hip.so")
 SOURCES = ["csrc/bsr_api.hip"]
-HEADERS = ["csrc/igemm_conv.h", "csrc/attention.h", "csrc/glue_kernels.h", "../include/bsr_hip.h"]
+
+
+def _deps():
+    """Everything the library is compiled from: every kernel header under csrc/ plus the public C header."""
+    import glob
+    return (sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.h"))) + sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip")))
+            + [os.path.join(PKG_DIR, "..", "include", "bsr_hip.h")])
+
+
+def source_sha16() -> str:
+    """Hash of the kernel sources: profiles/*_pmc_traffic.json records it so bench.py can tell a stale traffic figure."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _deps():
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def _hipcc() -> str:
@@ -22,7 +38,7 @@ def is_stale() -> bool:
     if not os.path.isfile(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(PKG_DIR, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in _deps())
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:

@@ -162,12 +162,13 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float*
 }
 
 inline hipError_t launch_nonlocal_attention(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (dev < 0 || !once.done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nonlocal_attention_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kAttSmemBytes);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0) once.done[dev] = true;
   }
   hipLaunchKernelGGL(nonlocal_attention_kernel, dim3(batch * (tokens / 128)), dim3(256), kAttSmemBytes, stream, qkv, out, tokens);
   return hipGetLastError();

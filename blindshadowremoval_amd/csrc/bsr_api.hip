@@ -35,6 +35,19 @@ int fail(int code, const std::string& msg) {
       return fail(BSR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                \
   } while (0)
 
+// Every entry point runs on the handle's device and puts the caller's current device back on return.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) err = hipSetDevice(device);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 // ---- packed-weight blob (written by blindshadowremoval_amd/pack.py) ----
 constexpr uint32_t kBlobMagic = 0x57525342u;  // "BSRW"
 constexpr uint32_t kBlobVersion = 1;
@@ -128,6 +141,7 @@ struct bsr_handle {
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
   std::vector<int> ev_class;
+  std::vector<std::string> ev_name;   // layer name of each event pair ("up3", "res2.conv2", "attention4", ...)
   size_t ev_used = 0;
 };
 
@@ -152,7 +166,7 @@ struct Launcher {
   hipStream_t s;
   int rc = BSR_OK;
 
-  void begin(int cls) {
+  void begin(int cls, const char* name) {
     if (!h->timing) return;
     if (h->ev_used + 2 > h->ev.size()) {
       for (int i = 0; i < 2; ++i) {
@@ -161,8 +175,10 @@ struct Launcher {
         h->ev.push_back(e);
       }
       h->ev_class.push_back(cls);
+      h->ev_name.emplace_back();
     }
     h->ev_class[h->ev_used / 2] = cls;
+    h->ev_name[h->ev_used / 2] = name;
     hipEventRecord(h->ev[h->ev_used], s);
   }
   void end() {
@@ -203,7 +219,7 @@ struct Launcher {
       rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': feature map is not a multiple of the 4x32 tile");
       return;
     }
-    begin(cls);
+    begin(cls, name);
     if (h->f16 && (KH == 3 && KW == 3))
       check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB, (KH == 3 && KW == 3)>(a, h->B, s), name);
     else
@@ -228,7 +244,7 @@ struct Launcher {
     a.w = l.w; a.bias = l.b; a.nchunk = l.nchunk; a.n_pad = l.n_pad; a.n_store = n_store; a.act = act;
     a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c;
     a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
-    begin(cls);
+    begin(cls, name);
     check(bsr::launch_gemm_nloop<NI, NCH>(a, pixels, kNSplit, s), name);
     end();
   }
@@ -246,7 +262,7 @@ struct Launcher {
     a.pad_t = (KH - 1) / 2; a.pad_l = (KW - 1) / 2;
     a.gs = gs; a.w_gs = h->clr_gs_w; a.tail_w = h->tail_w; a.inputs = inputs; a.con_rgb = con_rgb; a.dif = dif;
     if (H % (4 * RW) != 0 || W % 32 != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': image is not a multiple of its tile"); return; }
-    begin(cls);
+    begin(cls, name);
     check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW>(a, h->B, s), name);
     end();
   }
@@ -254,6 +270,7 @@ struct Launcher {
 
 int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
   Plan p = make_plan(B, H, W, h->var);
+  bool fresh = false;
   if (p.total > h->ws_floats) {
     HIP_TRY(hipStreamSynchronize(s));
     if (h->ws) HIP_TRY(hipFree(h->ws));
@@ -261,11 +278,22 @@ int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
     h->ws_floats = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ws), p.total * sizeof(float)));
     h->ws_floats = p.total;
-    h->B = 0;  // force re-zero below
+    h->B = 0;
+    fresh = true;
   }
-  if (B != h->B || H != h->H || W != h->W) {
-    // channel-pad lanes of the concat buffers must read as 0: clear once per shape
+  if (fresh) {
+    // a new allocation holds arbitrary bits (NaN x zero weight = NaN): clear all of it once
     HIP_TRY(hipMemsetAsync(h->ws, 0, p.total * sizeof(float), s));
+    h->ran = false;
+  } else if (B != h->B || H != h->H || W != h->W) {
+    // A new shape moves every buffer.  All of them are fully rewritten by their producers each forward except the channel-pad
+    // lanes of the 1/8-resolution concat buffers (xa, xh, r0..r5: real channels < stride), which must read as exact zeros:
+    // clear just those (a few MB per image instead of the whole workspace).
+    const size_t cells = (size_t)B * H * W / 64;
+    const Variant& v = h->var;
+    HIP_TRY(hipMemsetAsync(h->ws + p.xa, 0, cells * v.cs_a * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(h->ws + p.xh, 0, cells * v.cs_h * sizeof(float), s));
+    for (int i = 0; i < 6; ++i) HIP_TRY(hipMemsetAsync(h->ws + p.r[i], 0, cells * (i < 3 ? v.cs_r : v.cs_h) * sizeof(float), s));
     h->ran = false;
   }
   h->plan = p;
@@ -277,7 +305,7 @@ int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
 
 extern "C" {
 
-int bsr_abi_version(void) { return 1; }
+int bsr_abi_version(void) { return 2; }
 
 const char* bsr_last_error(void) { return g_last_error.c_str(); }
 
@@ -297,7 +325,8 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   if (hd.magic != kBlobMagic || hd.version != kBlobVersion) return fail(BSR_ERR_BLOB, "bsr_create: bad blob magic/version");
   const size_t table_end = sizeof(BlobHeader) + (size_t)hd.n_entries * sizeof(BlobEntry);
   if (table_end > nbytes) return fail(BSR_ERR_BLOB, "bsr_create: blob entry table exceeds blob size");
-  HIP_TRY(hipSetDevice(device));
+  DeviceGuard guard(device);
+  HIP_TRY(guard.err);
   bsr_handle* h = new bsr_handle();
   h->device = device;
   h->f16 = dtype == BSR_DTYPE_F16;
@@ -351,7 +380,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
 
 void bsr_destroy(bsr_handle* h) {
   if (h == nullptr) return;
-  hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   if (h->ws) hipFree(h->ws);
   if (h->d_blob) hipFree(h->d_blob);
@@ -360,7 +389,8 @@ void bsr_destroy(bsr_handle* h) {
 
 int bsr_reserve(bsr_handle* h, int B, int H, int W) {
   if (h == nullptr || B <= 0 || H <= 0 || W <= 0) return fail(BSR_ERR_ARG, "bsr_reserve: bad argument");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard(h->device);
+  HIP_TRY(guard.err);
   Plan p = make_plan(B, H, W, h->var);
   if (p.total > h->ws_floats) {
     HIP_TRY(hipDeviceSynchronize());
@@ -368,8 +398,10 @@ int bsr_reserve(bsr_handle* h, int B, int H, int W) {
     h->ws = nullptr;
     h->ws_floats = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ws), p.total * sizeof(float)));
+    HIP_TRY(hipMemset(h->ws, 0, p.total * sizeof(float)));
     h->ws_floats = p.total;
     h->B = 0;
+    h->ran = false;
   }
   return BSR_OK;
 }
@@ -395,6 +427,23 @@ int bsr_get_timing(bsr_handle* h, float ms[BSR_NUM_CLASSES], int launches[BSR_NU
   return BSR_OK;
 }
 
+int bsr_timing_launches(bsr_handle* h) { return h == nullptr ? 0 : (int)(h->ev_used / 2); }
+
+int bsr_timing_entry(bsr_handle* h, int i, char* name, size_t name_cap, float* ms, int* cls) {
+  if (h == nullptr || name == nullptr || ms == nullptr || cls == nullptr || name_cap == 0) return fail(BSR_ERR_ARG, "bsr_timing_entry: null argument");
+  if (i < 0 || (size_t)(2 * i + 1) >= h->ev_used) return fail(BSR_ERR_ARG, "bsr_timing_entry: index out of range");
+  HIP_TRY(hipEventSynchronize(h->ev[2 * i + 1]));
+  HIP_TRY(hipEventElapsedTime(ms, h->ev[2 * i], h->ev[2 * i + 1]));
+  *cls = h->ev_class[i];
+  snprintf(name, name_cap, "%s", h->ev_name[i].c_str());
+  return BSR_OK;
+}
+
+size_t bsr_handle_workspace_bytes(const bsr_handle* h, int B, int H, int W) {
+  if (h == nullptr || B <= 0 || H <= 0 || W <= 0) return 0;
+  return make_plan(B, H, W, h->var).total * sizeof(float);
+}
+
 static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, const float* reg, int frame, int share, int B, int H, int W,
                         float* gs, float* con_rgb, float* mask22, float* dif, void* stream) {
   if (h == nullptr || inputs == nullptr || uv == nullptr || gs == nullptr || con_rgb == nullptr || mask22 == nullptr || dif == nullptr)
@@ -408,7 +457,8 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   if (H <= 0 || W <= 0 || H % 32 != 0 || W % 256 != 0)
     return fail(BSR_ERR_ARG, "bsr_forward: H must be a multiple of 32 and W a multiple of 256 (reference: 256x256)");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard(h->device);
+  HIP_TRY(guard.err);
   int rc = ensure_workspace(h, B, H, W, s);
   if (rc != BSR_OK) return rc;
   h->ev_used = 0;
@@ -417,7 +467,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   const size_t npix = (size_t)B * H * W, ncell = npix / 64;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
   Launcher L{h, s};
-  auto glue_begin = [&]() { L.begin(K_GLUE); };
+  auto glue_begin = [&](const char* what) { L.begin(K_GLUE, what); };
   auto glue_end = [&](const char* what) { L.check(hipGetLastError(), what); L.end(); };
 
   // conv1 = Conv(32, 7x7) + BN + LeakyReLU (model.py:203,230): dedicated stem kernel (7 row taps x 21 contiguous floats)
@@ -426,7 +476,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     L.rc = find_layer(h, "conv1", 1, 7, 28, 32, &l);
     if (L.rc == BSR_OK) {
       bsr::StemArgs a{inputs, ws + p.x1, l.w, l.b, H, W, 0, 0};
-      L.begin(K_CONV7);
+      L.begin(K_CONV7, "conv1");
       L.check(bsr::launch_stem7<4>(a, B, s), "conv1");
       L.end();
     }
@@ -436,20 +486,20 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down2", ws + p.c3, 128, 64, 64, H2, W2, ws + p.c2, 160, 96, 64, 1);
   L.conv<3, 3, 2, false, 3, 16, 1>(K_CONV3, "down3", ws + p.c2, 160, 96, 64, H4, W4, ws + p.xa, V.cs_a, 0, 96, 1);
   // uv = resize(uv, [h,w]); x = cat[x, uv] (model.py:237-238) and the uv slot of cat[x_hole, bmask, uv] (model.py:259)
-  glue_begin();
+  glue_begin("uv_resize8");
   hipLaunchKernelGGL(bsr::uv_resize8_kernel, dim3((unsigned)((ncell * 3 + 255) / 256)), dim3(256), 0, s, uv, H, W, ws + p.xa, V.cs_a, V.uv_a,
                      ws + p.xh, V.cs_h, V.uv_h, ncell);
   glue_end("uv_resize8");
 
   // TSM: x_share = ShareLayer(x, reg, frame, share) into channels [96, 288) of xa (model_with_TSM.py:271-272)
   auto share_layer = [&](const float* x, int x_cs, int C, float* out, int out_cs, int out_coff) {
-    glue_begin();
+    glue_begin("share_layer");
     if (share) hipLaunchKernelGGL(bsr::share_reduce_kernel, dim3((unsigned)(ncell / frame)), dim3(128), 0, s, x, x_cs, C, ws + p.reg32, H8, frame, ws + p.share);
     hipLaunchKernelGGL(bsr::share_unwarp_kernel, dim3((unsigned)ncell), dim3(128), 0, s, ws + p.share, x, x_cs, C, ws + p.reg32, H8, frame, share, out, out_cs, out_coff);
     glue_end("share_layer");
   };
   if (V.tsm) {
-    glue_begin();
+    glue_begin("reg_resize8");
     hipLaunchKernelGGL(bsr::reg_resize8_kernel, dim3((unsigned)((ncell * 4 + 255) / 256)), dim3(256), 0, s, reg, H, W, ws + p.reg32, ncell);
     glue_end("reg_resize8");
     share_layer(ws + p.xa, V.cs_a, 96, ws + p.xa, V.cs_a, 96);
@@ -471,7 +521,8 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     // The y3 output also absorbs the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
     L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
     if (L.rc == BSR_OK) {
-      L.begin(K_ATT);
+      snprintf(nm, sizeof nm, "res%d.attention", i);
+      L.begin(K_ATT, nm);
       L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
       L.end();
     }
@@ -479,7 +530,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     snprintf(nm, sizeof nm, "res%d.w", i);
     L.gemm<3, 4>(K_CONV1, nm, ws + p.att[i], 128, ncell, r_out, o_cs, o_cs < 288 ? o_cs : 288, 1, y3, CS_Y3X, CS_Y3X);
     if (x_c > 288 && L.rc == BSR_OK) {      // the block output keeps the wider of x / y (model.py:105-113): channels the GEMM does not cover
-      glue_begin();
+      glue_begin("lrelu_copy");
       hipLaunchKernelGGL(bsr::lrelu_copy_kernel, dim3((unsigned)((ncell * (x_c - 288) + 255) / 256)), dim3(256), 0, s, x, x_cs, r_out, o_cs, 288, x_c, ncell);
       glue_end("lrelu_copy");
     }
@@ -495,12 +546,12 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
   // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
   L.conv16<7, 1, false, false, 2>(K_CONV7, "heads", ws + p.ybuf, 64, H, W, ws + p.qh, 16, 0, nullptr, nullptr, nullptr, nullptr);
-  glue_begin();
+  glue_begin("heads_post");
   hipLaunchKernelGGL(bsr::heads_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.qh, inputs, h->head_bias[0],
                      h->head_bias[1], gs, mask22, W, npix);
   glue_end("heads_post");
   // bmask / x_hole (model.py:256-259)
-  glue_begin();
+  glue_begin("bmask_xhole");
   hipLaunchKernelGGL(bsr::bmask_xhole_kernel, dim3((unsigned)ncell), dim3(64), 0, s, gs, inputs, H, W, ws + p.r[2], V.cs_r, V.c_r, ws + p.xh,
                      V.cs_h, ws + p.probe);
   glue_end("bmask_xhole");
@@ -541,7 +592,8 @@ int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* str
 int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream) {
   if (h == nullptr || name == nullptr || dst == nullptr || shape4 == nullptr) return fail(BSR_ERR_ARG, "bsr_probe: null argument");
   if (!h->ran) return fail(BSR_ERR_STATE, "bsr_probe: no forward has run on this handle");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard(h->device);
+  HIP_TRY(guard.err);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Plan& p = h->plan;
   const int B = h->B, H = h->H, W = h->W;

@@ -333,19 +333,20 @@ template <int KH, int KW, bool GS, bool TAIL, int RW>
 inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream) {
   using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
   auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW>;
-  static bool attr_set = false;
-  static int resident = 0;                 // workgroups the device holds at once (2 per CU: LDS-bound)
-  if (!attr_set) {
+  static PerDeviceOnce once;               // .value = workgroups the device holds at once (2 per CU: LDS-bound)
+  const int dev = PerDeviceOnce::current();
+  int resident = dev >= 0 && once.done[dev] ? once.value[dev] : 0;
+  if (resident == 0) {
     if (C::SMEM_BYTES > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
       if (e != hipSuccess) return e;
     }
-    int dev = 0, cus = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int cur = 0, cus = 0;
+    hipError_t e = hipGetDevice(&cur);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur);
     if (e != hipSuccess) return e;
     resident = 2 * cus;
-    attr_set = true;
+    if (dev >= 0) { once.value[dev] = resident; once.done[dev] = true; }
   }
   a.tiles_x = a.W / C::TW;
   a.tiles_y = a.H / C::TH;

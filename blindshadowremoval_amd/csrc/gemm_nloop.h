@@ -216,11 +216,12 @@ template <int NI, int NCH>
 inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, int nsplit, hipStream_t stream) {
   using C = GemmNLoopCfg<NI, NCH>;
   auto kern = gemm_nloop_kernel<NI, NCH>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (dev < 0 || !once.done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0) once.done[dev] = true;
   }
   const int tiles_total = (a.n_store + 31) / 32;
   a.tiles_x = (tiles_total + nsplit - 1) / nsplit;            // tiles per blockIdx.y range

@@ -50,6 +50,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);   // raw, stride 0, 2 GiB window
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are PER DEVICE: launchers keep their one-time state per
+// device ordinal, so one process may hold handles on several GPUs (the deployment rule stays one process per GPU).
+constexpr int kMaxDevices = 64;
+struct PerDeviceOnce {
+  bool done[kMaxDevices] = {};
+  int value[kMaxDevices] = {};
+  // returns the current device ordinal, or -1 (never cached) when it is out of range / unknown
+  static int current() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return -1;
+    return d;
+  }
+};
+
 struct ConvArgs {
   const float* in;      // NHWC activations, channel stride in_cs, first channel in_coff
   int in_cs, in_coff;
@@ -407,11 +421,12 @@ template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI
 inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
   auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, F16>;
-  static bool attr_set = false;
-  if (!attr_set && C::SMEM_BYTES > 48 * 1024) {
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (C::SMEM_BYTES > 48 * 1024 && (dev < 0 || !once.done[dev])) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0) once.done[dev] = true;
   }
   const int mh = TR ? a.H : a.Ho, mw = TR ? a.W : a.Wo;   // the M grid: input pixels for transposed, output pixels otherwise
   a.tiles_x = mw / TW;

@@ -47,7 +47,9 @@ class Generator:
         blob = pack_generator(weights)
         handle = ctypes.c_void_p()
         buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
-        _lib.check(lib.bsr_create(ctypes.byref(handle), dev, ctypes.cast(buf, ctypes.c_void_p), len(blob), 1 if self.dtype == "f16" else 0), "bsr_create")
+        with torch.cuda.device(dev):
+            rc = lib.bsr_create(ctypes.byref(handle), dev, ctypes.cast(buf, ctypes.c_void_p), len(blob), 1 if self.dtype == "f16" else 0)
+        _lib.check(rc, "bsr_create")
         self.close()
         self._lib, self._handle, self._device = lib, handle, dev
         return self
@@ -84,6 +86,22 @@ class Generator:
             t = t.to("cuda:%d" % dev)
         return t.contiguous()
 
+    @staticmethod
+    def _check_out(out, B: int, H: int, W: int, dev: int):
+        """Caller-supplied output buffers go to the library as raw pointers: refuse anything it would write out of bounds."""
+        if not isinstance(out, (tuple, list)) or len(out) != 4:
+            raise ValueError("out must be a tuple (gs, con_rgb, mask22, dif)")
+        for t, c, name in zip(out, (1, 3, 3, 1), ("gs", "con_rgb", "mask22", "dif")):
+            if not isinstance(t, torch.Tensor) or tuple(t.shape) != (B, H, W, c):
+                raise ValueError("out[%s] must be a tensor of shape %s, got %s" % (name, (B, H, W, c), tuple(getattr(t, "shape", ()))))
+            if t.dtype != torch.float32:
+                raise TypeError("out[%s] must be float32, got %s" % (name, t.dtype))
+            if t.device.type != "cuda" or t.device.index != dev:
+                raise ValueError("out[%s] must live on cuda:%d, got %s" % (name, dev, t.device))
+            if not t.is_contiguous():
+                raise ValueError("out[%s] must be contiguous (dense NHWC)" % name)
+        return tuple(out)
+
     def __call__(self, inputs, uv, reg=None, chuck: int = 1, training: bool = False,
                  out: Optional[Tuple[torch.Tensor, ...]] = None):
         if training:
@@ -106,7 +124,7 @@ class Generator:
                 mask22 = torch.empty((B, H, W, 3), dtype=torch.float32, device=inputs.device)
                 dif = torch.empty((B, H, W, 1), dtype=torch.float32, device=inputs.device)
             else:
-                gs, con_rgb, mask22, dif = out
+                gs, con_rgb, mask22, dif = self._check_out(out, B, H, W, dev)
             stream = torch.cuda.current_stream().cuda_stream
             rc = self._lib.bsr_forward(self._handle, inputs.data_ptr(), uv.data_ptr(), B, H, W, gs.data_ptr(), con_rgb.data_ptr(),
                                        mask22.data_ptr(), dif.data_ptr(), stream)
@@ -173,6 +191,17 @@ class Generator:
         n = (ctypes.c_int * _lib.NUM_CLASSES)()
         _lib.check(self._lib.bsr_get_timing(self._handle, ctypes.byref(ms), ctypes.byref(n)), "bsr_get_timing")
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.CLASS_NAMES)}
+
+
+    def get_launch_timing(self):
+        """[(layer name, ms, class name)] of the last timed forward, in launch order (bsr_timing_entry)."""
+        out = []
+        name = ctypes.create_string_buffer(64)
+        ms, cls = ctypes.c_float(), ctypes.c_int()
+        for i in range(self._lib.bsr_timing_launches(self._handle)):
+            _lib.check(self._lib.bsr_timing_entry(self._handle, i, name, 64, ctypes.byref(ms), ctypes.byref(cls)), "bsr_timing_entry")
+            out.append((name.value.decode(), float(ms.value), _lib.CLASS_NAMES[cls.value]))
+        return out
 
 
 class GeneratorTSM(Generator):

@@ -9,7 +9,9 @@
  * caller (NHWC float32, dense); the library owns only its packed weights and its activation workspace.
  *
  * Threading: a handle is bound to one device and is not re-entrant; bsr_forward is asynchronous on the
- * given hipStream_t and the caller synchronises.  Multi-GPU = one handle per device (one process per GPU).
+ * given hipStream_t and the caller synchronises.  Multi-GPU = one handle per device (deployment: one process per GPU;
+ * one process may also hold handles on several devices — per-device launch state is kept per device ordinal).  Every
+ * entry point switches to the handle's device and restores the caller's current device before returning.
  * Every function returns 0 on success or a non-zero code; bsr_last_error() describes the last failure
  * of the calling thread.
  */
@@ -59,12 +61,13 @@ int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const f
 
 /* Bytes of activation workspace the library holds for a batch of B HxW images (grown lazily by
  * bsr_forward; growth synchronises the stream — call bsr_reserve first to keep forwards allocation-free). */
-size_t bsr_workspace_bytes(int B, int H, int W);
+size_t bsr_workspace_bytes(int B, int H, int W);                              /* GSC channel plan */
+size_t bsr_handle_workspace_bytes(const bsr_handle* h, int B, int H, int W);  /* the plan of THIS handle's variant (GSC or the wider TSM one) */
 int bsr_reserve(bsr_handle* h, int B, int H, int W);
 
 /* Test hook: copy a named intermediate of the LAST forward (dense NHWC, real channel count) into dst
  * (device pointer, capacity cap_floats).  shape4 receives [B,H,W,C].  Names: x1 x2 x3 x0 res0..res5 up1 up2
- * y d32 bmask xh f1 f2 f att<i> y3_<i>.  shape4 is filled even when cap_floats is too small (BSR_ERR_ARG), so a caller can
+ * y d32 bmask xh f1 f2 f att<i> y3x<i>.  shape4 is filled even when cap_floats is too small (BSR_ERR_ARG), so a caller can
  * size its buffer with a first call of capacity 0. */
 int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream);
 
@@ -76,6 +79,11 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
 #define BSR_NUM_CLASSES 7
 int bsr_set_timing(bsr_handle* h, int enable);
 int bsr_get_timing(bsr_handle* h, float ms_per_class[BSR_NUM_CLASSES], int launches_per_class[BSR_NUM_CLASSES]);
+/* The same events, launch by launch in issue order: bsr_timing_launches() entries; entry i = the layer name the launch computes
+ * ("conv1", "down1", "res3.conv2", "res3.c3q" (conv3 + theta|phi|g), "res3.attention", "res3.w", "up2", "heads", "clr_conv1", glue
+ * kernel names), its device time and its class.  bench.py derives the per-kernel roofline from these. */
+int bsr_timing_launches(bsr_handle* h);
+int bsr_timing_entry(bsr_handle* h, int i, char* name, size_t name_cap, float* ms, int* cls);
 
 /* Test hook: the fused NonLocalBlock attention kernel alone (/root/reference/model.py:51-53).
  * qkv [B,tokens,384] (theta | phi | g, 128 channels each) -> y [B,tokens,128]; tokens % 128 == 0. */

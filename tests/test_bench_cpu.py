@@ -1,0 +1,65 @@
+"""bench.py's rank logic on a CPU box: `--gpus N` must start N ranks itself (the driver runs `python bench.py --gpus N`),
+report n_gpus = N, and refuse to fall back to fewer ranks.  The generator is the labelled stub; nothing is measured."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_gpus2_launches_two_ranks_over_gloo():
+    r = _run(["--gpus", "2", "--backend", "gloo", "--stub", "--batch", "2", "--steps", "2", "--warmup", "1", "--repeats", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["stub"] is True and j["steps"] == 2 and j["warmup"] == 1
+    assert j["scaling"] == "weak" and j["higher_is_better"] is True and j["unit"] == "images/sec"
+    assert j["config"]["global_batch"] == 4 and j["config"]["parallelism"] == "dp2"
+    assert j["config"]["collective"].startswith("all_gather")
+    ag = j["config"]["allgather"]
+    assert ag["bytes_per_rank"] == 2 * 256 * 256 * 4 * 4 and ag["ms_alone"] > 0
+    assert len(j["config"]["per_rank_images_per_sec"]) == 2
+    assert abs(j["value"] - 4 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-3      # whole-job aggregate over both ranks
+    assert j["repeats"]["n"] == 2 and j["repeats"]["ms_per_step_min"] > 0
+
+
+def test_gpus_without_devices_fails_loudly():
+    """No silent fall-back to one GPU: on this CPU box `--gpus 2` on the real path must exit non-zero before starting ranks."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert r.returncode != 0
+    assert "only 0 GPU" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_mismatch_is_rejected():
+    r = _run(["--gpus", "4", "--backend", "gloo", "--stub", "--batch", "1", "--steps", "1", "--warmup", "0"],
+             env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 4" in r.stderr
+
+
+def test_stub_needs_gloo_and_gloo_needs_stub():
+    assert _run(["--backend", "gloo"]).returncode != 0
+    assert _run(["--stub"]).returncode != 0
+
+
+def test_roofline_tables_are_consistent():
+    """The per-layer MMAC table bench.py prices launches with sums to SURVEY Appendix C's total and every layer sits in exactly one
+    kernel group."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert abs(sum(bench.LAYER_MMAC.values()) - 9052.06) < 1.0
+    grouped = [n for layers in bench.KERNEL_GROUPS.values() for n in layers]
+    assert sorted(grouped) == sorted(bench.LAYER_MMAC)
+    assert abs(2e-3 * sum(bench.LAYER_MMAC[n] for n in bench.LAYERS_3X3) - 2e-3 * (16.78 + 3.15) - bench.GFLOP_3X3_PER_IMAGE) < 0.01
+    assert bench.physical_cores() >= 1

@@ -24,7 +24,7 @@ def test_library_is_the_in_tree_hip_extension():
     from blindshadowremoval_amd import _lib
     from blindshadowremoval_amd.build import LIB_PATH
     lib = _lib.load()
-    assert lib._name == LIB_PATH and lib.bsr_abi_version() == 1
+    assert lib._name == LIB_PATH and lib.bsr_abi_version() == 2
 
 
 @pytest.mark.parametrize("seed,B", [(0, 2), (7, 3)])
@@ -234,3 +234,94 @@ def test_f16_mfma_mode_tracks_the_fp32_oracle():
     print("f16 mode: max abs err", errs, "bmask flips", nflip)
     assert max(errs.values()) > 1e-6          # it really is a different arithmetic (guards against silently running fp32)
     gen.close()
+
+
+def test_config3_rank_shape_f16_batch32():
+    """BASELINE configs[3] = 256 images over 8 GPUs with the fp16 MFMA conv path: the PER-RANK shape (B = 32, dtype f16) on one
+    GPU against the fp32 oracle, all 32 rows, same tolerance as the B = 2 test above."""
+    from blindshadowremoval_amd import Generator
+    from parity_util import run_and_compare
+    F16_TOL = 5e-3
+    weights = init_weights(1)
+    gen = Generator(dtype="f16").load_weights(weights)
+    g = torch.Generator().manual_seed(21)
+    inp, uv = torch.rand(32, 256, 256, 3, generator=g), torch.rand(32, 256, 256, 3, generator=g)
+    out, ref, errs, nflip = run_and_compare(gen, weights, inp, uv, tol=F16_TOL, flip_tol=F16_TOL)
+    print("f16 B=32: max abs err", errs, "bmask flips", nflip)
+    assert out[1].shape == (32, 256, 256, 3)
+    gen.close()
+
+
+def test_config4_rank_shape_tsm_512_batch8():
+    """BASELINE configs[4] = 64 frames of 512x512 over 8 GPUs through the TSM generator: the PER-RANK shape (B = 8, 512x512,
+    frame = 2) on one GPU against the TSM oracle (4096-token attention, 64x64 ShareLayer warp)."""
+    from blindshadowremoval_amd import GeneratorTSM
+    from oracle.gsc_oracle import GeneratorTSMOracle
+    from parity_util import FLIP_TOL, TOL
+    w = init_weights(1, variant="tsm")
+    gen = GeneratorTSM().load_weights(w)
+    g = torch.Generator().manual_seed(33)
+    B, S = 8, 512
+    inp, uv = torch.rand(B, S, S, 3, generator=g), torch.rand(B, S, S, 3, generator=g)
+    reg = torch.nn.functional.interpolate((torch.rand(B, 6, 9, 9, generator=g) - 0.5) * 0.2, size=(S, S), mode="bicubic",
+                                          align_corners=True).permute(0, 2, 3, 1).contiguous()
+    reg[..., 2] = 0
+    reg[..., 5] = 0
+    out = [t.cpu() for t in gen(inp.cuda(), uv.cuda(), reg.cuda(), 2, True)]
+    bmask, d32 = gen.probe("bmask").cpu(), gen.probe("d32").cpu()
+    oracle, pr = GeneratorTSMOracle(w), {}
+    ref = oracle(inp, uv, reg, 2, True, probes=pr)
+    assert float((d32 - pr["d32"]).abs().max()) <= TOL
+    flips = bmask != pr["bmask"]
+    if int(flips.sum()):
+        assert float((pr["d32"][flips] - 0.1).abs().max()) < FLIP_TOL
+        ref = oracle(inp, uv, reg, 2, True, bmask_override=bmask)
+    for a, b, name in zip(out, ref, ("gs", "con_rgb", "mask22", "dif")):
+        assert a.shape == b.shape == (B, S, S, a.shape[3])
+        assert float((a - b).abs().max()) <= TOL, name
+    gen.close()
+
+
+def test_out_buffers_are_validated_and_device_is_restored(gen_w):
+    """Caller-supplied `out=` buffers reach the library as raw pointers: wrong shape / dtype / layout / device must be refused
+    before the call; the C ABI restores the caller's current device."""
+    gen, _ = gen_w
+    t = torch.rand(2, 256, 256, 3).cuda()
+    good = tuple(torch.empty((2, 256, 256, c), device="cuda") for c in (1, 3, 3, 1))
+    a = [x.clone() for x in gen(t, t, out=good)]
+    b = gen(t, t)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        gen(t, t, out=good[:3])
+    with pytest.raises(ValueError):
+        gen(t, t, out=(good[0], good[1], good[2], torch.empty((1, 256, 256, 1), device="cuda")))
+    with pytest.raises(TypeError):
+        gen(t, t, out=(good[0], good[1].double(), good[2], good[3]))
+    with pytest.raises(ValueError):
+        gen(t, t, out=(good[0], torch.empty((2, 256, 256, 6), device="cuda")[..., ::2], good[2], good[3]))
+    with pytest.raises(ValueError):
+        gen(t, t, out=(good[0].cpu(), good[1], good[2], good[3]))
+    assert torch.cuda.current_device() == 0
+
+
+def test_per_launch_timing_names_every_layer(gen_w):
+    """bsr_timing_entry: one entry per launch, named by the reference layer(s) it computes; bench.py's roofline table keys on them."""
+    import importlib.util
+    import os
+    gen, _ = gen_w
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = torch.rand(1, 256, 256, 3).cuda()
+    gen.set_timing(True)
+    gen(t, t)
+    torch.cuda.synchronize()
+    entries = gen.get_launch_timing()
+    gen.set_timing(False)
+    names = [n for n, _, _ in entries]
+    assert set(bench.LAYER_MMAC) <= set(names), sorted(set(bench.LAYER_MMAC) - set(names))
+    assert all(ms > 0 for _, ms, _ in entries)
+    assert abs(sum(bench.LAYER_MMAC.values()) - 9052.06) < 1.0          # SURVEY Appendix C total
+    grouped = [n for layers in bench.KERNEL_GROUPS.values() for n in layers]
+    assert sorted(grouped) == sorted(bench.LAYER_MMAC)
