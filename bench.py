@@ -223,6 +223,17 @@ class _StubGenerator:
 
 
 # ----------------------------------------------------------------------------------------------- roofline from per-launch events
+H16_LAYERS = (["down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3"] + ["res%d.conv2" % i for i in range(6)])   # = pack.H16_LAYERS
+
+
+def group_peak(layers, dtype):
+    """Matrix-core peak that bounds a kernel group: fp32 MFMA for fp32 kernels; in the 16-bit modes the igemm_h16 layers are priced
+    against the dense fp16 peak — divided by 3 for f32x3, whose every algorithmic MAC costs three fp16 MACs (hi.hi + hi.lo + lo.hi)."""
+    if dtype != "f32" and all(n in H16_LAYERS for n in layers):
+        return PEAK_F16_MFMA_TFLOPS / (3.0 if dtype == "f32x3" else 1.0)
+    return PEAK_F32_MFMA_TFLOPS
+
+
 def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
     """HIP events around every launch of a few extra forwards on the forward's stream (bsr_set_timing): per-layer device time ->
     the dominant kernel instantiation's achieved TFLOP/s, the 3x3-conv path's, and every kernel group's fraction of the peak."""
@@ -235,26 +246,29 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
         for name, ms, _cls in gen.get_launch_timing():
             layer_ms[name] = layer_ms.get(name, 0.0) + ms / n_rep
     gen.set_timing(False)
-    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F16_MFMA_TFLOPS
     groups = {}
     for gname, layers in KERNEL_GROUPS.items():
         ms = sum(layer_ms.get(n, 0.0) for n in layers)
         if ms <= 0:
             continue
         gflop = 2e-3 * sum(LAYER_MMAC[n] for n in layers) * B
-        groups[gname] = {"ms": round(ms, 4), "launches": len(layers), "tflops": round(gflop / ms, 2), "frac": round(gflop / ms / peak, 4),
-                         "gflop": gflop}
+        gpeak = group_peak(layers, dtype)
+        label = gname.replace("igemm_conv_kernel", "igemm_h16_kernel") if gpeak != PEAK_F32_MFMA_TFLOPS else gname
+        groups[label] = {"ms": round(ms, 4), "launches": len(layers), "tflops": round(gflop / ms, 2), "peak": round(gpeak, 1),
+                         "frac": round(gflop / ms / gpeak, 4), "gflop": gflop}
     dom_name = max(groups, key=lambda k: groups[k]["ms"])
     dom = groups[dom_name]
+    peak = dom["peak"]
     t33 = sum(layer_ms.get(n, 0.0) for n in LAYERS_3X3)
     path = GFLOP_3X3_PER_IMAGE * B / t33
+    peak33 = group_peak(["up3"], dtype)
     t_all = sum(layer_ms.values())
     glue_ms = sum(ms for n, ms in layer_ms.items() if n not in LAYER_MMAC)
     rf = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
           "kernel": dom_name + " — the largest kernel instantiation, %.0f %% of the forward's device time" % (100 * dom["ms"] / t_all),
           "launches_per_forward": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
           "algorithmic_gflop_per_launch": round(dom["gflop"] / dom["launches"], 2),
-          "path_3x3": {"achieved": round(path, 2), "frac": round(path / peak, 4), "launches": len(LAYERS_3X3), "ms": round(t33, 4),
+          "path_3x3": {"achieved": round(path, 2), "peak": round(peak33, 1), "frac": round(path / peak33, 4), "launches": len(LAYERS_3X3), "ms": round(t33, 4),
                        "algorithmic_gflop": round(GFLOP_3X3_PER_IMAGE * B, 2)},
           "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all, 2), "all_kernels_ms": round(t_all, 4),
           "kernel_groups": {k: {kk: vv for kk, vv in v.items() if kk != "gflop"} for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
@@ -284,6 +298,40 @@ def attach_traffic(rf, dom_name, B, dtype):
         return
 
 
+def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_parity):
+    """The same workload on the split-precision path, reported BESIDE the f32 line (never as `value`): per-GPU images/s of this
+    rank, its own roofline object, and (N = 1) its parity against the oracle under the fp32 tolerances."""
+    import torch
+    from blindshadowremoval_amd import Generator
+    gen = Generator(device=device, dtype="f32x3").load_weights(weights)
+    for _ in range(args.warmup):
+        gen(inp, uv, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gen(inp, uv, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rf, _ = roofline_from_events(gen, lambda: gen(inp, uv, out=out), B, "f32x3")
+    res = {"dtype": "f32x3", "value": round(B * args.steps / dt, 2), "unit": "images/sec (this GPU, no collective)", "ms_per_step": round(dt / args.steps * 1e3, 4),
+           "steps": args.steps, "roofline": rf,
+           "note": "3x3 / stride-2 / transposed 3x3 layers on v_mfma_f32_32x32x16_f16 with operands split into hi + lo fp16 planes at LDS staging "
+                   "(three instructions per K group, fp32 accumulate); every other kernel is the fp32 one; activations stay fp32 in HBM"}
+    if with_parity:
+        from oracle.gsc_oracle import GeneratorOracle
+        torch.manual_seed(0)
+        i8, u8 = torch.rand(8, 256, 256, 3), torch.rand(8, 256, 256, 3)
+        hip = [t.cpu() for t in gen(i8.to(inp.device), u8.to(inp.device))]
+        bmask = gen.probe("bmask").cpu()
+        oracle, pr = GeneratorOracle(weights), {}
+        oracle(i8, u8, probes=pr)
+        ref = oracle(i8, u8, bmask_override=bmask)
+        res["parity"] = {"max_abs_err": max(float((a - r).abs().max()) for a, r in zip(hip, ref)), "bmask_flips": int((bmask != pr["bmask"]).sum()),
+                         "sample": "8 synthetic images, all four outputs vs the CPU oracle (tolerance 1e-3)"}
+    gen.close()
+    return res
+
+
 # ----------------------------------------------------------------------------------------------- one rank
 def run_rank(args):
     import torch
@@ -303,7 +351,13 @@ def run_rank(args):
         dev = torch.device("cuda", local_rank)
     else:
         dev = torch.device("cpu")
+    real_stdout = None
     if distributed:
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the ONE JSON line by pointing
+        # fd 1 at stderr for the lifetime of the rank and writing the line to the saved descriptor at the end
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
@@ -412,6 +466,9 @@ def run_rank(args):
         elif args.dtype == "f32":
             cfg["workload"] = ("BASELINE configs[1]: batch=32 synthetic 256x256x3 per GPU, full GSC generator fp32 "
                                "(seeded random-init weights in the ckpt-94 variable layout)")
+        elif args.dtype == "f32x3":
+            cfg["workload"] = ("BASELINE configs[1] shape (batch=32 synthetic 256x256x3 per GPU, full GSC generator) with the 3x3-conv path on the fp16 matrix "
+                               "cores in split precision (hi.hi + hi.lo + lo.hi, fp32 accumulate, fp32 activations): fp32-class accuracy, NOT the headline dtype")
         else:
             cfg["workload"] = ("BASELINE configs[3]: batch=32 synthetic 256x256x3 per GPU, fp16 MFMA (fp32 accumulate/storage) on the "
                                "3x3-conv path, fp32 elsewhere; NOT the headline configuration")
@@ -439,13 +496,26 @@ def run_rank(args):
                 result["cpu_baseline"] = cpu_baseline(weights, gen=gen, device=dev)
             else:
                 result["cpu_baseline"] = None
+            if args.dtype == "f32" and not tsm and not args.no_secondary:
+                result["f32x3"] = secondary_f32x3(weights, local_rank, inp, uv, outs[0], B, args, world, timed if not distributed else None,
+                                                  with_parity=(world == 1 and not args.no_cpu_baseline))
             if args.loop and world == 1:
                 from blindshadowremoval_amd.loop_bench import loop_bench
                 result["loop"] = loop_bench(args.loop, gen)
-        print(json.dumps(result), flush=True)
+        line = json.dumps(result) + "\n"
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.write(real_stdout, line.encode())
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if real_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     return result
 
 
@@ -457,8 +527,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 8 for --workload tsm512)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each; `value` comes from the first")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
-                    help="f32 = the measured path (BASELINE configs[1]); f16 = opt-in fp16 MFMA on the 3x3-conv path (configs[3])")
+    ap.add_argument("--dtype", choices=("f32", "f32x3", "f16"), default="f32",
+                    help="f32 = the measured path (BASELINE configs[1], fp32 matrix cores); f32x3 = split-precision fp32 on the fp16 matrix cores "
+                         "(3x3-conv path; fp32-class accuracy); f16 = fp16 operands on the 3x3-conv path (configs[3])")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the f32x3 side measurement the default f32 run appends")
     ap.add_argument("--workload", choices=("gsc256", "tsm512"), default="gsc256",
                     help="gsc256 = BASELINE configs[1]/[3]; tsm512 = the per-rank shape of configs[4] (TSM generator, 512x512 frames)")
     ap.add_argument("--no-gather", action="store_true", help="skip the output all-gather (N>1)")

@@ -17,6 +17,7 @@
 #include "gemm_nloop.h"
 #include "glue_kernels.h"
 #include "igemm_conv.h"
+#include "igemm_h16.h"
 #include "stem7.h"
 
 namespace {
@@ -83,6 +84,8 @@ struct Variant {
   int c_h, cs_h, uv_h;        // blocks 3-5 input/output, uv slot
 };
 constexpr Variant kGSC{false, 99, 120, 96, 257, 264, 261, 264, 258};
+// 16-bit matrix-core modes (BSR_DTYPE_F16 / BSR_DTYPE_F32X3): K chunks are 32 channels, so the 257 / 261-wide tensors get stride 288
+constexpr Variant kGSC16{false, 99, 120, 96, 257, 288, 261, 288, 258};
 constexpr Variant kTSM{true, 291, 312, 288, 291, 312, 877, 888, 874};
 constexpr int CS_CF = 64;    // f = clr_up3 output; the gs channel of cat[gs, f] (model.py:267) is read from the gs output
 
@@ -129,7 +132,7 @@ struct bsr_handle {
   float* d_blob = nullptr;
   std::unordered_map<std::string, LayerW> layers;
   Variant var = kGSC;
-  bool f16 = false;              // BSR_DTYPE_F16: fp16 MFMA on the 3x3 / stride-2 / transposed 3x3 layers (igemm kernels), fp32 elsewhere
+  int dtype = BSR_DTYPE_F32;     // BSR_DTYPE_F16 / BSR_DTYPE_F32X3: 16-bit matrix cores on the 3x3 / stride-2 / transposed 3x3 layers (igemm_h16.h), fp32 kernels elsewhere
   float head_bias[2] = {0.f, 0.f};
   const float* tail_w = nullptr;
   const float* clr_gs_w = nullptr;
@@ -196,9 +199,17 @@ struct Launcher {
             int out_coff, int n_store, int act) {
     if (rc != BSR_OK) return;
     using C = bsr::ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
+    constexpr bool k33 = (KH == 3 && KW == 3);
+    constexpr int CCH = k33 ? (CC == 24 ? 32 : CC) : 16;          // K chunk of the 16-bit kernels (multiple of 16)
+    const bool h16 = k33 && h->dtype != BSR_DTYPE_F32;
     LayerW l;
     const int nb = (n_store + C::BN - 1) / C::BN;
-    rc = find_layer(h, name, k_pad / CC, KH * KW, CC + 4, nb * C::BN, &l);
+    if (h16) {
+      if (k_pad % CCH != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': K is not a multiple of the 16-bit kernels' chunk"); return; }
+      rc = find_layer(h, name, k_pad / CCH, KH * KW, ((h->dtype == BSR_DTYPE_F32X3 ? 2 : 1) * CCH + 8) / 2, nb * C::BN, &l);
+    } else {
+      rc = find_layer(h, name, k_pad / CC, KH * KW, CC + 4, nb * C::BN, &l);
+    }
     if (rc != BSR_OK) return;
     bsr::ConvArgs a{};
     a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.H = H; a.W = W;
@@ -220,10 +231,16 @@ struct Launcher {
       return;
     }
     begin(cls, name);
-    if (h->f16 && (KH == 3 && KW == 3))
-      check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB, (KH == 3 && KW == 3)>(a, h->B, s), name);
-    else
-      check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB, false>(a, h->B, s), name);
+    if constexpr (k33) {
+      if (h->dtype == BSR_DTYPE_F32X3)
+        check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 2>(a, h->B, s), name);
+      else if (h->dtype == BSR_DTYPE_F16)
+        check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1>(a, h->B, s), name);
+      else
+        check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
+    } else {
+      check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
+    }
     end();
   }
   // 1x1 conv as a resident-activation GEMM (K = NCH*32) over all N
@@ -317,19 +334,21 @@ size_t bsr_workspace_bytes(int B, int H, int W) {
 int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t nbytes, int dtype) {
   if (out == nullptr || packed_weights == nullptr) return fail(BSR_ERR_ARG, "bsr_create: null argument");
   *out = nullptr;
-  if (dtype != BSR_DTYPE_F32 && dtype != BSR_DTYPE_F16) return fail(BSR_ERR_ARG, "bsr_create: dtype must be BSR_DTYPE_F32 or BSR_DTYPE_F16");
+  if (dtype != BSR_DTYPE_F32 && dtype != BSR_DTYPE_F16 && dtype != BSR_DTYPE_F32X3)
+    return fail(BSR_ERR_ARG, "bsr_create: dtype must be BSR_DTYPE_F32, BSR_DTYPE_F16 or BSR_DTYPE_F32X3");
   if (nbytes < sizeof(BlobHeader)) return fail(BSR_ERR_BLOB, "bsr_create: blob shorter than its header");
   const uint8_t* blob = static_cast<const uint8_t*>(packed_weights);
   BlobHeader hd;
   memcpy(&hd, blob, sizeof hd);
   if (hd.magic != kBlobMagic || hd.version != kBlobVersion) return fail(BSR_ERR_BLOB, "bsr_create: bad blob magic/version");
+  if ((int)hd.reserved != dtype) return fail(BSR_ERR_BLOB, "bsr_create: the blob was packed for another dtype (pack_generator(weights, dtype) must match bsr_create's dtype)");
   const size_t table_end = sizeof(BlobHeader) + (size_t)hd.n_entries * sizeof(BlobEntry);
   if (table_end > nbytes) return fail(BSR_ERR_BLOB, "bsr_create: blob entry table exceeds blob size");
   DeviceGuard guard(device);
   HIP_TRY(guard.err);
   bsr_handle* h = new bsr_handle();
   h->device = device;
-  h->f16 = dtype == BSR_DTYPE_F16;
+  h->dtype = dtype;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -372,7 +391,8 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   {   // GSC or TSM weights?  (res0.conv1 has K = 120 -> 5 chunks of 24, or K = 312 -> 13)
     auto it = h->layers.find("res0.conv1");
     if (it == h->layers.end()) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob has no 'res0.conv1'"); }
-    h->var = it->second.nchunk == 13 ? kTSM : kGSC;
+    h->var = it->second.nchunk == 13 ? kTSM : (dtype == BSR_DTYPE_F32 ? kGSC : kGSC16);
+    if (h->var.tsm && dtype != BSR_DTYPE_F32) { bsr_destroy(h); return fail(BSR_ERR_ARG, "bsr_create: the TSM variant is implemented for BSR_DTYPE_F32 only"); }
   }
   *out = h;
   return BSR_OK;

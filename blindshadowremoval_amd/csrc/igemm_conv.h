@@ -116,15 +116,7 @@ struct ConvCfg {
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f16x4 to_f16x4(const f32x4& v) {
-  return f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};      // round-to-nearest-even (v_cvt_pk_f16_f32... rtz is NOT used)
-}
-
-// F16 = true: BASELINE config 4's "fp16 MFMA conv path" — operands are rounded to fp16 in registers right after the LDS read and
-// one v_mfma_f32_32x32x8_f16 (K = 8, fp32 accumulate) replaces the four fp32 MFMAs of a K group; storage, staging, bias and
-// epilogue stay fp32, so the same packed weights serve both modes.
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, bool F16 = false>
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
 __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH, G = C::G;
@@ -317,26 +309,13 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        if (F16) {
-          f16x4 ah[MI], bh[NI];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) ah[mi] = to_f16x4(af[cur][mi]);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bh[ni] = to_f16x4(bf[cur][ni]);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-              acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[mi], bh[ni], acc[ph][mi][ni], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni)
-                acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[ph][mi][ni], 0, 0, 0);
-        }
+              acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[ph][mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
 
@@ -417,10 +396,10 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 #endif
 }
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, bool F16 = false>
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
 inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
-  auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, F16>;
+  auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (C::SMEM_BYTES > 48 * 1024 && (dev < 0 || !once.done[dev])) {

@@ -1,0 +1,344 @@
+// Implicit-GEMM convolution on the CDNA4 16-bit matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate), NHWC fp32 in / out.
+//
+// Same layers, tiling, LDS rings and epilogue as igemm_conv.h (Conv2D 3x3 / stride-2 3x3 / Conv2DTranspose 3x3 s2 + folded
+// BatchNorm + LeakyReLU, /root/reference/model.py:115-177); what changes is the operand format inside the workgroup:
+//
+//  NSPLIT = 2 ("f32x3", split-precision contraction): every fp32 operand x is split at staging time into two fp16 planes,
+//      hi = fp16(x) and lo = fp16(x - hi) (x = hi + lo to ~2^-22 |x|), and a K group of 16 channels is contracted with THREE
+//      matrix instructions into the same fp32 accumulator: hi.hi + hi.lo + lo.hi (the lo.lo term, < 2^-22 relative, is dropped).
+//      The fp16 products are exact in fp32, so the result differs from the fp32 MFMA path by a few 2^-22 relative per
+//      product — fp32-class accuracy at 16/3 of the fp32 matrix rate.  Activations and outputs stay fp32 in HBM, so the
+//      kernels are drop-in for the fp32 ones; weights are split offline (pack.py, "<layer>.w2" entries).
+//      Range: |x| must stay below 65504 (fp16 max) — beyond it hi is inf; operands below 2^-14 lose relative (not absolute)
+//      precision because lo becomes subnormal (gfx950 matrix cores do not flush fp16 subnormals).
+//  NSPLIT = 1 ("f16", BASELINE configs[3]): hi plane only, one matrix instruction per K group, half-width LDS tiles.
+//
+// LDS row of one pixel / one output channel: [CC halves hi | CC halves lo (NSPLIT = 2) | 8 halves pad]  = LDP 32-bit words;
+// lane (r = l & 31, h = l >> 5) reads k = 8h .. 8h+7 of a 16-channel K group with one ds_read_b128 per plane — exactly the
+// A / B operand map of v_mfma_f32_32x32x16_f16 (cdna_hip_programming.md §3) — at the same word addresses the fp32 kernel uses
+// (row * LDP + 4h + 8g), so the bank behaviour is the fp32 kernel's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "igemm_conv.h"
+
+namespace bsr {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>
+struct H16Cfg {
+  static constexpr int T = KH * KW;
+  static constexpr int IH = TR ? TH + 1 : (TH - 1) * S + KH;
+  static constexpr int IW = TR ? TW + 1 : (TW - 1) * S + KW;
+  static constexpr int LDP = (NSPLIT * CC + 8) / 2;             // 32-bit words per LDS row
+  static constexpr int LO = CC / 2;                              // word offset of the lo plane inside a row
+  static constexpr int G = CC / 16;                              // K groups (one 32x32x16 instruction per plane pair) per chunk
+  static constexpr int BN = WN * NI * 32;
+  static constexpr int BM = WM * MI * 32;
+  static constexpr int NPH = TR ? 4 : 1;
+  static constexpr int IN_WORDS = IH * IW * LDP;
+  static constexpr int W_WORDS = BN * LDP;
+  static constexpr int SMEM_BYTES = (INB * IN_WORDS + 3 * W_WORDS) * 4;
+  static constexpr int IN_V8 = IH * IW * (CC / 8);               // 8-channel (32-byte) pieces of one input-tile chunk
+  static constexpr int IN_PER_THREAD = (IN_V8 + 255) / 256;
+  static constexpr int W_V4 = W_WORDS / 4;
+  static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
+  static_assert(NSPLIT == 1 || NSPLIT == 2, "one (f16) or two (f32x3) fp16 planes");
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BM == TH * TW, "M tile must equal the spatial tile");
+  static_assert(CC % 16 == 0, "channel chunk must be a multiple of the 16-wide K group");
+  static_assert(!TR || (KH == 3 && KW == 3 && S == 1), "transposed path is ConvT(3, stride 2)");
+  static_assert(INB == 1 || (T == 1 ? INB == 3 : INB == 2), "input buffers: 1, or 2 (taps > 1) / 3 (1x1)");
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(W_WORDS % 4 == 0, "weight image is copied in 16-byte pieces");
+};
+
+// hi = fp16(x) (round to nearest even), lo = fp16(x - hi)
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 ha = (_Float16)a[i], hb = (_Float16)b[i];
+    hi[i] = ha;
+    hi[4 + i] = hb;
+    lo[i] = (_Float16)(a[i] - (float)ha);
+    lo[4 + i] = (_Float16)(b[i] - (float)hb);
+  }
+}
+
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>
+__global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
+  using C = H16Cfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT>;
+  constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH, G = C::G, LO = C::LO;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;
+  float* s_w = smem + INB * C::IN_WORDS;
+
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  int bid = blockIdx.x;
+  const int tile_x = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int tile_y = bid % p.tiles_y;
+  const int img = bid / p.tiles_y;
+  const int n0 = blockIdx.y * BN;
+  const int y0 = tile_y * TH, x0 = tile_x * TW;
+  const int iy0 = TR ? y0 - 1 : y0 * S - p.pad_t;
+  const int ix0 = TR ? x0 - 1 : x0 * S - p.pad_l;
+  const float* in_img = p.in + (size_t)img * p.H * p.W * p.in_cs + p.in_coff;
+
+  int a_base[MI], b_base[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int px = (wm * MI + mi) * 32 + r;
+    const int ty = px / TW, tx = px % TW;
+    a_base[mi] = ((ty * S) * IW + tx * S) * LDP + 4 * h;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) b_base[ni] = ((wn * NI + ni) * 32 + r) * LDP + 4 * h;
+
+  float bias_n[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + (wn * NI + ni) * 32 + r;
+    bias_n[ni] = p.bias[n < p.n_pad ? n : 0];
+  }
+  f32x16 acc[NPH][MI][NI];
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ph][mi][ni][i] = bias_n[ni];
+
+  // staging addresses: wave-uniform base + per-thread constant, computed once (see igemm_conv.h)
+  unsigned in_goff[C::IN_PER_THREAD], w_off[C::W_PER_THREAD];
+  int in_loff[C::IN_PER_THREAD];
+  unsigned in_okmask = 0u;
+#pragma unroll
+  for (int i = 0; i < C::IN_PER_THREAD; ++i) {
+    const int idx0 = tid + i * 256;
+    const int idx = idx0 < C::IN_V8 ? idx0 : C::IN_V8 - 1;
+    const int pix = idx / (CC / 8), q = idx % (CC / 8);
+    const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+    const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+    in_goff[i] = (unsigned)(((iyc * p.W + ixc) * p.in_cs + q * 8) * 4);
+    in_loff[i] = idx0 < C::IN_V8 ? pix * LDP + q * 4 : -1;            // words: 8 halves = 4 words per piece and plane
+    in_okmask |= (ok ? 1u : 0u) << i;
+  }
+#pragma unroll
+  for (int i = 0; i < C::W_PER_THREAD; ++i) {
+    const int idx0 = tid + i * 256;
+    w_off[i] = (unsigned)((idx0 < C::W_V4 ? idx0 : C::W_V4 - 1) * 16);
+  }
+  auto fetch_in = [&](int ch, f32x4 (&regs)[2 * C::IN_PER_THREAD]) {
+    const char* base = reinterpret_cast<const char*>(in_img + ch * CC);
+#pragma unroll
+    for (int i = 0; i < C::IN_PER_THREAD; ++i) {
+      regs[2 * i] = *reinterpret_cast<const f32x4*>(base + in_goff[i]);
+      regs[2 * i + 1] = *reinterpret_cast<const f32x4*>(base + in_goff[i] + 16);
+    }
+  };
+  auto store_in = [&](int off, const f32x4 (&regs)[2 * C::IN_PER_THREAD]) {
+#pragma unroll
+    for (int i = 0; i < C::IN_PER_THREAD; ++i) {
+      if (in_loff[i] >= 0) {
+        f32x4 a = regs[2 * i], b = regs[2 * i + 1];
+        if (!((in_okmask >> i) & 1u)) { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }      // TF SAME zero padding
+        f16x8 hi, lo;
+        split8(a, b, hi, lo);
+        *reinterpret_cast<f16x8*>(s_in + off + in_loff[i]) = hi;
+        if (NSPLIT == 2) *reinterpret_cast<f16x8*>(s_in + off + in_loff[i] + LO) = lo;
+      }
+    }
+  };
+  // weights: p.w is the packed fp16 LDS image [chunk][tap][n_pad][LDP words], copied verbatim
+  auto fetch_w = [&](int step, f32x4 (&regs)[C::W_PER_THREAD]) {
+    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDP);
+#pragma unroll
+    for (int i = 0; i < C::W_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + w_off[i]);
+  };
+  auto store_w = [&](int off, const f32x4 (&regs)[C::W_PER_THREAD]) {
+    char* dst = reinterpret_cast<char*>(s_w + off);
+#pragma unroll
+    for (int i = 0; i < C::W_PER_THREAD; ++i) {
+      if (tid + i * 256 < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
+    }
+  };
+
+  f32x4 in_regs[2 * C::IN_PER_THREAD];
+  f32x4 w_regs[C::W_PER_THREAD];
+  const int nsteps = p.nchunk * T;
+
+  int w_cur = 0, w_n1 = C::W_WORDS, w_n2 = 2 * C::W_WORDS;
+  int in_cur = 0, in_n1 = (INB > 1) ? C::IN_WORDS : 0, in_n2 = (INB > 2) ? 2 * C::IN_WORDS : 0;
+
+  // prologue: steps 0 and 1 staged synchronously
+  fetch_in(0, in_regs);
+  fetch_w(0, w_regs);
+  store_in(0, in_regs);
+  store_w(0, w_regs);
+  if (nsteps > 1) {
+    fetch_w(1, w_regs);
+    store_w(w_n1, w_regs);
+    if (T == 1 && INB == 3) {
+      fetch_in(1, in_regs);
+      store_in(in_n1, in_regs);
+    }
+  }
+  __syncthreads();
+
+  f16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+  auto read_frags = [&](int slot, int a_off, int b_off) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ah[slot][mi] = *reinterpret_cast<const f16x8*>(s_in + a_base[mi] + a_off);
+      if (NSPLIT == 2) al[slot][mi] = *reinterpret_cast<const f16x8*>(s_in + a_base[mi] + a_off + LO);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      bh[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + b_off);
+      if (NSPLIT == 2) bl[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + b_off + LO);
+    }
+  };
+  auto tap_offset = [&](int t) -> int {
+    if (TR) {
+      const int a = t / 3, b = t % 3;
+      return (((a == 2) ? 0 : 1) * IW + ((b == 2) ? 0 : 1)) * LDP;
+    }
+    return ((t / KW) * IW + (t % KW)) * LDP;
+  };
+  read_frags(0, in_cur + tap_offset(0), w_cur);
+  __builtin_amdgcn_s_setprio(0);
+
+  for (int ch = 0; ch < p.nchunk; ++ch) {
+    const bool more = ch + 1 < p.nchunk;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int s = ch * T + t;
+      const bool has1 = s + 1 < nsteps, has2 = s + 2 < nsteps;
+      constexpr bool kRing1x1 = (T == 1 && INB == 3);
+      constexpr int kInFetchTap = (T >= 4) ? T - 4 : 0;
+      constexpr int kInStoreTap = (INB == 2) ? T - 2 : T - 1;
+      const bool fetch_now = kRing1x1 ? has2 : (T > 1 && t == kInFetchTap && more);
+      const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == kInStoreTap && more);
+      if (has2) fetch_w(s + 2, w_regs);
+      if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs);
+      __builtin_amdgcn_sched_barrier(0);
+
+      const int ph = TR ? (((t / 3 == 1) ? 2 : 0) + ((t % 3 == 1) ? 1 : 0)) : 0;
+      const int tap_off = tap_offset(t);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int cur = (t * G + g) & 1, nxt = cur ^ 1;
+        if (g + 1 < G) {
+          read_frags(nxt, in_cur + tap_off + (g + 1) * 8, w_cur + (g + 1) * 8);
+        } else if (t + 1 < T) {
+          read_frags(nxt, in_cur + tap_offset(t + 1 < T ? t + 1 : 0), w_n1);
+        } else if (INB > 1) {
+          if (has1) read_frags(nxt, in_n1 + tap_offset(0), w_n1);
+        }
+        if (g == G - 1) {                                                           // write point: stage step s+2
+          if (has2) store_w(w_n2, w_regs);
+          if (stage_in) store_in(kRing1x1 ? in_n2 : in_n1, in_regs);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if (NSPLIT == 2) {
+              // small terms first, the leading term last
+              acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][mi], bh[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+              acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mi], bl[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+            }
+            acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mi], bh[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+
+      __syncthreads();
+      if (INB == 1 && t == T - 1 && more) {
+        store_in(0, in_regs);
+        __syncthreads();
+        read_frags(((T * G) & 1), tap_offset(0), w_n1);
+      }
+      {
+        const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = tw;
+        if (T == 1 && INB == 3) { const int ti = in_cur; in_cur = in_n1; in_n1 = in_n2; in_n2 = ti; }
+        if (T > 1 && INB == 2 && t == T - 1) { const int ti = in_cur; in_cur = in_n1; in_n1 = ti; }
+      }
+    }
+    if ((T * G) & 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) { ah[0][mi] = ah[1][mi]; al[0][mi] = al[1][mi]; }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) { bh[0][ni] = bh[1][ni]; bl[0][ni] = bl[1][ni]; }
+    }
+  }
+
+  __builtin_amdgcn_s_setprio(3);
+  // ---- epilogue: identical to igemm_conv_kernel's (bias is already in the accumulator; LeakyReLU; NHWC raw-buffer stores) ----
+  static_assert(TW == 32, "epilogue assumes one tile row per 32-pixel MFMA tile");
+  constexpr int SX = TR ? 2 : 1;
+  const size_t blk_pix = (size_t)img * p.Ho * p.Wo + (size_t)(SX * y0) * p.Wo + SX * x0;
+  const unsigned lane_out = ((unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r) * 4u;
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.out + blk_pix * p.out_cs + p.out_coff);
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nt = n0 + (wn * NI + ni) * 32;
+        const unsigned voff = nt + r < p.n_store ? lane_out : kLaneOff;
+        const int ty = wm * MI + mi;
+        const unsigned tile_off = (unsigned)((SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0)) * (unsigned)p.out_cs + (unsigned)nt;
+        f32x16 v = acc[ph][mi][ni];
+        if (p.act) {
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 y = leaky_relu2(f32x2{v[i], v[i + 1]});
+            v[i] = y[0];
+            v[i + 1] = y[1];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = SX * ((i & 3) + 8 * (i >> 2));
+          const unsigned soff = (tile_off + (unsigned)k * (unsigned)p.out_cs) * 4u;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, voff, soff, 0);
+        }
+      }
+}
+
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>
+inline hipError_t launch_igemm_h16(ConvArgs a, int batch, hipStream_t stream) {
+  using C = H16Cfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT>;
+  auto kern = igemm_h16_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT>;
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (C::SMEM_BYTES > 48 * 1024 && (dev < 0 || !once.done[dev])) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
+    if (e != hipSuccess) return e;
+    if (dev >= 0) once.done[dev] = true;
+  }
+  const int mh = TR ? a.H : a.Ho, mw = TR ? a.W : a.Wo;
+  a.tiles_x = mw / TW;
+  a.tiles_y = mh / TH;
+  dim3 grid(a.tiles_x * a.tiles_y * batch, (a.n_store + C::BN - 1) / C::BN);
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM_BYTES, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace bsr

@@ -18,14 +18,15 @@ import numpy as np
 import torch
 
 from . import _lib
-from .pack import pack_generator
+from .pack import DTYPES, pack_generator
 from .tf_bundle import latest_checkpoint, load_generator_weights
 
 
 class Generator:
     def __init__(self, downsize: int = 1, n_res: int = 6, device: Optional[int] = None, dtype: str = "f32"):
-        if dtype not in ("f32", "f16"):
-            raise ValueError("dtype must be 'f32' (the measured path) or 'f16' (fp16 MFMA on the 3x3-conv path, BASELINE config 4)")
+        if dtype not in DTYPES:
+            raise ValueError("dtype must be 'f32' (the measured path), 'f32x3' (split-precision fp32 on the 16-bit matrix cores) or "
+                             "'f16' (fp16 operands on the 3x3-conv path, BASELINE configs[3])")
         self.dtype = dtype
         if n_res != 6:
             raise ValueError("the GSC generator has n_res=6 (/root/reference/model.py:199)")
@@ -44,11 +45,11 @@ class Generator:
             raise RuntimeError("blindshadowremoval_amd.Generator needs a ROCm GPU: there is no CPU path")
         lib = _lib.load()
         dev = torch.cuda.current_device() if self._device is None else int(self._device)
-        blob = pack_generator(weights)
+        blob = pack_generator(weights, self.dtype)
         handle = ctypes.c_void_p()
         buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
         with torch.cuda.device(dev):
-            rc = lib.bsr_create(ctypes.byref(handle), dev, ctypes.cast(buf, ctypes.c_void_p), len(blob), 1 if self.dtype == "f16" else 0)
+            rc = lib.bsr_create(ctypes.byref(handle), dev, ctypes.cast(buf, ctypes.c_void_p), len(blob), DTYPES[self.dtype])
         _lib.check(rc, "bsr_create")
         self.close()
         self._lib, self._handle, self._device = lib, handle, dev

@@ -26,15 +26,25 @@ _HEADER = struct.Struct("<4I")
 
 TRANSPOSED = ("up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3")
 
-def geometry(variant: str = "gsc") -> Dict[str, Tuple[int, int, int]]:
+DTYPES = {"f32": 0, "f16": 1, "f32x3": 2}     # BSR_DTYPE_* of include/bsr_hip.h
+# layers the 16-bit modes run on igemm_h16_kernel (csrc/igemm_h16.h): every 3x3 / stride-2 3x3 / transposed 3x3 igemm layer
+H16_LAYERS = ("down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3") + tuple("res%d.conv2" % i for i in range(6))
+
+
+def geometry(variant: str = "gsc", dtype: str = "f32") -> Dict[str, Tuple[int, int, int]]:
     """name -> (CC, k_pad, n_pad): must match the launch table in csrc/bsr_api.hip.  The TSM variant
-    (/root/reference/model_with_TSM.py) only widens the K of the layers fed by the ShareLayer concats: 291 -> 312, 877 -> 888."""
+    (/root/reference/model_with_TSM.py) only widens the K of the layers fed by the ShareLayer concats: 291 -> 312, 877 -> 888.
+    The 16-bit modes use 32-channel K chunks, so the 257 / 261-wide trunk tensors get stride 288 instead of 264 (kGSC16)."""
     tsm = variant == "tsm"
-    k_a, k_r, k_h = (312, 312, 888) if tsm else (120, 264, 264)
+    h16 = dtype != "f32"
+    if tsm and h16:
+        raise ValueError("the TSM variant is packed for dtype 'f32' only")
+    k_a, k_r, k_h = (312, 312, 888) if tsm else ((120, 288, 288) if h16 else (120, 264, 264))
+    cu = 32 if h16 else 24
     g: Dict[str, Tuple[int, int, int]] = {
         "conv1": (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),
-        "up1": (24, k_r, 96), "up2": (32, 160, 64), "up3": (32, 128, 64), "heads": (32, 64, 16),
-        "clr_up1": (24, k_h, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (32, 64, 16),
+        "up1": (cu, k_r, 96), "up2": (32, 160, 64), "up3": (32, 128, 64), "heads": (32, 64, 16),
+        "clr_up1": (cu, k_h, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (32, 64, 16),
     }
     for i in range(N_RES):
         g["res%d.conv1" % i] = (24, k_a if i == 0 else (k_r if i < N_RES // 2 else k_h), 128)
@@ -69,6 +79,29 @@ def pack_taps(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int, n_p
     full[:, :k, :n] = kernel_tkn
     arr = np.zeros((k_pad // cc, taps, n_pad, cc + 4), np.float32)
     arr[..., :cc] = full.reshape(taps, k_pad // cc, cc, n_pad).transpose(1, 0, 3, 2)
+    b = np.zeros(n_pad, np.float32)
+    b[:n] = bias
+    return arr, b
+
+
+def pack_taps_h16(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int, n_pad: int, nsplit: int):
+    """[taps, K, N] -> the fp16 LDS image of csrc/igemm_h16.h as float32 words: [k_pad/cc, taps, n_pad, (nsplit*cc + 8) / 2].
+    Row of output channel n: cc halves hi = fp16(w) | (nsplit == 2) cc halves lo = fp16(w - hi) | 8 halves of zero pad, where
+    w is the fp32 value the fp32 path uses (so hi + lo reproduces it to ~2^-22)."""
+    taps, k, n = kernel_tkn.shape
+    assert k <= k_pad and n <= n_pad and k_pad % cc == 0 and cc % 16 == 0 and nsplit in (1, 2)
+    full = np.zeros((taps, k_pad, n_pad), np.float64)
+    full[:, :k, :n] = kernel_tkn.astype(np.float32)
+    rows = full.reshape(taps, k_pad // cc, cc, n_pad).transpose(1, 0, 3, 2)          # [chunk, tap, n, cc]
+    hi = rows.astype(np.float16)
+    if not np.all(np.isfinite(hi)):
+        raise ValueError("a folded weight exceeds the fp16 range (65504): this layer cannot run in the 16-bit modes")
+    planes = [hi]
+    if nsplit == 2:
+        planes.append((rows - hi.astype(np.float64)).astype(np.float16))
+    planes.append(np.zeros(rows.shape[:3] + (8,), np.float16))
+    img = np.ascontiguousarray(np.concatenate(planes, axis=3))                        # [chunk, tap, n, nsplit*cc + 8] halves
+    arr = img.view(np.float32)                                                         # two halves per 32-bit word, little endian
     b = np.zeros(n_pad, np.float32)
     b[:n] = bias
     return arr, b
@@ -134,15 +167,20 @@ def tail_weights(w: Dict[str, np.ndarray]) -> np.ndarray:
     return np.concatenate([k2.reshape(-1), b2, k3.reshape(-1), w["clr_conv3/conv/bias"].astype(np.float64)]).astype(np.float32)
 
 
-def pack_generator(weights: Dict[str, np.ndarray]) -> bytes:
-    """reference-named variables -> blob for ``bsr_create``."""
+def pack_generator(weights: Dict[str, np.ndarray], dtype: str = "f32") -> bytes:
+    """reference-named variables -> blob for ``bsr_create(..., dtype)`` (the blob header records the dtype it was packed for)."""
+    if dtype not in DTYPES:
+        raise ValueError("dtype must be one of %s" % sorted(DTYPES))
     variant = detect_variant(weights)
     check_weights(weights, variant)
-    geo = geometry(variant)
+    geo = geometry(variant, dtype)
     entries: List[Tuple[str, np.ndarray, Tuple[int, int, int, int]]] = []
     for name, (k, b) in layer_matrices(weights).items():
         cc, k_pad, n_pad = geo[name]
-        arr, bias = pack_taps(k, b, cc, k_pad, n_pad)
+        if dtype != "f32" and name in H16_LAYERS:
+            arr, bias = pack_taps_h16(k, b, cc, k_pad, n_pad, 2 if dtype == "f32x3" else 1)
+        else:
+            arr, bias = pack_taps(k, b, cc, k_pad, n_pad)
         entries.append((name + ".w", arr, tuple(arr.shape)))
         entries.append((name + ".b", bias, (n_pad, 0, 0, 0)))
     entries.append(("heads.bias", np.array([weights["conv2/conv/bias"][0], weights["conv3/conv/bias"][0]], np.float32), (2, 0, 0, 0)))
@@ -159,7 +197,7 @@ def pack_generator(weights: Dict[str, np.ndarray]) -> bytes:
         chunks.append((off, raw))
         off = (off + len(raw) + 255) & ~255
     blob = bytearray(off)
-    blob[:_HEADER.size] = _HEADER.pack(BLOB_MAGIC, BLOB_VERSION, len(entries), 0)
+    blob[:_HEADER.size] = _HEADER.pack(BLOB_MAGIC, BLOB_VERSION, len(entries), DTYPES[dtype])
     blob[_HEADER.size:_HEADER.size + len(table)] = table
     for o, raw in chunks:
         blob[o:o + len(raw)] = raw

@@ -33,14 +33,17 @@ typedef struct bsr_handle bsr_handle;
 #define BSR_ERR_STATE 4    /* probe requested before any forward, unknown probe name, ... */
 
 #define BSR_DTYPE_F32 0
-#define BSR_DTYPE_F16 1     /* BASELINE config 4: fp16 MFMA (fp32 accumulate, fp32 storage) on the 3x3-conv path; the rest stays fp32 */
+#define BSR_DTYPE_F16 1     /* BASELINE configs[3]: fp16 operands (fp32 accumulate, fp32 HBM storage) on the 3x3-conv path via v_mfma_f32_32x32x16_f16; the rest stays fp32 */
+#define BSR_DTYPE_F32X3 2   /* split-precision fp32: every operand of the 3x3-conv path is split into hi + lo fp16 halves at staging time and contracted
+                               with three fp16 matrix instructions (hi.hi + hi.lo + lo.hi, fp32 accumulate): fp32-class accuracy (~2^-22 per product) at
+                               16/3 of the fp32 matrix rate.  Activations / outputs stay fp32.  Requires |activations| < 65504. */
 
 /* Replaces Generator() construction + tf.train.Checkpoint(generator=...).restore(...)
  * (/root/reference/train_test_GSC.py:120, :143-148, :365, :845).
  * packed_weights: HOST pointer to the blob written by blindshadowremoval_amd.pack.pack_generator()
  * (BatchNorm folded, MFMA-friendly layout); it is copied to the device, the caller may free it.
- * dtype: BSR_DTYPE_F32 (the arithmetic type of the measured path) or BSR_DTYPE_F16 (same blob; operands of the 3x3 / stride-2 /
- * transposed 3x3 convolutions are rounded to fp16 in registers and contracted with v_mfma_f32_32x32x8_f16). */
+ * dtype: BSR_DTYPE_F32 (the arithmetic type of the measured path), BSR_DTYPE_F16 or BSR_DTYPE_F32X3; the blob must have been packed
+ * for the same dtype (pack_generator(weights, dtype): the 16-bit modes carry fp16 weight planes for the 3x3-conv layers). */
 int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t nbytes, int dtype);
 
 /* Replaces Generator.call(inputs, uv, reg, chuck, training=False) (/root/reference/model.py:228-290).

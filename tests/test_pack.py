@@ -151,3 +151,34 @@ def test_blob_layout(w):
         bad = dict(w); bad.pop("up1/conv/kernel"); pack.pack_generator(bad)
     with pytest.raises(ValueError):
         bad = dict(w); bad["up1/conv/kernel"] = bad["up1/conv/kernel"].transpose(0, 1, 3, 2); pack.pack_generator(bad)
+
+
+def test_h16_pack_planes_reproduce_the_fp32_weights():
+    """16-bit modes (csrc/igemm_h16.h): row = [cc halves hi | cc halves lo | 8 halves pad]; hi + lo must give back the fp32 weight
+    to ~2^-22 relative (f32x3), hi alone to 2^-11 (f16); the blob header records the dtype."""
+    import struct
+    from blindshadowremoval_amd import pack
+    rng = np.random.default_rng(3)
+    k = rng.standard_normal((9, 40, 70)) * 0.05
+    b = rng.standard_normal(70)
+    arr, bias = pack.pack_taps_h16(k, b, 32, 64, 96, 2)
+    assert arr.shape == (2, 9, 96, 36) and arr.dtype == np.float32 and bias.shape == (96,)
+    halves = arr.view(np.float16).reshape(2, 9, 96, 72)
+    hi, lo, pad = halves[..., :32].astype(np.float64), halves[..., 32:64].astype(np.float64), halves[..., 64:]
+    assert not pad.any()
+    full = np.zeros((9, 64, 96))
+    full[:, :40, :70] = k.astype(np.float32)
+    want = full.reshape(9, 2, 32, 96).transpose(1, 0, 3, 2)
+    assert np.abs(hi + lo - want).max() <= 2.0 ** -21 * np.abs(want).max()
+    assert np.abs(hi - want).max() <= 2.0 ** -11 * np.abs(want).max()
+    arr1, _ = pack.pack_taps_h16(k, b, 32, 64, 96, 1)
+    assert arr1.shape == (2, 9, 96, 20)
+    assert np.array_equal(arr1.view(np.float16).reshape(2, 9, 96, 40)[..., :32], halves[..., :32])
+    w = init_weights(1)
+    for dtype, code in pack.DTYPES.items():
+        blob = pack.pack_generator(w, dtype)
+        assert struct.unpack_from("<4I", blob)[3] == code
+    with pytest.raises(ValueError):
+        pack.pack_generator(init_weights(1, variant="tsm"), "f32x3")
+    with pytest.raises(ValueError):
+        pack.pack_taps_h16(k * 1e7, b, 32, 64, 96, 2)
