@@ -1,0 +1,40 @@
+"""Worker process of the test-time loader (dataset.Dataset(workers=N)): reads pickled jobs from stdin, writes pickled dataset
+elements to stdout, both length-prefixed.  Started as `python -m blindshadowremoval_amd._row_worker`, so it never depends on the
+parent's __main__ module and never imports torch or touches a GPU (numpy / PIL / matplotlib.tri only)."""
+import os
+import pickle
+import struct
+import sys
+
+
+def _read_exact(f, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = f.read(n - len(buf))
+        if not chunk:
+            return None
+        buf += chunk
+    return bytes(buf)
+
+
+def main() -> int:
+    fin = os.fdopen(os.dup(0), "rb")
+    fout = os.fdopen(os.dup(1), "wb")
+    os.dup2(2, 1)                       # anything a library prints goes to stderr, never into the result stream
+    from blindshadowremoval_amd.dataset import build_element
+    while True:
+        head = _read_exact(fin, 8)
+        if head is None:
+            return 0
+        job = pickle.loads(_read_exact(fin, struct.unpack("<Q", head)[0]))
+        try:
+            payload = pickle.dumps(("ok", build_element(job)), protocol=pickle.HIGHEST_PROTOCOL)
+        except Exception as e:          # reported to the parent, which re-raises
+            payload = pickle.dumps(("err", "%s: %s" % (type(e).__name__, e)), protocol=pickle.HIGHEST_PROTOCOL)
+        fout.write(struct.pack("<Q", len(payload)))
+        fout.write(payload)
+        fout.flush()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

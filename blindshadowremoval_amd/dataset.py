@@ -45,11 +45,22 @@ def imread_rgb(path: str) -> np.ndarray:
 
 
 def resize_linear(img: np.ndarray, size: int) -> np.ndarray:
-    """cv2.resize(img, (size, size)) with the default INTER_LINEAR: half-pixel centres, edge clamp, no antialias."""
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(img, np.float64)).permute(2, 0, 1)[None]
-    out = torch.nn.functional.interpolate(t, size=(size, size), mode="bilinear", align_corners=False, antialias=False)
-    return out[0].permute(1, 2, 0).numpy()
+    """cv2.resize(img, (size, size)) with the default INTER_LINEAR: half-pixel centres, edge clamp, no antialias
+    (source coordinate max((o + 0.5) * n / size - 0.5, 0), neighbours clamped to n - 1).  Pure numpy so that the loader's worker
+    processes never import torch."""
+    img = np.ascontiguousarray(img, np.float64)
+
+    def axis(n):
+        src = np.maximum((np.arange(size) + 0.5) * (n / size) - 0.5, 0.0)
+        i0 = np.minimum(np.floor(src).astype(np.int64), n - 1)
+        return i0, np.minimum(i0 + 1, n - 1), src - i0
+    y0, y1, wy = axis(img.shape[0])
+    x0, x1, wx = axis(img.shape[1])
+    wx = wx[None, :, None]
+    top = img[y0][:, x0] * (1 - wx) + img[y0][:, x1] * wx
+    bot = img[y1][:, x0] * (1 - wx) + img[y1][:, x1] * wx
+    wy = wy[:, None, None]
+    return top * (1 - wy) + bot * wy
 
 
 def gaussian_blur5(a: np.ndarray) -> np.ndarray:
@@ -143,15 +154,40 @@ def build_row(img_path: str, lm_path: str, gt_path: Optional[str] = None, size: 
     return np.concatenate([crop, uvm, reg_in, reg_out, face], axis=2).astype(np.float32), np.asarray(box, np.float32)
 
 
+def build_element(job) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """One dataset element `(img[1,R,size,size,16], box[1,4], name[1])` from a job `(lm_path, gt_path, sibling lm paths, size)`.
+    Top-level so that worker processes can run it (the rows of an element never depend on another element)."""
+    lm_path, gt_path, siblings, size = job
+    img_path = os.path.splitext(lm_path)[0] + ".png"
+    row0, box = build_row(img_path, lm_path, gt_path, size)
+    rows = [row0]
+    for sib in siblings:                                               # rows 1..9: random same-folder images (dataset.py:641-762)
+        rows.append(row0 if sib == lm_path else build_row(os.path.splitext(sib)[0] + ".png", sib, gt_path or img_path, size)[0])
+    name = (gt_path or img_path).encode()
+    return np.stack(rows, axis=0)[None], box[None], np.array([name])
+
+
 class Dataset:
     """`Dataset(config, 'test')` counterpart (dataset.py:18-72).  `ucb=True` switches to `parse_fn_test`, whose ground truth
-    comes from the sibling `gt` tree (dataset.py:155)."""
+    comes from the sibling `gt` tree (dataset.py:155).
 
-    def __init__(self, config, mode: str = "test", dset=None, ucb: bool = False, rows: int = 1, seed: int = 0):
+    `workers` / `prefetch` are the counterpart of the reference pipeline's `map(parse_fn, num_parallel_calls=AUTOTUNE).batch(1)
+    .prefetch(AUTOTUNE)` (dataset.py:63-72): with `workers` > 0 elements are prepared by that many worker PROCESSES (the
+    Delaunay interpolations are Python / GIL-bound), up to `prefetch` elements ahead of the consumer, and delivered in
+    `name_list` order with bit-identical contents to the serial path (`workers=0`, the default); `workers=-1` picks
+    min(cpu_count, 16)."""
+
+    def __init__(self, config, mode: str = "test", dset=None, ucb: bool = False, rows: int = 1, seed: int = 0,
+                 workers: int = 0, prefetch: Optional[int] = None):
         if mode != "test" or dset is not None:
             raise NotImplementedError("only the GSC test loaders are provided (training / SFW loaders are out of scope)")
         self.config, self.mode, self.ucb, self.rows = config, mode, ucb, rows
         self._rng = random.Random(seed)
+        if workers < 0:
+            workers = min(os.cpu_count() or 1, 16)
+        self.workers = int(workers)
+        self.prefetch = int(prefetch) if prefetch is not None else max(2, 2 * self.workers)
+        self._pool = None
         self.name_list: List[str] = []
         for d in config.DATA_DIR_TEST:                                     # dataset.py:55-61
             for folder in sorted(glob.glob(d), key=natural_key):
@@ -164,16 +200,112 @@ class Dataset:
         parts = lm_path.replace("\\", "/").split("/")
         return os.path.splitext("/".join(parts[:-3] + ["gt"] + parts[-2:]))[0] + ".png"      # .../train/input/x/y -> .../train/gt/x/y
 
-    def _iterate(self):
+    def _jobs(self):
+        """Jobs in name_list order; the sibling draws consume the seeded RNG in that order whatever the worker count."""
         size = self.config.IMG_SIZE
         for lm_path in self.name_list:
-            img_path = os.path.splitext(lm_path)[0] + ".png"
-            gt_path = self._gt_path(lm_path)
-            row0, box = build_row(img_path, lm_path, gt_path, size)
-            rows = [row0]
-            siblings = sorted(glob.glob(os.path.join(os.path.dirname(lm_path), "*.npy")), key=natural_key)
-            for _ in range(self.rows - 1):                                 # rows 1..9: random same-folder images (dataset.py:641-762)
-                sib = siblings[self._rng.randint(0, len(siblings) - 1)]
-                rows.append(row0 if sib == lm_path else build_row(os.path.splitext(sib)[0] + ".png", sib, gt_path or img_path, size)[0])
-            name = (gt_path or img_path).encode()
-            yield np.stack(rows, axis=0)[None], box[None], np.array([name])
+            sibs = []
+            if self.rows > 1:
+                siblings = sorted(glob.glob(os.path.join(os.path.dirname(lm_path), "*.npy")), key=natural_key)
+                sibs = [siblings[self._rng.randint(0, len(siblings) - 1)] for _ in range(self.rows - 1)]
+            yield (lm_path, self._gt_path(lm_path), sibs, size)
+
+    def close(self) -> None:
+        pool, self._pool = self._pool, None
+        if pool is not None:
+            pool.shutdown()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _iterate(self):
+        jobs = self._jobs()
+        if self.workers <= 0:
+            for job in jobs:
+                yield build_element(job)
+            return
+        import collections
+        self._pool = _WorkerPool(self.workers)
+        try:
+            inflight = collections.deque()
+            for job in jobs:
+                inflight.append(self._pool.submit(job))
+                if len(inflight) >= self.prefetch:
+                    yield inflight.popleft().result()
+            while inflight:
+                yield inflight.popleft().result()
+        finally:
+            self.close()
+
+
+class _WorkerPool:
+    """N worker PROCESSES (`python -m blindshadowremoval_amd._row_worker`), each driven by one thread of a ThreadPoolExecutor
+    over a pair of pipes.  Plain subprocesses instead of multiprocessing: nothing is forked from a process that may hold a GPU
+    context, and the workers do not re-import the parent's __main__."""
+
+    def __init__(self, n: int):
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self._local = threading.local()
+        self._procs = []
+        self._lock = threading.Lock()
+        self._ex = ThreadPoolExecutor(max_workers=n, thread_name_prefix="bsr-row")
+
+    def _proc(self):
+        p = getattr(self._local, "proc", None)
+        if p is None:
+            import subprocess
+            import sys
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env = dict(os.environ)
+            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+            env.setdefault("OMP_NUM_THREADS", "1")
+            env.setdefault("OPENBLAS_NUM_THREADS", "1")
+            p = subprocess.Popen([sys.executable, "-m", "blindshadowremoval_amd._row_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+            self._local.proc = p
+            with self._lock:
+                self._procs.append(p)
+        return p
+
+    def _run(self, job):
+        import pickle
+        import struct
+        p = self._proc()
+        payload = pickle.dumps(job, protocol=pickle.HIGHEST_PROTOCOL)
+        p.stdin.write(struct.pack("<Q", len(payload)) + payload)
+        p.stdin.flush()
+        head = p.stdout.read(8)
+        if len(head) != 8:
+            raise RuntimeError("loader worker exited (code %s)" % p.poll())
+        n = struct.unpack("<Q", head)[0]
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = p.stdout.read(n - len(buf))
+            if not chunk:
+                raise RuntimeError("loader worker closed its pipe mid-result")
+            buf += chunk
+        status, value = pickle.loads(bytes(buf))
+        if status != "ok":
+            raise RuntimeError("loader worker failed: %s" % value)
+        return value
+
+    def submit(self, job):
+        return self._ex.submit(self._run, job)
+
+    def shutdown(self) -> None:
+        self._ex.shutdown(wait=True, cancel_futures=True)
+        with self._lock:
+            procs, self._procs = self._procs, []
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()                # the exact child we started

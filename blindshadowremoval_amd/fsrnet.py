@@ -100,12 +100,13 @@ def _name(x) -> str:
 
 
 class FSRNet(object):
-    def __init__(self, config: Config, weights: Optional[Dict[str, np.ndarray]] = None):
+    def __init__(self, config: Config, weights: Optional[Dict[str, np.ndarray]] = None, dtype: str = "f32"):
         self.config = config
-        self.gen = Generator(device=config.GPU_INDEX if torch.cuda.is_available() else None)
+        self.gen = Generator(device=config.GPU_INDEX if torch.cuda.is_available() else None, dtype=dtype)
         if weights is not None:
             self.gen.load_weights(weights)
         self.log = Logging(config)
+        self.timings: Dict[str, float] = {}      # wall-clock split of the last test / testFFHQ loop (see _loop)
 
     # -- checkpoint -------------------------------------------------------------------------
     def _restore(self) -> int:
@@ -168,28 +169,37 @@ class FSRNet(object):
         names = list(dataset.name_list)
         num_list = len(names)
         results = []
+        # where the loop's wall time goes: waiting for the loader, host->device + forward (+ device->host of what the host
+        # post-processing reads), the reference's UCB post-processing, PNG encoding
+        tm = {"prep_wait_s": 0.0, "forward_s": 0.0, "post_s": 0.0, "png_s": 0.0, "forwards": 0, "items": 0}
+        self.timings = tm
         pending: List[Tuple[int, str, torch.Tensor, object]] = []
         mask_files = self._ucb_masks() if ucb and postprocess else None
-        if mask_files is not None and len(mask_files) < num_list:
-            raise ValueError("FSRNet.test: %d items but only %d mask files" % (num_list, len(mask_files)))
+        if mask_files is not None and len(mask_files) < len(set(names)):
+            raise ValueError("FSRNet.test: %d items but only %d mask files" % (len(set(names)), len(mask_files)))
 
         def flush():
             if not pending:
                 return
+            t0 = time.perf_counter()
             rows = torch.cat([self._split_row0(p[2]) for p in pending], dim=0)
             im, gt, uv, reg, face = torch.split(rows, list(SPLIT_FFHQ), dim=3)
             dev = "cuda:%d" % self.gen._device
             gs, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg, chuck=4 if ucb else 1, training=False)
             if ucb and postprocess:
                 con_h, mask_h = con_rgb.cpu().numpy(), mask_pred.cpu().numpy()
+            torch.cuda.synchronize(self.gen._device)
+            tm["forward_s"] += time.perf_counter() - t0
+            tm["forwards"] += 1
             for j, (step, name, _, box) in enumerate(pending):
                 sl = slice(j, j + 1)
                 losses: Dict[str, float] = {}
+                t1 = time.perf_counter()
                 if ucb and postprocess:                                        # train_test_GSC.py:424-748 on the host
                     from .ucb_post import ucb_postprocess
                     with np.errstate(invalid="ignore", divide="ignore"):
                         losses, f = ucb_postprocess(im[j].numpy(), gt[j].numpy(), con_h[j], mask_h[j], np.asarray(box).reshape(-1)[:4],
-                                                    self._read_masks(mask_files[step]))
+                                                    self._read_masks(mask_files[step % len(mask_files)]))
                     figs = [torch.from_numpy(a) for a in f]
                     shown = figs
                 elif ucb:
@@ -198,18 +208,26 @@ class FSRNet(object):
                 else:
                     figs = [im[sl].to(dev), torch.clamp(con_rgb[sl], 0, 1), mask_pred[sl] * face[sl].to(dev) * 2]
                     shown = figs
+                t2 = time.perf_counter()
                 self.log.display(losses, 0, step, False, num_list)
                 self.log.save_img(shown, name)
+                t3 = time.perf_counter()
+                tm["post_s"] += t2 - t1
+                tm["png_s"] += t3 - t2
+                tm["items"] += 1
                 results.append((name, figs) if not (ucb and postprocess) else (name, figs, losses))
             pending.clear()
 
         for step, img_name in enumerate(names):
+            t0 = time.perf_counter()
             element = next(dataset.feed)
+            tm["prep_wait_s"] += time.perf_counter() - t0
             img = element[0]
             pending.append((step, _name(img_name), img, element[1] if len(element) > 1 else None))
             if len(pending) >= batch:
                 flush()
         flush()
+        tm["total_s"] = time.time() - start
         print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
         return results
 

@@ -1,0 +1,50 @@
+"""End-to-end rate of the reference's test loops on this box (bench.py --loop ffhq|ucb): host input preparation (Dataset, with and
+without the worker pool) -> host-to-device -> generator forward -> the reference's post-processing -> PNG strips, i.e.
+`FSRNet.testFFHQ` (train_test_GSC.py:840-890) / `FSRNet.test` (:360-748) as a user runs them — NOT the `value` of bench.py, which
+times the forward alone on resident inputs.  The fixtures under tests/golden are the reference's own sample data
+(sample_imgs/02165; the first 20 UCB items with their seven masks), repeated to a list of ~100 items (BASELINE configs[2]: the
+UCB test set has 100 items)."""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import shutil
+import tempfile
+import time
+
+from .dataset import Dataset
+from .fsrnet import Config, FSRNet
+from .weights import init_weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def loop_bench(kind: str, gen=None, items: int = 100, batch: int = 16, workers: int = -1, dtype: str = "f32") -> dict:
+    ucb = kind == "ucb"
+    cfg = Config(0)
+    out_dir = tempfile.mkdtemp(prefix="bsr_loop_")
+    cfg.CHECKPOINT_DIR = out_dir
+    cfg.DATA_DIR_TEST = [os.path.join(GOLDEN, "UCB", "train", "input", "*") if ucb else os.path.join(GOLDEN, "sample_imgs", "*")]
+    cfg.UCB_MASK_ROOT = os.path.join(GOLDEN, "UCB_masks")
+    fsr = FSRNet(cfg, weights=init_weights(1), dtype=dtype)
+    res = {"loop": "FSRNet.test (UCB, batch %d, host post-processing + SSIM/PSNR)" % batch if ucb else "FSRNet.testFFHQ (batch %d)" % batch,
+           "dtype": dtype}
+    try:
+        for label, nw in (("serial_loader", 0), ("pooled_loader", workers)):
+            ds = Dataset(cfg, "test", ucb=ucb, workers=nw)
+            base = list(ds.name_list)
+            ds.name_list = (base * ((items + len(base) - 1) // len(base)))[:items]
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                out = fsr.test(ds, batch=batch) if ucb else fsr.testFFHQ(ds, batch=batch)
+            dt = time.perf_counter() - t0
+            tm = dict(fsr.timings)
+            res[label] = {"workers": ds.workers, "items": len(out), "images_per_sec": round(len(out) / dt, 2), "seconds": round(dt, 3),
+                          "split_s": {k: round(v, 3) for k, v in tm.items() if k.endswith("_s")}, "forwards": tm.get("forwards")}
+            ds.close()
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+        fsr.gen.close()
+    return res

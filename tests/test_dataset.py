@@ -91,8 +91,9 @@ def test_config1_end_to_end(tmp_path, golden_dir):
 
 @pytest.mark.gpu
 def test_config3_ucb_miniature(tmp_path, golden_dir):
-    """BASELINE config 3 in miniature: two UCB items (committed as data fixtures) through the UCB loader (ground truth from the
-    sibling gt tree) and FSRNet.test at batch 16; PSNR / SSIM of the HIP outputs against the oracle's ("PSNR vs ref")."""
+    """BASELINE configs[2] (UCB, fsr.test, batch 16): the first 20 UCB items (the reference's own data files, committed as
+    fixtures) through the pooled UCB loader (ground truth from the sibling gt tree) and FSRNet.test at batch 16 — one TRUE B = 16
+    forward plus a ragged B = 4 one; PSNR / SSIM of the HIP outputs against the oracle's ("PSNR vs ref")."""
     import torch
     from blindshadowremoval_amd import metrics as M
     from blindshadowremoval_amd.fsrnet import Config, FSRNet
@@ -102,12 +103,14 @@ def test_config3_ucb_miniature(tmp_path, golden_dir):
     cfg.CHECKPOINT_DIR = str(tmp_path)
     cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
     w = init_weights(1)
-    ds = D.Dataset(cfg, "test", ucb=True)
-    assert len(ds.name_list) == 2
-    res = FSRNet(cfg, weights=w).test(ds, batch=16, postprocess=False)
-    assert len(res) == 2
-    ds2 = D.Dataset(cfg, "test", ucb=True)
-    rows = torch.from_numpy(np.concatenate([next(ds2.feed)[0][0] for _ in range(2)], axis=0))      # [2,256,256,16]
+    N = 20
+    ds = D.Dataset(cfg, "test", ucb=True, workers=4)
+    assert len(ds.name_list) == N
+    fsr = FSRNet(cfg, weights=w)
+    res = fsr.test(ds, batch=16, postprocess=False)
+    assert len(res) == N and fsr.timings["forwards"] == 2 and fsr.timings["items"] == N       # 16 + 4
+    ds2 = D.Dataset(cfg, "test", ucb=True, workers=4)
+    rows = torch.from_numpy(np.concatenate([next(ds2.feed)[0][0] for _ in range(N)], axis=0))      # [20,256,256,16]
     assert not torch.equal(rows[..., 0:3], rows[..., 3:6])                                          # gt differs from the shadowed input
     img, gt, uv, reg, face = torch.split(rows, [3, 3, 3, 6, 1], dim=3)
     oracle = GeneratorOracle(w)
@@ -124,15 +127,56 @@ def test_config3_ucb_miniature(tmp_path, golden_dir):
     # the whole UCB step (generator + the reference's host post-processing, train_test_GSC.py:411-748) against the same
     # post-processing applied to the ORACLE's generator outputs: identical shadow masks, SSIM / PSNR within 1e-3
     from blindshadowremoval_amd.ucb_post import ucb_postprocess
-    from ucb_cases import ITEMS, load_masks
     cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
-    full = FSRNet(cfg, weights=w).test(D.Dataset(cfg, "test", ucb=True), batch=16)
+    fsr2 = FSRNet(cfg, weights=w)
+    full = fsr2.test(D.Dataset(cfg, "test", ucb=True, workers=4), batch=16)
+    assert len(full) == N
     ds3 = D.Dataset(cfg, "test", ucb=True)
+    mask_files = fsr2._ucb_masks()
     for j, (name, figs, losses) in enumerate(full):
         box = np.asarray(next(ds3.feed)[1]).reshape(-1)
+        stem = os.path.basename(name).split(".")[0]                                               # e.g. 9157-022
+        assert os.path.basename(mask_files[j]["face_hair"]) == "%s_%s-result.png" % (stem.split("-")[0], stem)      # masks pair up with items by order
         with np.errstate(invalid="ignore", divide="ignore"):
-            ref_losses, ref_figs = ucb_postprocess(img[j].numpy(), gt[j].numpy(), ref_rgb[j].numpy(), ref_dif[j].numpy(), box, load_masks(ITEMS[j]))
+            ref_losses, ref_figs = ucb_postprocess(img[j].numpy(), gt[j].numpy(), ref_rgb[j].numpy(), ref_dif[j].numpy(), box, fsr2._read_masks(mask_files[j]))
         assert len(figs) == 7 and figs[4].shape == (1, 256, 256, 3)
         assert int((figs[4].numpy() != ref_figs[4]).sum()) <= 3 * 4          # at most a few pixels may sit on a threshold
         for k in ("ssim", "psnr"):
             assert np.isfinite(losses[k]) and abs(losses[k] - ref_losses[k]) < 1e-3 * max(1.0, abs(ref_losses[k]))
+
+
+def test_pooled_loader_matches_serial_bit_for_bit(golden_dir):
+    """Dataset(workers=N): worker processes + prefetch (counterpart of map(num_parallel_calls=AUTOTUNE).prefetch,
+    /root/reference/dataset.py:63-72) must deliver the same elements in the same order as the serial path, sibling draws
+    (rows > 1) included."""
+    cfg = type("C", (), {"DATA_DIR_TEST": [os.path.join(golden_dir, "UCB", "train", "input", "*")], "IMG_SIZE": 256})()
+    serial = D.Dataset(cfg, "test", ucb=True, rows=2, seed=5)
+    pooled = D.Dataset(cfg, "test", ucb=True, rows=2, seed=5, workers=3, prefetch=4)
+    assert serial.name_list == pooled.name_list and len(serial.name_list) == 20
+    serial.name_list = serial.name_list[:7]
+    pooled.name_list = pooled.name_list[:7]
+    n = 0
+    for a, b in zip(serial.feed, pooled.feed):
+        assert a[0].shape == (1, 2, 256, 256, 16) and a[0].dtype == np.float32
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2][0] == b[2][0]
+        n += 1
+    assert n == 7
+    with pytest.raises(StopIteration):
+        next(pooled.feed)
+    assert pooled._pool is None                              # workers are shut down when the list is exhausted
+    # a failing job surfaces as an exception in the consumer, not a hang
+    bad = D.Dataset(cfg, "test", ucb=True, workers=2)
+    bad.name_list = [os.path.join(golden_dir, "UCB", "train", "input", "9156", "missing.npy")]
+    with pytest.raises(RuntimeError, match="loader worker failed"):
+        next(bad.feed)
+
+
+def test_resize_linear_is_opencv_inter_linear():
+    """numpy restatement of cv2.resize(INTER_LINEAR) against torch's half-pixel bilinear (both directions of scale)."""
+    import torch
+    rng = np.random.default_rng(0)
+    for n in (300, 200, 256):
+        a = rng.random((n, n, 6))
+        t = torch.from_numpy(a).permute(2, 0, 1)[None]
+        want = torch.nn.functional.interpolate(t, size=(256, 256), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(D.resize_linear(a, 256) - want).max() < 1e-12
