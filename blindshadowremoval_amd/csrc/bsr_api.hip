@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "attention.h"
+#include "attention_x3.h"
 #include "conv_n16.h"
 #include "gemm_nloop.h"
 #include "glue_kernels.h"
@@ -85,7 +86,7 @@ struct Variant {
 };
 constexpr Variant kGSC{false, 99, 120, 96, 257, 264, 261, 264, 258};
 // 16-bit matrix-core modes (BSR_DTYPE_F16 / BSR_DTYPE_F32X3): K chunks are 32 channels, so the 257 / 261-wide tensors get stride 288
-constexpr Variant kGSC16{false, 99, 120, 96, 257, 288, 261, 288, 258};
+constexpr Variant kGSC16{false, 99, 128, 96, 257, 288, 261, 288, 258};
 constexpr Variant kTSM{true, 291, 312, 288, 291, 312, 877, 888, 874};
 constexpr int CS_CF = 64;    // f = clr_up3 output; the gs channel of cat[gs, f] (model.py:267) is read from the gs output
 
@@ -200,13 +201,16 @@ struct Launcher {
     if (rc != BSR_OK) return;
     using C = bsr::ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
     constexpr bool k33 = (KH == 3 && KW == 3);
-    constexpr int CCH = k33 ? (CC == 24 ? 32 : CC) : 16;          // K chunk of the 16-bit kernels (multiple of 16)
-    const bool h16 = k33 && h->dtype != BSR_DTYPE_F32;
+    constexpr bool k11 = (KH == 1 && KW == 1);
+    constexpr int CCH = CC == 24 ? 32 : CC;                       // K chunk of the 16-bit kernels (multiple of 16)
+    const bool h16 = h->dtype != BSR_DTYPE_F32;
+    // 16-bit modes: the 3x3-conv layers take fp16 operands (f16) or hi/lo planes (f32x3); the 1x1 layers are split-precision in both
+    const int nsplit = (k33 && h->dtype == BSR_DTYPE_F16) ? 1 : 2;
     LayerW l;
     const int nb = (n_store + C::BN - 1) / C::BN;
     if (h16) {
       if (k_pad % CCH != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': K is not a multiple of the 16-bit kernels' chunk"); return; }
-      rc = find_layer(h, name, k_pad / CCH, KH * KW, ((h->dtype == BSR_DTYPE_F32X3 ? 2 : 1) * CCH + 8) / 2, nb * C::BN, &l);
+      rc = find_layer(h, name, k_pad / CCH, KH * KW, (nsplit * CCH + 8) / 2, nb * C::BN, &l);
     } else {
       rc = find_layer(h, name, k_pad / CC, KH * KW, CC + 4, nb * C::BN, &l);
     }
@@ -231,16 +235,13 @@ struct Launcher {
       return;
     }
     begin(cls, name);
-    if constexpr (k33) {
-      if (h->dtype == BSR_DTYPE_F32X3)
-        check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 2>(a, h->B, s), name);
-      else if (h->dtype == BSR_DTYPE_F16)
-        check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1>(a, h->B, s), name);
-      else
-        check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
-    } else {
+    static_assert(k33 || k11, "igemm layers are 3x3 or 1x1");
+    if (!h16)
       check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
-    }
+    else if (nsplit == 2)
+      check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 2>(a, h->B, s), name);
+    else if constexpr (k33)
+      check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1>(a, h->B, s), name);
     end();
   }
   // 1x1 conv as a resident-activation GEMM (K = NCH*32) over all N
@@ -262,7 +263,10 @@ struct Launcher {
     a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c;
     a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
     begin(cls, name);
-    check(bsr::launch_gemm_nloop<NI, NCH>(a, pixels, kNSplit, s), name);
+    if (h->dtype == BSR_DTYPE_F32)
+      check(bsr::launch_gemm_nloop<NI, NCH, 0>(a, pixels, kNSplit, s), name);
+    else
+      check(bsr::launch_gemm_nloop<NI, NCH, 2>(a, pixels, kNSplit, s), name);      // split-precision in both 16-bit modes
     end();
   }
 
@@ -280,7 +284,10 @@ struct Launcher {
     a.gs = gs; a.w_gs = h->clr_gs_w; a.tail_w = h->tail_w; a.inputs = inputs; a.con_rgb = con_rgb; a.dif = dif;
     if (H % (4 * RW) != 0 || W % 32 != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': image is not a multiple of its tile"); return; }
     begin(cls, name);
-    check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW>(a, h->B, s), name);
+    if (h->dtype == BSR_DTYPE_F32)
+      check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW, 0>(a, h->B, s), name);
+    else
+      check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW, 2>(a, h->B, s), name);      // split precision in both 16-bit modes
     end();
   }
 };
@@ -543,7 +550,10 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     if (L.rc == BSR_OK) {
       snprintf(nm, sizeof nm, "res%d.attention", i);
       L.begin(K_ATT, nm);
-      L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
+      if (h->dtype == BSR_DTYPE_F32)
+        L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
+      else
+        L.check(bsr::launch_nonlocal_attention_x3(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention_x3");
       L.end();
     }
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att)))
@@ -602,11 +612,20 @@ int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const f
   return forward_impl(h, inputs, uv, reg, frame, share != 0, B, H, W, gs, con_rgb, mask22, dif, stream);
 }
 
-int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream) {
+int bsr_debug_attention_dtype(const float* qkv, float* y, int B, int tokens, int dtype, void* stream) {
   if (qkv == nullptr || y == nullptr) return fail(BSR_ERR_ARG, "bsr_debug_attention: null argument");
   if (B <= 0 || tokens <= 0 || tokens % 128 != 0) return fail(BSR_ERR_ARG, "bsr_debug_attention: tokens must be a positive multiple of 128");
-  HIP_TRY(bsr::launch_nonlocal_attention(qkv, y, B, tokens, static_cast<hipStream_t>(stream)));
+  if (dtype == BSR_DTYPE_F32)
+    HIP_TRY(bsr::launch_nonlocal_attention(qkv, y, B, tokens, static_cast<hipStream_t>(stream)));
+  else if (dtype == BSR_DTYPE_F32X3 || dtype == BSR_DTYPE_F16)
+    HIP_TRY(bsr::launch_nonlocal_attention_x3(qkv, y, B, tokens, static_cast<hipStream_t>(stream)));
+  else
+    return fail(BSR_ERR_ARG, "bsr_debug_attention: unknown dtype");
   return BSR_OK;
+}
+
+int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream) {
+  return bsr_debug_attention_dtype(qkv, y, B, tokens, BSR_DTYPE_F32, stream);
 }
 
 int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream) {

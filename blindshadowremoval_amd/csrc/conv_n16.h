@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "igemm_conv.h"
+#include "igemm_h16.h"
 
 namespace bsr {
 
@@ -52,7 +53,12 @@ struct ConvN16Cfg {
   static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
 };
 
-template <int KH, int KW, bool GS, bool TAIL, int RW>
+// H = 0: fp32 matrix cores (v_mfma_f32_16x16x4_f32).  H = 2: split precision on v_mfma_f32_16x16x32_f16 (igemm_h16.h): the
+// LDS row of a pixel / output channel keeps its 36 words but holds [32 hi halves | 32 lo halves | pad]; activations are split
+// when the staged registers are written to LDS, the weight image is pack_taps_h16's, and one tap of a 32-channel chunk is ONE
+// K = 32 step of three instructions (hi.hi + hi.lo + lo.hi) instead of eight fp32 ones.  Lane (r = l & 15, q = l >> 4) holds
+// k = 8q .. 8q+7 of A and B; C/D is the fp32 instruction's layout, so the gs K group and the fused 1x1 tail stay as they are.
+template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0>
 __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, TW = C::TW, TH = C::TH, MT = C::MT;
@@ -115,11 +121,27 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
       regs[C::IH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_h, (unsigned)(ch * 32) * 4u, 0));
     }
   };
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  auto put = [&](char* dst_f32, char* dst_h16, const f32x4& v) {      // 4 channels of one pixel: fp32, or hi | lo fp16 planes
+    if constexpr (H == 0) {
+      *reinterpret_cast<f32x4*>(dst_f32) = v;
+    } else {
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)v[e];
+        lo[e] = (_Float16)(v[e] - (float)hi[e]);
+      }
+      *reinterpret_cast<f16x4*>(dst_h16) = hi;
+      *reinterpret_cast<f16x4*>(dst_h16 + 64) = lo;
+    }
+  };
+  const unsigned lds_m16 = (unsigned)(pxm * LDP * 4 + c4 * 8), lds_h16 = (unsigned)((hrow * IW + hcol) * LDP * 4 + c4 * 8);
   auto store_in = [&](const f32x4 (&regs)[C::IN_PER_THREAD]) {
     char* base = reinterpret_cast<char*>(s_in);
 #pragma unroll
-    for (int row = 0; row < C::IH; ++row) *reinterpret_cast<f32x4*>(base + lds_m + row * IW * LDP * 4) = regs[row];
-    if (HALO_W && tid < HALO_V4) *reinterpret_cast<f32x4*>(base + lds_h) = regs[C::IH];
+    for (int row = 0; row < C::IH; ++row) put(base + lds_m + row * IW * LDP * 4, base + lds_m16 + row * IW * LDP * 4, regs[row]);
+    if (HALO_W && tid < HALO_V4) put(base + lds_h, base + lds_h16, regs[C::IH]);
   };
   auto fetch_w = [&](int ch, f32x4 (&regs)[C::W_PER_THREAD]) {
     const float* src = p.w + (size_t)ch * C::W_FLOATS;
@@ -226,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
         if (GS) fetch_gs(nxt, gs_regs);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (H == 0) {
       f32x4 wf[2], xf[2][MT];
       wf[0] = *reinterpret_cast<const f32x4*>(s_w + w_base);
 #pragma unroll
@@ -246,6 +269,39 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cu][j], xf[cu][mt][j], acc[mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+      }
+      } else {
+      // one K = 32 step per tap: A = weight row r, k = 8q..8q+7 (16 bytes of the hi plane, lo plane 64 bytes further), B = pixel r
+      f16x8 wh[2], wl[2], xh[2][MT], xl[2][MT];
+      wh[0] = *reinterpret_cast<const f16x8*>(s_w + w_base);
+      wl[0] = *reinterpret_cast<const f16x8*>(s_w + w_base + 16);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        xh[0][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt]);
+        xl[0][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + 16);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int cu = t & 1, nx = cu ^ 1;
+        if (t + 1 < T) {
+          const int tn = t + 1;
+          wh[nx] = *reinterpret_cast<const f16x8*>(s_w + w_base + tn * 16 * LDP);
+          wl[nx] = *reinterpret_cast<const f16x8*>(s_w + w_base + tn * 16 * LDP + 16);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            xh[nx][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + ((tn / KW) * IW + (tn % KW)) * LDP);
+            xl[nx][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + ((tn / KW) * IW + (tn % KW)) * LDP + 16);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[cu], xh[cu][mt], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xl[cu][mt], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xh[cu][mt], acc[mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       }
       if (ch == 1 && GS) {   // the gs channel: K group k = 4q + j <-> tap (k/3, k%3), k < 9
 #pragma unroll
@@ -329,10 +385,10 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #endif
 }
 
-template <int KH, int KW, bool GS, bool TAIL, int RW>
+template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0>
 inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream) {
   using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
-  auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW>;
+  auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW, H>;
   static PerDeviceOnce once;               // .value = workgroups the device holds at once (2 per CU: LDS-bound)
   const int dev = PerDeviceOnce::current();
   int resident = dev >= 0 && once.done[dev] ? once.value[dev] : 0;

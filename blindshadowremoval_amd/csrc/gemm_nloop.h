@@ -11,12 +11,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "igemm_conv.h"
+#include "igemm_h16.h"
 
 namespace bsr {
 
-template <int NI, int NCH>   // NI 32-wide channel tiles per group, NCH = K / 32
+// H = 0: fp32 matrix cores (v_mfma_f32_32x32x2_f32).  H = 2 / 1: 16-bit matrix cores as in igemm_h16.h — the A fragments are split
+// into hi / lo fp16 planes once, when they are loaded into registers; the weight image is the fp16 one of pack_taps_h16 (for
+// H = 2 it has the same 36-word rows as the fp32 image), and a 16-channel K group costs 3 (f32x3) or 1 (f16) v_mfma_f32_32x32x16_f16.
+template <int NI, int NCH, int H = 0>   // NI 32-wide channel tiles per group, NCH = K / 32
 struct GemmNLoopCfg {
-  static constexpr int CC = 32, LDP = 36, G = 4, BM = 128, BN = NI * 32;
+  static constexpr int CC = 32, LDP = (H == 1 ? 20 : 36), G = (H ? 2 : 4), LO = 16, BM = 128, BN = NI * 32;
   static constexpr int W_FLOATS = BN * LDP;
   static constexpr int MAX_TILES = 24;                        // tiles per blockIdx.y range (bias staged in LDS)
   static constexpr int SMEM_BYTES = (3 * W_FLOATS + MAX_TILES * 32) * 4;
@@ -27,9 +31,9 @@ struct GemmNLoopCfg {
 // ConvArgs use: in/in_cs/in_coff (K = NCH*32 channels), pixels flattened (multiple of 128),
 // w packed [NCH][1][n_pad][36] with n_pad >= 32 * (tiles + NI - 1), bias[n_pad], out/out_cs/out_coff/n_store
 // (+ out2/n_split/n_store1), act, res1 (one residual, channels [0, res1_c)).  tiles_x = tiles per blockIdx.y range.
-template <int NI, int NCH>
+template <int NI, int NCH, int H = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
-  using C = GemmNLoopCfg<NI, NCH>;
+  using C = GemmNLoopCfg<NI, NCH, H>;
   constexpr int LDP = C::LDP, G = C::G;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_w = smem;
@@ -82,11 +86,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   f32x4 w_regs[C::W_PER_THREAD], w_regs1[C::W_PER_THREAD];
   fetch_w(0, w_regs);
   if (nsteps > 1) fetch_w(1, w_regs1);
-  f32x4 afr[NCH * G];
-  {
+  f32x4 afr[H ? 1 : NCH * G];
+  f16x8 ahi[H ? NCH * G : 1], alo[H == 2 ? NCH * G : 1];
+  if constexpr (H == 0) {
     const float* row = p.in + (pix0 + wave * 32 + r) * p.in_cs + p.in_coff + 4 * h;
 #pragma unroll
     for (int g = 0; g < NCH * G; ++g) afr[g] = *reinterpret_cast<const f32x4*>(row + g * 8);
+  } else {          // channels 16g + 8h .. +7 of this lane's pixel: the A operand map of v_mfma_f32_32x32x16_f16
+    const float* row = p.in + (pix0 + wave * 32 + r) * p.in_cs + p.in_coff + 8 * h;
+    f32x4 raw[2 * NCH * G];
+#pragma unroll
+    for (int g = 0; g < NCH * G; ++g) {
+      raw[2 * g] = *reinterpret_cast<const f32x4*>(row + g * 16);
+      raw[2 * g + 1] = *reinterpret_cast<const f32x4*>(row + g * 16 + 4);
+    }
+#pragma unroll
+    for (int g = 0; g < NCH * G; ++g) {
+      f16x8 hi, lo;
+      split8(raw[2 * g], raw[2 * g + 1], hi, lo);
+      ahi[g] = hi;
+      if (H == 2) alo[g] = lo;
+    }
   }
   for (int i = tid; i < (t1 - t0) * 32; i += 256) s_bias[i] = p.bias[t0 * 32 + i];   // keeps bias loads out of the MFMA loop's vmcnt queue
   store_w(0, w_regs);
@@ -94,10 +114,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   __syncthreads();
 
   int w_cur = 0, w_n1 = C::W_FLOATS, w_n2 = 2 * C::W_FLOATS;
-  f32x4 bf[2][NI];
+  f32x4 bf[2][H ? 1 : NI];
+  f16x8 bh[2][H ? NI : 1], bl[2][H == 2 ? NI : 1];
   auto read_frags = [&](int slot, int b_off) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_w + b_base[ni] + b_off);
+    for (int ni = 0; ni < NI; ++ni) {
+      if constexpr (H == 0) {
+        bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_w + b_base[ni] + b_off);
+      } else {
+        bh[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + b_off);
+        if constexpr (H == 2) bl[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + b_off + C::LO);
+      }
+    }
   };
   read_frags(0, w_cur);
   __builtin_amdgcn_s_setprio(0);
@@ -142,12 +170,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
         }
         if (g == G - 1 && has2) store_w(w_n2, w_regs);
         __builtin_amdgcn_sched_barrier(0);
-        const f32x4 a = afr[ch * G + g];
+        if constexpr (H == 0) {
+          const f32x4 a = afr[ch * G + g];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          if (ni < nvalid) {
+          for (int ni = 0; ni < NI; ++ni) {
+            if (ni < nvalid) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[cur][ni][j], acc[ni], 0, 0, 0);
+              for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[cur][ni][j], acc[ni], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if (ni < nvalid) {
+              if constexpr (H == 2) {
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ch * G + g], bh[cur][ni], acc[ni], 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ch * G + g], bl[cur][ni], acc[ni], 0, 0, 0);
+              }
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ch * G + g], bh[cur][ni], acc[ni], 0, 0, 0);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -212,10 +253,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
 #endif
 }
 
-template <int NI, int NCH>
+template <int NI, int NCH, int H = 0>
 inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, int nsplit, hipStream_t stream) {
-  using C = GemmNLoopCfg<NI, NCH>;
-  auto kern = gemm_nloop_kernel<NI, NCH>;
+  using C = GemmNLoopCfg<NI, NCH, H>;
+  auto kern = gemm_nloop_kernel<NI, NCH, H>;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {

@@ -28,6 +28,12 @@ namespace bsr {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt = simm16[15:14 | 3:0], expcnt [6:4], lgkmcnt [11:8])
+constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+// vmcnt <= n AND lgkmcnt == 0 (every LDS access of this wave done): what a workgroup barrier needs while LDS-DMAs stay in flight.
+// __syncthreads() cannot be used there: hipcc drains vmcnt to 0 in front of it as soon as a global_load_lds is outstanding.
+constexpr int waitcnt_vm_lgkm0(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4); }
+
 template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>
 struct H16Cfg {
   static constexpr int T = KH * KW;
@@ -41,7 +47,16 @@ struct H16Cfg {
   static constexpr int NPH = TR ? 4 : 1;
   static constexpr int IN_WORDS = IH * IW * LDP;
   static constexpr int W_WORDS = BN * LDP;
-  static constexpr int SMEM_BYTES = (INB * IN_WORDS + 3 * W_WORDS) * 4;
+  // Weights by LDS-DMA (multi-tap layers): with 16-bit operands a (chunk, tap) step is only NI * G * NSPLIT' matrix instructions
+  // long (a few hundred cycles), far less than an L2 round trip, so the register-staged ring of igemm_conv.h (load at the start
+  // of a step, ds_write at its end) exposes the load latency on every step.  global_load_lds_dwordx4 copies the packed image
+  // straight into a 4-slot LDS ring THREE steps ahead, needs no registers, and stays in flight across two barriers.
+  static constexpr bool DMAW = T > 1;
+  static constexpr int W_CHUNKS = (W_WORDS * 4 + 1023) / 1024;   // 1 KiB = one wave-instruction of 64 lanes x 16 B
+  static constexpr int W_DMA_PER_WAVE = (W_CHUNKS + 3) / 4;
+  static constexpr int W_SLOT_WORDS = DMAW ? W_CHUNKS * 256 : W_WORDS;
+  static constexpr int W_SLOTS = DMAW ? 4 : 3;
+  static constexpr int SMEM_BYTES = (INB * IN_WORDS + W_SLOTS * W_SLOT_WORDS) * 4;
   static constexpr int IN_V8 = IH * IW * (CC / 8);               // 8-channel (32-byte) pieces of one input-tile chunk
   static constexpr int IN_PER_THREAD = (IN_V8 + 255) / 256;
   static constexpr int W_V4 = W_WORDS / 4;
@@ -176,27 +191,60 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     }
   };
 
+  // LDS-DMA of one step's weight image into ring slot `off`: wave w copies 1-KiB pieces w, w+4, ... (a piece index past the
+  // image re-copies the last piece; a last piece shorter than 1 KiB spills into the slot's padding with clamped sources)
+  constexpr bool DMAW = C::DMAW;
+  unsigned dma_src[C::W_DMA_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < C::W_DMA_PER_WAVE; ++i) {
+    const int c = min(wave + 4 * i, C::W_CHUNKS - 1);
+    dma_src[i] = (unsigned)min(c * 1024 + lane * 16, C::W_WORDS * 4 - 16);
+  }
+  auto dma_w = [&](int step, int off) {
+    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDP);
+#pragma unroll
+    for (int i = 0; i < C::W_DMA_PER_WAVE; ++i) {
+      const int c = min(wave + 4 * i, C::W_CHUNKS - 1);                              // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_src[i]),
+                                       (__attribute__((address_space(3))) void*)(s_w + off + c * 256), 16, 0, 0);
+    }
+  };
+
+#ifdef BSR_STAMPS
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0;
+  unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   f32x4 in_regs[2 * C::IN_PER_THREAD];
   f32x4 w_regs[C::W_PER_THREAD];
   const int nsteps = p.nchunk * T;
 
-  int w_cur = 0, w_n1 = C::W_WORDS, w_n2 = 2 * C::W_WORDS;
+  int w_cur = 0, w_n1 = C::W_SLOT_WORDS, w_n2 = 2 * C::W_SLOT_WORDS, w_n3 = 3 * C::W_SLOT_WORDS;
   int in_cur = 0, in_n1 = (INB > 1) ? C::IN_WORDS : 0, in_n2 = (INB > 2) ? 2 * C::IN_WORDS : 0;
 
-  // prologue: steps 0 and 1 staged synchronously
-  fetch_in(0, in_regs);
-  fetch_w(0, w_regs);
-  store_in(0, in_regs);
-  store_w(0, w_regs);
-  if (nsteps > 1) {
-    fetch_w(1, w_regs);
-    store_w(w_n1, w_regs);
-    if (T == 1 && INB == 3) {
-      fetch_in(1, in_regs);
-      store_in(in_n1, in_regs);
+  // prologue: the first steps staged synchronously
+  if constexpr (DMAW) {
+    dma_w(0, w_cur);
+    if (nsteps > 1) dma_w(1, w_n1);
+    if (nsteps > 2) dma_w(2, w_n2);
+    fetch_in(0, in_regs);
+    store_in(0, in_regs);
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __syncthreads();
+  } else {
+    fetch_in(0, in_regs);
+    fetch_w(0, w_regs);
+    store_in(0, in_regs);
+    store_w(0, w_regs);
+    if (nsteps > 1) {
+      fetch_w(1, w_regs);
+      store_w(w_n1, w_regs);
+      if (T == 1 && INB == 3) {
+        fetch_in(1, in_regs);
+        store_in(in_n1, in_regs);
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
 
   f16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
   auto read_frags = [&](int slot, int a_off, int b_off) {
@@ -220,6 +268,9 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   };
   read_frags(0, in_cur + tap_offset(0), w_cur);
   __builtin_amdgcn_s_setprio(0);
+#ifdef BSR_STAMPS
+  st1 = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int ch = 0; ch < p.nchunk; ++ch) {
     const bool more = ch + 1 < p.nchunk;
@@ -232,7 +283,12 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
       constexpr int kInStoreTap = (INB == 2) ? T - 2 : T - 1;
       const bool fetch_now = kRing1x1 ? has2 : (T > 1 && t == kInFetchTap && more);
       const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == kInStoreTap && more);
-      if (has2) fetch_w(s + 2, w_regs);
+      const bool has3 = s + 3 < nsteps;
+      if constexpr (DMAW) {
+        if (has3) dma_w(s + 3, w_n3);
+      } else {
+        if (has2) fetch_w(s + 2, w_regs);
+      }
       if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs);
       __builtin_amdgcn_sched_barrier(0);
 
@@ -249,7 +305,9 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
           if (has1) read_frags(nxt, in_n1 + tap_offset(0), w_n1);
         }
         if (g == G - 1) {                                                           // write point: stage step s+2
-          if (has2) store_w(w_n2, w_regs);
+          if constexpr (!DMAW) {
+            if (has2) store_w(w_n2, w_regs);
+          }
           if (stage_in) store_in(kRing1x1 ? in_n2 : in_n1, in_regs);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -267,13 +325,37 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
 
-      __syncthreads();
+      if constexpr (DMAW) {
+        // The image of step s+2 (DMA issued at the top of step s-1) must have landed before this barrier publishes it.  vmcnt
+        // retires in issue order: younger than that DMA are this step's DMA (step s+3) and an input-tile fetch issued in this or
+        // the previous step; they may stay in flight.
+        constexpr int NW = C::W_DMA_PER_WAVE, NIN = 2 * C::IN_PER_THREAD;
+        const bool near_fetch = T > 1 && (t == kInFetchTap || t == kInFetchTap + 1);      // compile-time once t is unrolled
+        if (!has3) {
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
+        } else if (near_fetch && more) {
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW + NIN));
+        } else {
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW));
+        }
+        __builtin_amdgcn_s_barrier();
+      } else {
+        __syncthreads();
+      }
       if (INB == 1 && t == T - 1 && more) {
         store_in(0, in_regs);
-        __syncthreads();
+        if constexpr (DMAW) {
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(C::W_DMA_PER_WAVE));      // the tile's ds_writes are done; this step's DMA may stay in flight
+          __builtin_amdgcn_s_barrier();
+        } else {
+          __syncthreads();
+        }
         read_frags(((T * G) & 1), tap_offset(0), w_n1);
       }
-      {
+      if constexpr (DMAW) {
+        const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = w_n3; w_n3 = tw;
+        if (T > 1 && INB == 2 && t == T - 1) { const int ti = in_cur; in_cur = in_n1; in_n1 = ti; }
+      } else {
         const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = tw;
         if (T == 1 && INB == 3) { const int ti = in_cur; in_cur = in_n1; in_n1 = in_n2; in_n2 = ti; }
         if (T > 1 && INB == 2 && t == T - 1) { const int ti = in_cur; in_cur = in_n1; in_n1 = ti; }
@@ -288,6 +370,9 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   }
 
   __builtin_amdgcn_s_setprio(3);
+#ifdef BSR_STAMPS
+  st2 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: identical to igemm_conv_kernel's (bias is already in the accumulator; LeakyReLU; NHWC raw-buffer stores) ----
   static_assert(TW == 32, "epilogue assumes one tile row per 32-pixel MFMA tile");
   constexpr int SX = TR ? 2 : 1;
@@ -320,6 +405,16 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, voff, soff, 0);
         }
       }
+#ifdef BSR_STAMPS
+  unsigned long long st2b = __builtin_amdgcn_s_memtime();
+  if (p.stamps != nullptr && lane == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* d = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+    unsigned long long rt3 = __builtin_amdgcn_s_memrealtime();
+    d[0] = st1 - st0; d[1] = st2 - st1; d[2] = ((rt3 - rt0) << 32) | (st2b - st2); d[3] = st3 - st2;
+  }
+#endif
 }
 
 template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>

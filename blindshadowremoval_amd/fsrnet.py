@@ -54,10 +54,15 @@ class Config(object):
 class Logging(object):
     """utils.Logging counterpart (utils.py:127-253): running-mean text + PNG strips."""
 
-    def __init__(self, config: Config):
+    def __init__(self, config: Config, png_threads: int = 4):
         self.config = config
         self.losses: Dict[str, List[float]] = {}
         self.saved: List[str] = []
+        # PNG encoding (zlib) releases the GIL: strips are encoded by a few background threads while the loop goes on;
+        # flush() — called by the loops before they return — waits for them
+        self._png_threads = png_threads
+        self._pool = None
+        self._pending: List = []
 
     def display(self, losses: Dict[str, float], epoch: int, step: int, training: bool, allstep: int) -> None:
         for k, v in losses.items():
@@ -85,10 +90,26 @@ class Logging(object):
         stem = (parts[-2] + '_' if len(parts) > 1 else '') + parts[-1].split('.')[0]
         out = os.path.join(self.config.CHECKPOINT_DIR, 'test', stem + '-result.png')
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        from PIL import Image
-        Image.fromarray(strip).save(out)
         self.saved.append(out)
+        if self._png_threads > 0:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self._png_threads, thread_name_prefix="bsr-png")
+            self._pending.append(self._pool.submit(self._write_png, strip, out))
+        else:
+            self._write_png(strip, out)
         return out
+
+    @staticmethod
+    def _write_png(strip: np.ndarray, out: str) -> None:
+        from PIL import Image
+        Image.fromarray(strip).save(out, compress_level=1)        # cv2.imwrite's default PNG compression is 1 (fastest); pixels are identical
+
+    def flush(self) -> None:
+        """Wait for every queued PNG (re-raises a writer's exception)."""
+        pending, self._pending = self._pending, []
+        for f in pending:
+            f.result()
 
 
 def _name(x) -> str:
@@ -227,6 +248,9 @@ class FSRNet(object):
             if len(pending) >= batch:
                 flush()
         flush()
+        t0 = time.perf_counter()
+        self.log.flush()
+        tm["png_s"] += time.perf_counter() - t0
         tm["total_s"] = time.time() - start
         print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
         return results
@@ -326,6 +350,7 @@ class FSRNetTSM(object):
             self.log.display(losses, 0, step, False, len(names))
             self.log.save_img(figs, _name(img_name))
             results.append((_name(img_name), losses, figs))
+        self.log.flush()
         print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
         return results
 

@@ -29,6 +29,8 @@ TRANSPOSED = ("up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3")
 DTYPES = {"f32": 0, "f16": 1, "f32x3": 2}     # BSR_DTYPE_* of include/bsr_hip.h
 # layers the 16-bit modes run on igemm_h16_kernel (csrc/igemm_h16.h): every 3x3 / stride-2 3x3 / transposed 3x3 igemm layer
 H16_LAYERS = ("down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3") + tuple("res%d.conv2" % i for i in range(6))
+# 1x1 layers (igemm_h16_kernel<1,1> / gemm_nloop_kernel<.., H = 2>): split-precision (hi + lo planes) in BOTH 16-bit modes
+X3_LAYERS = tuple("res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w")) + ("heads", "clr_conv1")      # + conv_n16_kernel<.., H = 2>
 
 
 def geometry(variant: str = "gsc", dtype: str = "f32") -> Dict[str, Tuple[int, int, int]]:
@@ -39,7 +41,7 @@ def geometry(variant: str = "gsc", dtype: str = "f32") -> Dict[str, Tuple[int, i
     h16 = dtype != "f32"
     if tsm and h16:
         raise ValueError("the TSM variant is packed for dtype 'f32' only")
-    k_a, k_r, k_h = (312, 312, 888) if tsm else ((120, 288, 288) if h16 else (120, 264, 264))
+    k_a, k_r, k_h = (312, 312, 888) if tsm else ((128, 288, 288) if h16 else (120, 264, 264))
     cu = 32 if h16 else 24
     g: Dict[str, Tuple[int, int, int]] = {
         "conv1": (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),
@@ -47,7 +49,7 @@ def geometry(variant: str = "gsc", dtype: str = "f32") -> Dict[str, Tuple[int, i
         "clr_up1": (cu, k_h, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (32, 64, 16),
     }
     for i in range(N_RES):
-        g["res%d.conv1" % i] = (24, k_a if i == 0 else (k_r if i < N_RES // 2 else k_h), 128)
+        g["res%d.conv1" % i] = (cu, k_a if i == 0 else (k_r if i < N_RES // 2 else k_h), 128)
         g["res%d.conv2" % i] = (32, 128, 128)
         g["res%d.c3q" % i] = (32, 128, 768)       # [y3: 257 real of 288 | theta|phi|g: 384 | 3 zero tiles of slack]
         g["res%d.w" % i] = (32, 128, 384)         # 257 real of 288 + 3 zero tiles of slack (gemm_nloop group reads)
@@ -179,6 +181,8 @@ def pack_generator(weights: Dict[str, np.ndarray], dtype: str = "f32") -> bytes:
         cc, k_pad, n_pad = geo[name]
         if dtype != "f32" and name in H16_LAYERS:
             arr, bias = pack_taps_h16(k, b, cc, k_pad, n_pad, 2 if dtype == "f32x3" else 1)
+        elif dtype != "f32" and name in X3_LAYERS:
+            arr, bias = pack_taps_h16(k, b, cc, k_pad, n_pad, 2)
         else:
             arr, bias = pack_taps(k, b, cc, k_pad, n_pad)
         entries.append((name + ".w", arr, tuple(arr.shape)))

@@ -91,6 +91,9 @@ int bsr_timing_entry(bsr_handle* h, int i, char* name, size_t name_cap, float* m
 /* Test hook: the fused NonLocalBlock attention kernel alone (/root/reference/model.py:51-53).
  * qkv [B,tokens,384] (theta | phi | g, 128 channels each) -> y [B,tokens,128]; tokens % 128 == 0. */
 int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream);
+/* The same with the kernel of a given BSR_DTYPE_*: F32 = fp32 matrix cores; F32X3 / F16 = the split-precision kernel (attention is
+ * split-precision in both 16-bit modes). */
+int bsr_debug_attention_dtype(const float* qkv, float* y, int B, int tokens, int dtype, void* stream);
 
 void bsr_destroy(bsr_handle* h);
 

@@ -107,9 +107,11 @@ def test_full_batch_properties(gen_w):
         assert float((a.cpu() - b).abs().max()) <= 1e-3
 
 
-def test_attention_kernel_forced_rescale():
+@pytest.mark.parametrize("dtype_code", [0, 2])
+def test_attention_kernel_forced_rescale(dtype_code):
     """Online-softmax rescale branch (cdna guide rule 26): spike late keys so the running max jumps in the
-    last tiles; compare with an fp64 softmax on the full tensor."""
+    last tiles; compare with an fp64 softmax on the full tensor.  dtype_code 0 = the fp32 matrix-core kernel (attention.h),
+    2 = the split-precision fp16 matrix-core kernel of the f32x3 / f16 modes (attention_x3.h) — same tolerance."""
     from blindshadowremoval_amd import _lib
     lib = _lib.load()
     torch.manual_seed(2)
@@ -120,13 +122,14 @@ def test_attention_kernel_forced_rescale():
     qkv[0, 3, :D] = 0.0                                  # a query with all-zero logits (uniform softmax)
     x = qkv.cuda()
     y = torch.empty(B, T, D, device="cuda")
-    _lib.check(lib.bsr_debug_attention(x.data_ptr(), y.data_ptr(), B, T, None), "bsr_debug_attention")
+    _lib.check(lib.bsr_debug_attention_dtype(x.data_ptr(), y.data_ptr(), B, T, dtype_code, None), "bsr_debug_attention")
     torch.cuda.synchronize()
     q, k, v = (t.double() for t in qkv.split(D, dim=2))
     ref = torch.softmax(q @ k.transpose(1, 2), -1) @ v
     assert float((q @ k.transpose(1, 2)).max()) > 50.0          # the test really exercises large logits
     assert float((y.cpu().double() - ref).abs().max()) < 2e-5
-    rc = lib.bsr_debug_attention(x.data_ptr(), y.data_ptr(), B, 1000, None)
+    print("attention dtype", dtype_code, "max abs err vs fp64", float((y.cpu().double() - ref).abs().max()))
+    rc = lib.bsr_debug_attention_dtype(x.data_ptr(), y.data_ptr(), B, 1000, dtype_code, None)
     assert rc == 1 and b"multiple of 128" in lib.bsr_last_error()
 
 
