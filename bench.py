@@ -44,6 +44,25 @@ for _i in range(6):
     LAYER_MMAC["res%d.c3q" % _i] = 4 * 33.69            # conv3 + theta | phi | g (composed offline into one K = 128 GEMM)
     LAYER_MMAC["res%d.attention" % _i] = 2 * 134.22
     LAYER_MMAC["res%d.w" % _i] = 33.69
+# Algorithmic activation floats per 256x256 image of each launch: every input element read once + every output element written once
+# (weights, 12 MB in all, stay in L2).  x 4 bytes x images / time = the algorithmic HBM rate of the launch.
+def _io(hw_in, c_in, hw_out, c_out):
+    return hw_in * hw_in * c_in + hw_out * hw_out * c_out
+
+
+LAYER_IO_FLOATS = {"conv1": _io(256, 3, 256, 32), "down1": _io(256, 32, 128, 64), "down2": _io(128, 64, 64, 64), "down3": _io(64, 64, 32, 96),
+                   "up1": _io(32, 257, 64, 96), "up2": _io(64, 160, 128, 64), "up3": _io(128, 128, 256, 64), "heads": _io(256, 64, 256, 16),
+                   "clr_up1": _io(32, 261, 64, 128), "clr_up2": _io(64, 128, 128, 96), "clr_up3": _io(128, 96, 256, 64),
+                   "clr_conv1": _io(256, 64 + 1 + 3, 256, 4)}
+for _i in range(6):
+    _cin = (99, 257, 257, 261, 261, 261)[_i]
+    LAYER_IO_FLOATS["res%d.conv1" % _i] = _io(32, _cin, 32, 128)
+    LAYER_IO_FLOATS["res%d.conv2" % _i] = _io(32, 128, 32, 128)
+    LAYER_IO_FLOATS["res%d.c3q" % _i] = _io(32, 128 + _cin, 32, 288 + 384)          # + the block input (skip folded into y3x)
+    LAYER_IO_FLOATS["res%d.attention" % _i] = _io(32, 384, 32, 128)
+    LAYER_IO_FLOATS["res%d.w" % _i] = _io(32, 128 + 288, 32, 264)
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
 # the "3x3-conv path" of north_star / SURVEY §8d: 3x3, stride-2 3x3 and transposed 3x3 layers (clr_conv1's launch also carries the fused 1x1 tail)
 LAYERS_3X3 = (["down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3", "clr_conv1"] + ["res%d.conv2" % i for i in range(6)])
 # kernel instantiation -> the layers it runs (csrc/bsr_api.hip launch table)
@@ -226,11 +245,18 @@ class _StubGenerator:
 H16_LAYERS = (["down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3"] + ["res%d.conv2" % i for i in range(6)])   # = pack.H16_LAYERS
 
 
+# layers that run split-precision (hi/lo fp16 planes, three fp16 matrix instructions per K group) in BOTH 16-bit modes = pack.X3_LAYERS + attention
+X3_LAYERS = (["res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w", "attention")] + ["heads", "clr_conv1"])
+
+
 def group_peak(layers, dtype):
-    """Matrix-core peak that bounds a kernel group: fp32 MFMA for fp32 kernels; in the 16-bit modes the igemm_h16 layers are priced
-    against the dense fp16 peak — divided by 3 for f32x3, whose every algorithmic MAC costs three fp16 MACs (hi.hi + hi.lo + lo.hi)."""
+    """Matrix-core peak that bounds a kernel group: fp32 MFMA for fp32 kernels (every kernel of dtype f32; the stem in all modes); in
+    the 16-bit modes the dense fp16 peak — divided by 3 where an algorithmic MAC costs three fp16 MACs (hi.hi + hi.lo + lo.hi):
+    every 16-bit kernel of f32x3, and the 1x1 / attention / 16-channel kernels of f16 too."""
     if dtype != "f32" and all(n in H16_LAYERS for n in layers):
         return PEAK_F16_MFMA_TFLOPS / (3.0 if dtype == "f32x3" else 1.0)
+    if dtype != "f32" and all(n in X3_LAYERS for n in layers):
+        return PEAK_F16_MFMA_TFLOPS / 3.0
     return PEAK_F32_MFMA_TFLOPS
 
 
@@ -253,9 +279,14 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
             continue
         gflop = 2e-3 * sum(LAYER_MMAC[n] for n in layers) * B
         gpeak = group_peak(layers, dtype)
-        label = gname.replace("igemm_conv_kernel", "igemm_h16_kernel") if gpeak != PEAK_F32_MFMA_TFLOPS else gname
+        label = gname
+        if gpeak != PEAK_F32_MFMA_TFLOPS:          # the 16-bit instantiations (csrc/igemm_h16.h, attention_x3.h, gemm_nloop / conv_n16 with H = 2)
+            label = (gname.replace("igemm_conv_kernel", "igemm_h16_kernel").replace("nonlocal_attention_kernel", "nonlocal_attention_x3_kernel")
+                     .replace("gemm_nloop_kernel", "gemm_nloop_kernel<..,H=2>").replace("conv_n16_kernel<", "conv_n16_kernel<H=2,"))
+        gbytes = 4e-9 * sum(LAYER_IO_FLOATS[n] for n in layers) * B
         groups[label] = {"ms": round(ms, 4), "launches": len(layers), "tflops": round(gflop / ms, 2), "peak": round(gpeak, 1),
-                         "frac": round(gflop / ms / gpeak, 4), "gflop": gflop}
+                         "frac": round(gflop / ms / gpeak, 4), "alg_GBps": round(gbytes / ms * 1e3, 1), "hbm_frac": round(gbytes / ms * 1e3 / PEAK_HBM_GBPS, 4),
+                         "gflop": gflop}
     dom_name = max(groups, key=lambda k: groups[k]["ms"])
     dom = groups[dom_name]
     peak = dom["peak"]
@@ -265,6 +296,8 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
     t_all = sum(layer_ms.values())
     glue_ms = sum(ms for n, ms in layer_ms.items() if n not in LAYER_MMAC)
     rf = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+          "hbm_view": {"alg_GBps": dom["alg_GBps"], "peak_GBps": PEAK_HBM_GBPS, "frac": dom["hbm_frac"],
+                       "note": "algorithmic activation bytes (input read once + output written once) / device time of the same launches"},
           "kernel": dom_name + " — the largest kernel instantiation, %.0f %% of the forward's device time" % (100 * dom["ms"] / t_all),
           "launches_per_forward": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
           "algorithmic_gflop_per_launch": round(dom["gflop"] / dom["launches"], 2),
@@ -277,24 +310,28 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
 
 
 def attach_traffic(rf, dom_name, B, dtype):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py; separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE runs as MI355X_MICROARCH.md prescribes).  The figure is only reported while the kernel sources
-    still hash to what the passes were taken on; otherwise null."""
+    """HBM bytes per launch of the transposed-conv kernel from the committed PMC passes (tools/pmc_traffic.py; separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE runs as MI355X_MICROARCH.md prescribes).  Reported only while the kernel sources still hash to
+    what the passes were taken on and the roofline kernel is that one; otherwise null with the reason."""
     from blindshadowremoval_amd.build import source_sha16
     sha = source_sha16()
+    sfx = "" if dtype == "f32" else "_" + dtype
     for tag in ("r2", "r1"):
-        tpath = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx))
         if not os.path.isfile(tpath):
             continue
         with open(tpath) as ft:
             t = json.load(ft)
-        if B == t.get("batch") and dtype == "f32" and t.get("kernel_src_sha16") == sha and t.get("dominant_kernel", dom_name) == dom_name:
+        if "up2, up3, clr_up3" not in dom_name:
+            rf["traffic_note"] = "the PMC passes cover the transposed-conv kernel (up2, up3, clr_up3); the dominant kernel of this run is another one"
+        elif B == t.get("batch") and t.get("kernel_src_sha16") == sha:
             rf["traffic"] = t.get("dominant_kernel_hbm_bytes_per_launch")
-            rf["traffic_note"] = ("HBM bytes per launch of the same kernel (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/%s_pmc_traffic.csv, "
-                                  "taken on kernel sources %s = this build); algorithmic activation bytes per launch: %s" % (tag, sha, t.get("dominant_kernel_algorithmic_bytes_per_launch")))
-            return
-        rf["traffic_note"] = ("profiles/%s_pmc_traffic.json was measured on kernel sources %s / batch %s, this build is %s / batch %d: not reported"
-                              % (tag, t.get("kernel_src_sha16"), t.get("batch"), sha, B))
+            rf["traffic_note"] = ("HBM bytes per launch of the same kernel (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/%s_pmc_traffic%s.csv, "
+                                  "taken on kernel sources %s = this build); algorithmic activation bytes per launch (input read once, output written once): %.3g"
+                                  % (tag, sfx, sha, t.get("dominant_kernel_algorithmic_bytes_per_launch", 0.0)))
+        else:
+            rf["traffic_note"] = ("profiles/%s_pmc_traffic%s.json was measured on kernel sources %s / batch %s, this build is %s / batch %d: not reported"
+                                  % (tag, sfx, t.get("kernel_src_sha16"), t.get("batch"), sha, B))
         return
 
 
@@ -312,7 +349,8 @@ def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_p
         gen(inp, uv, out=out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    rf, _ = roofline_from_events(gen, lambda: gen(inp, uv, out=out), B, "f32x3")
+    rf, dom = roofline_from_events(gen, lambda: gen(inp, uv, out=out), B, "f32x3")
+    attach_traffic(rf, dom, B, "f32x3")
     res = {"dtype": "f32x3", "value": round(B * args.steps / dt, 2), "unit": "images/sec (this GPU, no collective)", "ms_per_step": round(dt / args.steps * 1e3, 4),
            "steps": args.steps, "roofline": rf,
            "note": "3x3 / stride-2 / transposed 3x3 layers on v_mfma_f32_32x32x16_f16 with operands split into hi + lo fp16 planes at LDS staging "

@@ -54,12 +54,13 @@ class Config(object):
 class Logging(object):
     """utils.Logging counterpart (utils.py:127-253): running-mean text + PNG strips."""
 
-    def __init__(self, config: Config, png_threads: int = 4):
+    def __init__(self, config: Config, png_threads: int = 0):
         self.config = config
         self.losses: Dict[str, List[float]] = {}
         self.saved: List[str] = []
-        # PNG encoding (zlib) releases the GIL: strips are encoded by a few background threads while the loop goes on;
-        # flush() — called by the loops before they return — waits for them
+        # PNG encoding (zlib) releases the GIL: with png_threads > 0 (the FSRNet loops use 4) strips are encoded by background
+        # threads while the loop goes on and flush() — called by the loops before they return — waits for them; the default
+        # (0) writes synchronously, as the reference's cv2.imwrite does
         self._png_threads = png_threads
         self._pool = None
         self._pending: List = []
@@ -126,7 +127,7 @@ class FSRNet(object):
         self.gen = Generator(device=config.GPU_INDEX if torch.cuda.is_available() else None, dtype=dtype)
         if weights is not None:
             self.gen.load_weights(weights)
-        self.log = Logging(config)
+        self.log = Logging(config, png_threads=4)
         self.timings: Dict[str, float] = {}      # wall-clock split of the last test / testFFHQ loop (see _loop)
 
     # -- checkpoint -------------------------------------------------------------------------
@@ -306,7 +307,7 @@ class FSRNetTSM(object):
         self.gen = GeneratorTSM(device=config.GPU_INDEX if torch.cuda.is_available() else None)
         if weights is not None:
             self.gen.load_weights(weights)
-        self.log = Logging(config)
+        self.log = Logging(config, png_threads=4)
 
     def _prep(self, img, n: int, split):
         s = self.config.IMG_SIZE
