@@ -210,7 +210,9 @@ struct Launcher {
     const int nb = (n_store + C::BN - 1) / C::BN;
     if (h16) {
       if (k_pad % CCH != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': K is not a multiple of the 16-bit kernels' chunk"); return; }
-      rc = find_layer(h, name, k_pad / CCH, KH * KW, (nsplit * CCH + 8) / 2, nb * C::BN, &l);
+      // words per weight row: padded rows, or the unpadded swizzled 128-byte rows of the DMA-fed f32x3 layers (H16Cfg::LDPW)
+      const int ldpw = nsplit == 2 ? bsr::H16Cfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 2>::LDPW : (CCH + 8) / 2;
+      rc = find_layer(h, name, k_pad / CCH, KH * KW, ldpw, nb * C::BN, &l);
     } else {
       rc = find_layer(h, name, k_pad / CC, KH * KW, CC + 4, nb * C::BN, &l);
     }

@@ -46,7 +46,14 @@ struct H16Cfg {
   static constexpr int BM = WM * MI * 32;
   static constexpr int NPH = TR ? 4 : 1;
   static constexpr int IN_WORDS = IH * IW * LDP;
-  static constexpr int W_WORDS = BN * LDP;
+  // Weight rows of the DMA-fed f32x3 layers with 32-channel chunks are stored UNPADDED (128 bytes: 4 hi + 4 lo 16-byte slots) with
+  // the slot index XOR-swizzled by (row >> 1) & 7 (applied offline by pack.py): an LDS-DMA piece costs the issuing wave 100+
+  // cycles beside the matrix stream, and 64 rows x 128 B are 8 pieces = 2 per wave where the padded 144-B rows needed 3.
+  // Conflict-free for ds_read_b128: two 128-B rows fill one 256-B bank row and the 8 even (odd) rows of every 16-lane group
+  // get 8 different slots.
+  static constexpr bool SWZ = NSPLIT == 2 && CC == 32 && T > 1;
+  static constexpr int LDPW = SWZ ? 32 : LDP;                    // words per weight row
+  static constexpr int W_WORDS = BN * LDPW;
   // Weights by LDS-DMA (multi-tap layers): with 16-bit operands a (chunk, tap) step is only NI * G * NSPLIT' matrix instructions
   // long (a few hundred cycles), far less than an L2 round trip, so the register-staged ring of igemm_conv.h (load at the start
   // of a step, ds_write at its end) exposes the load latency on every step.  global_load_lds_dwordx4 copies the packed image
@@ -86,7 +93,8 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
 template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   using C = H16Cfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT>;
-  constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH, G = C::G, LO = C::LO;
+  constexpr int T = C::T, IW = C::IW, LDP = C::LDP, LDPW = C::LDPW, BN = C::BN, NPH = C::NPH, G = C::G, LO = C::LO;
+  constexpr bool SWZ = C::SWZ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
   float* s_w = smem + INB * C::IN_WORDS;
@@ -117,7 +125,13 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     a_base[mi] = ((ty * S) * IW + tx * S) * LDP + 4 * h;
   }
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) b_base[ni] = ((wn * NI + ni) * 32 + r) * LDP + 4 * h;
+  for (int ni = 0; ni < NI; ++ni) b_base[ni] = ((wn * NI + ni) * 32 + r) * LDPW + 4 * h;
+  // swizzled rows: logical 16-byte slot (2g + h) of the hi plane, 4 + 2g + h of the lo plane -> physical slot ^ ((r >> 1) & 7)
+  int b_sw[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) b_sw[ni][ci] = ((wn * NI + ni) * 32 + r) * LDPW + 4 * ((2 * ci) ^ (h ^ ((r >> 1) & 7)));
 
   float bias_n[NI];
 #pragma unroll
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   };
   // weights: p.w is the packed fp16 LDS image [chunk][tap][n_pad][LDP words], copied verbatim
   auto fetch_w = [&](int step, f32x4 (&regs)[C::W_PER_THREAD]) {
-    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDP);
+    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDPW);
 #pragma unroll
     for (int i = 0; i < C::W_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + w_off[i]);
   };
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     dma_src[i] = (unsigned)min(c * 1024 + lane * 16, C::W_WORDS * 4 - 16);
   }
   auto dma_w = [&](int step, int off) {
-    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDP);
+    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDPW);
 #pragma unroll
     for (int i = 0; i < C::W_DMA_PER_WAVE; ++i) {
       const int c = min(wave + 4 * i, C::W_CHUNKS - 1);                              // wave-uniform
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   }
 
   f16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
-  auto read_frags = [&](int slot, int a_off, int b_off) {
+  auto read_frags = [&](int slot, int a_off, int w_off_, int g) {      // A at a_off (group offset included), B = K group g of ring slot w_off_
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       ah[slot][mi] = *reinterpret_cast<const f16x8*>(s_in + a_base[mi] + a_off);
@@ -255,8 +269,13 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      bh[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + b_off);
-      if (NSPLIT == 2) bl[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + b_off + LO);
+      if constexpr (SWZ) {
+        bh[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + w_off_ + b_sw[ni][g]);
+        bl[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + w_off_ + b_sw[ni][2 + g]);
+      } else {
+        bh[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + w_off_ + g * 8);
+        if (NSPLIT == 2) bl[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + w_off_ + g * 8 + LO);
+      }
     }
   };
   auto tap_offset = [&](int t) -> int {
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     }
     return ((t / KW) * IW + (t % KW)) * LDP;
   };
-  read_frags(0, in_cur + tap_offset(0), w_cur);
+  read_frags(0, in_cur + tap_offset(0), w_cur, 0);
   __builtin_amdgcn_s_setprio(0);
 #ifdef BSR_STAMPS
   st1 = __builtin_amdgcn_s_memtime();
@@ -285,7 +304,9 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
       const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == kInStoreTap && more);
       const bool has3 = s + 3 < nsteps;
       if constexpr (DMAW) {
+#ifndef H16_DIAG_NO_DMA
         if (has3) dma_w(s + 3, w_n3);
+#endif
       } else {
         if (has2) fetch_w(s + 2, w_regs);
       }
@@ -298,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
       for (int g = 0; g < G; ++g) {
         const int cur = (t * G + g) & 1, nxt = cur ^ 1;
         if (g + 1 < G) {
-          read_frags(nxt, in_cur + tap_off + (g + 1) * 8, w_cur + (g + 1) * 8);
+          read_frags(nxt, in_cur + tap_off + (g + 1) * 8, w_cur, g + 1);
         } else if (t + 1 < T) {
-          read_frags(nxt, in_cur + tap_offset(t + 1 < T ? t + 1 : 0), w_n1);
+          read_frags(nxt, in_cur + tap_offset(t + 1 < T ? t + 1 : 0), w_n1, 0);
         } else if (INB > 1) {
-          if (has1) read_frags(nxt, in_n1 + tap_offset(0), w_n1);
+          if (has1) read_frags(nxt, in_n1 + tap_offset(0), w_n1, 0);
         }
         if (g == G - 1) {                                                           // write point: stage step s+2
           if constexpr (!DMAW) {
@@ -331,6 +352,9 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         // the previous step; they may stay in flight.
         constexpr int NW = C::W_DMA_PER_WAVE, NIN = 2 * C::IN_PER_THREAD;
         const bool near_fetch = T > 1 && (t == kInFetchTap || t == kInFetchTap + 1);      // compile-time once t is unrolled
+#ifdef H16_DIAG_NO_VMWAIT
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));
+#else
         if (!has3) {
           __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
         } else if (near_fetch && more) {
@@ -338,7 +362,10 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         } else {
           __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW));
         }
+#endif
+#ifndef H16_DIAG_NO_STEP_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
       } else {
         __syncthreads();
       }
@@ -350,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         } else {
           __syncthreads();
         }
-        read_frags(((T * G) & 1), tap_offset(0), w_n1);
+        read_frags(((T * G) & 1), tap_offset(0), w_n1, 0);
       }
       if constexpr (DMAW) {
         const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = w_n3; w_n3 = tw;

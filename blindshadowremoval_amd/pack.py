@@ -86,7 +86,7 @@ def pack_taps(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int, n_p
     return arr, b
 
 
-def pack_taps_h16(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int, n_pad: int, nsplit: int):
+def pack_taps_h16(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int, n_pad: int, nsplit: int, swizzle: bool = False):
     """[taps, K, N] -> the fp16 LDS image of csrc/igemm_h16.h as float32 words: [k_pad/cc, taps, n_pad, (nsplit*cc + 8) / 2].
     Row of output channel n: cc halves hi = fp16(w) | (nsplit == 2) cc halves lo = fp16(w - hi) | 8 halves of zero pad, where
     w is the fp32 value the fp32 path uses (so hi + lo reproduces it to ~2^-22)."""
@@ -101,8 +101,20 @@ def pack_taps_h16(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int,
     planes = [hi]
     if nsplit == 2:
         planes.append((rows - hi.astype(np.float64)).astype(np.float16))
-    planes.append(np.zeros(rows.shape[:3] + (8,), np.float16))
-    img = np.ascontiguousarray(np.concatenate(planes, axis=3))                        # [chunk, tap, n, nsplit*cc + 8] halves
+    if swizzle:
+        # unpadded 128-byte rows for the LDS-DMA-fed f32x3 layers (H16Cfg::SWZ in csrc/igemm_h16.h): the eight 16-byte slots
+        # [hi k0-7, hi k8-15, hi k16-23, hi k24-31, lo ...] of row n are stored at slot ^ ((n >> 1) & 7)
+        assert nsplit == 2 and cc == 32
+        lin = np.concatenate(planes, axis=3).reshape(rows.shape[:3] + (8, 8))          # [chunk, tap, n, slot, 8 halves]
+        img = np.empty_like(lin)
+        for row in range(n_pad):
+            sw = (row >> 1) & 7
+            for slot in range(8):
+                img[:, :, row, slot ^ sw] = lin[:, :, row, slot]
+        img = np.ascontiguousarray(img.reshape(rows.shape[:3] + (64,)))
+    else:
+        planes.append(np.zeros(rows.shape[:3] + (8,), np.float16))
+        img = np.ascontiguousarray(np.concatenate(planes, axis=3))                    # [chunk, tap, n, nsplit*cc + 8] halves
     arr = img.view(np.float32)                                                         # two halves per 32-bit word, little endian
     b = np.zeros(n_pad, np.float32)
     b[:n] = bias
@@ -180,7 +192,7 @@ def pack_generator(weights: Dict[str, np.ndarray], dtype: str = "f32") -> bytes:
     for name, (k, b) in layer_matrices(weights).items():
         cc, k_pad, n_pad = geo[name]
         if dtype != "f32" and name in H16_LAYERS:
-            arr, bias = pack_taps_h16(k, b, cc, k_pad, n_pad, 2 if dtype == "f32x3" else 1)
+            arr, bias = pack_taps_h16(k, b, cc, k_pad, n_pad, 2 if dtype == "f32x3" else 1, swizzle=(dtype == "f32x3" and cc == 32))
         elif dtype != "f32" and name in X3_LAYERS:
             arr, bias = pack_taps_h16(k, b, cc, k_pad, n_pad, 2)
         else:

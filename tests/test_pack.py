@@ -174,6 +174,13 @@ def test_h16_pack_planes_reproduce_the_fp32_weights():
     arr1, _ = pack.pack_taps_h16(k, b, 32, 64, 96, 1)
     assert arr1.shape == (2, 9, 96, 20)
     assert np.array_equal(arr1.view(np.float16).reshape(2, 9, 96, 40)[..., :32], halves[..., :32])
+    # swizzled unpadded rows of the DMA-fed f32x3 layers: slot s of row n sits at slot s ^ ((n >> 1) & 7), nothing else changes
+    arrs, _ = pack.pack_taps_h16(k, b, 32, 64, 96, 2, swizzle=True)
+    assert arrs.shape == (2, 9, 96, 32)
+    hs = arrs.view(np.float16).reshape(2, 9, 96, 8, 8)
+    for n in (0, 1, 2, 37, 95):
+        for slot in range(8):
+            assert np.array_equal(hs[:, :, n, slot ^ ((n >> 1) & 7)], halves[:, :, n, 8 * slot:8 * slot + 8])
     w = init_weights(1)
     for dtype, code in pack.DTYPES.items():
         blob = pack.pack_generator(w, dtype)
