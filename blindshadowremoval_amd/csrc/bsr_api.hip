@@ -502,11 +502,15 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   // conv1 = Conv(32, 7x7) + BN + LeakyReLU (model.py:203,230): dedicated stem kernel (7 row taps x 21 contiguous floats)
   {
     LayerW l;
-    L.rc = find_layer(h, "conv1", 1, 7, 28, 32, &l);
+    const bool x3 = h->dtype != BSR_DTYPE_F32;                     // split precision in both 16-bit modes
+    L.rc = find_layer(h, "conv1", 1, 7, x3 ? 36 : 28, 32, &l);
     if (L.rc == BSR_OK) {
       bsr::StemArgs a{inputs, ws + p.x1, l.w, l.b, H, W, 0, 0};
       L.begin(K_CONV7, "conv1");
-      L.check(bsr::launch_stem7<4>(a, B, s), "conv1");
+      if (x3)
+        L.check(bsr::launch_stem7<4, 2>(a, B, s), "conv1");
+      else
+        L.check(bsr::launch_stem7<4, 0>(a, B, s), "conv1");
       L.end();
     }
   }

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "igemm_conv.h"
+#include "igemm_h16.h"
 
 namespace bsr {
 
@@ -21,17 +22,21 @@ struct StemArgs {
   int tiles_x, tiles_y;
 };
 
-template <int RW>   // image rows per wave
+// H = 2 (split precision, igemm_h16.h): every image value is split ONCE at staging time and kept in LDS as one 32-bit word
+// (hi fp16 | lo fp16 << 16); the A fragment of pixel tx, K step s is the 8 words at row + 3 tx + 16 s + 8 h (same stride-3
+// conflict-free ds_read_b32 pattern), unzipped into a hi and a lo f16x8 by four v_perm_b32 each.  K = 21 -> 32 (two
+// 32x32x16 steps per vertical tap), weights = pack_taps_h16's [7][32][36-word] image.
+template <int RW, int H = 0>   // image rows per wave
 struct StemCfg {
-  static constexpr int TH = 4 * RW, TW = 32, IH = TH + 6, ROWF = 120;   // 38 pixels x 3 floats = 114 used, reads reach 116
-  static constexpr int IN_FLOATS = IH * ROWF;
-  static constexpr int W_FLOATS = 7 * 32 * 28;
+  static constexpr int TH = 4 * RW, TW = 32, IH = TH + 6, ROWF = 120;   // 38 pixels x 3 floats = 114 used, reads reach 116 (H = 2: 124)
+  static constexpr int IN_FLOATS = IH * ROWF + (H ? 8 : 0);
+  static constexpr int W_FLOATS = H ? 7 * 32 * 36 : 7 * 32 * 28;
   static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS) * 4;
 };
 
-template <int RW>
+template <int RW, int H = 0>
 __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
-  using C = StemCfg<RW>;
+  using C = StemCfg<RW, H>;
   constexpr int ROWF = C::ROWF;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_w = smem;                    // weights first: 16-byte aligned rows for ds_read_b128
@@ -55,8 +60,13 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
     const int px = f / 3, c = f % 3;
     const int iy = y0 - 3 + row, ix = x0 - 3 + px;
     float v = 0.f;
-    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = in_img[((size_t)iy * p.W + ix) * 3 + c];
-    s_in[i] = v;
+    if (row < C::IH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = in_img[((size_t)iy * p.W + ix) * 3 + c];
+    if constexpr (H == 0) {
+      s_in[i] = v;
+    } else {
+      const _Float16 vh = (_Float16)v, vl = (_Float16)(v - (float)vh);
+      reinterpret_cast<unsigned*>(s_in)[i] = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
+    }
   }
   const float bias = p.bias[r];
   f32x16 acc[RW];
@@ -67,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
   __syncthreads();
   __builtin_amdgcn_s_setprio(0);
 
+  if constexpr (H == 0) {
   const int a_base = (wave * RW) * ROWF + 3 * r + 4 * h;      // + (mi + ky) * ROWF + 8g + j
   const int b_base = r * 28 + 4 * h;                            // + ky * 32 * 28 + 8g
 #pragma unroll
@@ -84,6 +95,36 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
 #pragma unroll
         for (int mi = 0; mi < RW; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[j], acc[mi], 0, 0, 0);
     }
+  }
+  } else {
+  const int a_base = (wave * RW) * ROWF + 3 * r + 8 * h;      // + (mi + ky) * ROWF + 16 s + j
+  const int b_base = r * 36 + 4 * h;                            // + ky * 32 * 36 + 8 s (hi), + 16 (lo)
+  const unsigned* s_pk = reinterpret_cast<const unsigned*>(s_in);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const f16x8 bh = *reinterpret_cast<const f16x8*>(s_w + b_base + ky * 32 * 36 + ks * 8);
+      const f16x8 bl = *reinterpret_cast<const f16x8*>(s_w + b_base + ky * 32 * 36 + ks * 8 + 16);
+#pragma unroll
+      for (int mi = 0; mi < RW; ++mi) {
+        unsigned wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = s_pk[a_base + (mi + ky) * ROWF + ks * 16 + j];
+        u32x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hi[j] = __builtin_amdgcn_perm(wv[2 * j + 1], wv[2 * j], 0x05040100u);      // low halves of two words
+          lo[j] = __builtin_amdgcn_perm(wv[2 * j + 1], wv[2 * j], 0x07060302u);      // high halves
+        }
+        const f16x8 ah = __builtin_bit_cast(f16x8, hi), al = __builtin_bit_cast(f16x8, lo);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mi], 0, 0, 0);
+      }
+    }
+  }
   }
 
   __builtin_amdgcn_s_setprio(3);
@@ -108,12 +149,12 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
   }
 }
 
-template <int RW>
+template <int RW, int H = 0>
 inline hipError_t launch_stem7(StemArgs a, int batch, hipStream_t stream) {
-  using C = StemCfg<RW>;
+  using C = StemCfg<RW, H>;
   a.tiles_x = a.W / C::TW;
   a.tiles_y = a.H / C::TH;
-  hipLaunchKernelGGL(stem7_kernel<RW>, dim3(a.tiles_x * a.tiles_y * batch), dim3(256), C::SMEM_BYTES, stream, a);
+  hipLaunchKernelGGL((stem7_kernel<RW, H>), dim3(a.tiles_x * a.tiles_y * batch), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ DTYPES = {"f32": 0, "f16": 1, "f32x3": 2}     # BSR_DTYPE_* of include/bsr_hip.h
 # layers the 16-bit modes run on igemm_h16_kernel (csrc/igemm_h16.h): every 3x3 / stride-2 3x3 / transposed 3x3 igemm layer
 H16_LAYERS = ("down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3") + tuple("res%d.conv2" % i for i in range(6))
 # 1x1 layers (igemm_h16_kernel<1,1> / gemm_nloop_kernel<.., H = 2>): split-precision (hi + lo planes) in BOTH 16-bit modes
-X3_LAYERS = tuple("res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w")) + ("heads", "clr_conv1")      # + conv_n16_kernel<.., H = 2>
+X3_LAYERS = tuple("res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w")) + ("heads", "clr_conv1", "conv1")      # + conv_n16_kernel / stem7_kernel<.., H = 2>
 
 
 def geometry(variant: str = "gsc", dtype: str = "f32") -> Dict[str, Tuple[int, int, int]]:
@@ -44,7 +44,7 @@ def geometry(variant: str = "gsc", dtype: str = "f32") -> Dict[str, Tuple[int, i
     k_a, k_r, k_h = (312, 312, 888) if tsm else ((128, 288, 288) if h16 else (120, 264, 264))
     cu = 32 if h16 else 24
     g: Dict[str, Tuple[int, int, int]] = {
-        "conv1": (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),
+        "conv1": (32, 32, 32) if h16 else (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),
         "up1": (cu, k_r, 96), "up2": (32, 160, 64), "up3": (32, 128, 64), "heads": (32, 64, 16),
         "clr_up1": (cu, k_h, 128), "clr_up2": (32, 128, 96), "clr_up3": (32, 96, 64), "clr_conv1": (32, 64, 16),
     }
