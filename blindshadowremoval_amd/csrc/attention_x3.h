@@ -9,9 +9,18 @@
 //  * S^T: A = phi tile in LDS, [key][128 hi | 128 lo halves], one ds_read_b128 per plane and 16-channel K step; B = theta of the
 //    lane's query, split once into registers.
 //  * O^T: B = P^T straight from the S^T accumulator: registers 8t..8t+7 of lane half h are keys 16t + 8(j >> 2) + 4h + (j & 3).
-//    A = g^T must present the same key order along k, so the g tile is stored TRANSPOSED and key-PERMUTED in LDS:
-//    row = channel d, position p = 16t + 8h + 4a + b holds key 16t + 8a + 4h + b — again one ds_read_b128 per plane and K step.
-//    The transpose is done by the staging threads (thread = one channel x 16 keys: coalesced dword loads, 16-byte LDS stores).
+//    A = g^T must present the same key order along k.  The g tile is staged exactly like phi — row-major [key][128 hi | 128 lo]
+//    with 16-byte stores — and TRANSPOSED ON READ by ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16-lane group the
+//    instruction reads a block of 4 keys x 16 channels and hands lane i the 4 keys of channel c0 + i, i.e. four consecutive k of
+//    the A operand; two such reads (keys 16t + 4h .. +3 and 16t + 8 + 4h .. +3) make the 8-element fragment in P's key order.
+//    (A first version transposed at staging time — one channel x 16 keys per thread, 16 dword loads — and was bound by those
+//    narrow loads.)  Row stride 576 bytes puts the 4 keys of a block on disjoint bank quarters: conflict-free.
+//
+// Workgroup = 8 waves = 128 queries x TWO key streams: waves 0-3 take the even 32-key tiles, waves 4-7 the odd ones, each with
+// its own running (max, sum, O^T); the two partial results are merged through LDS at the end (O = O0 2^(m0-m) + O1 2^(m1-m), same
+// for the sums).  With one wave per SIMD the softmax / operand-split VALU work and the staging of a tile cannot overlap that wave's
+// own matrix instructions (measured: 4 800 cycles per tile for 1 536 cycles of MFMA); two waves per SIMD on different tiles do
+// overlap (fp16 matrix instructions and VALU co-issue), and a tile pair is staged by 512 threads, half the per-thread work.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "attention.h"
@@ -20,13 +29,17 @@
 namespace bsr {
 
 constexpr int kAx3LdK = 132;                                   // words per phi row: 64 (hi) + 64 (lo) + 4 pad
-constexpr int kAx3LdV = 36;                                    // words per g^T row: 16 (hi) + 16 (lo) + 4 pad
-constexpr int kAx3StageWords = kAttKT * kAx3LdK + kAttD * kAx3LdV;
-constexpr int kAx3SmemBytes = 2 * kAx3StageWords * 4;
+constexpr int kAx3LdV = 144;                                   // words per g row: 64 (hi) + 64 (lo) + 16 pad (576 B: bank offset 16 words per key)
+constexpr int kAx3StageWords = kAttKT * kAx3LdK + kAttKT * kAx3LdV;    // one 32-key tile: phi rows + g rows
+constexpr int kAx3SmemBytes = 4 * kAx3StageWords * 4;                  // two tile PAIRS (double buffer)
+static_assert(kAx3SmemBytes <= 160 * 1024, "LDS budget");
+static_assert(66 * 64 * 4 <= 4 * kAx3StageWords, "merge scratch fits the staging buffers");
 
-__global__ __launch_bounds__(256, 1) void nonlocal_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
+__global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3;                    // key stream (even / odd tiles), query block of 32
   const int h = lane >> 5, r = lane & 31;
   const int qblocks = tokens / 128;
   int img, qb;
@@ -43,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_x3_kernel(const flo
     }
   }
   const float* base = qkv + (size_t)img * tokens * (3 * kAttD);
-  const int q = qb * 128 + wave * 32 + r;
+  const int q = qb * 128 + wq * 32 + r;
 
   // theta of this lane's query, pre-scaled by log2(e) (softmax in base 2), split: K step s covers channels 16s + 8h .. +7
   f16x8 qh[kAttD / 16], ql[kAttD / 16];
@@ -62,60 +75,60 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_x3_kernel(const flo
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // staging: phi as 8-channel pieces (512 per tile, 2 per thread); g as (channel, 16-key half) columns (256 per tile, 1 per thread)
-  f32x4 kreg[4];
-  float vreg[16];
-  const int vd = tid & 127, vt = tid >> 7;
-  auto fetch = [&](int kt) {
+  // staging of a tile PAIR (2p, 2p+1) by 512 threads: phi and g as 8-channel pieces (2 x 512 each; piece i of a thread belongs to tile 2p+i)
+  f32x4 kreg[4], vreg[4];
+  const int kkey = tid >> 4, kc8 = tid & 15;
+  auto fetch = [&](int pr) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int idx = tid + i * 256;
-      const int key = idx >> 4, c8 = idx & 15;
-      const float* row = base + (size_t)(kt * kAttKT + key) * (3 * kAttD) + kAttD + c8 * 8;
+      const float* row = base + (size_t)((2 * pr + i) * kAttKT + kkey) * (3 * kAttD) + kAttD + kc8 * 8;
       kreg[2 * i] = *reinterpret_cast<const f32x4*>(row);
       kreg[2 * i + 1] = *reinterpret_cast<const f32x4*>(row + 4);
+      vreg[2 * i] = *reinterpret_cast<const f32x4*>(row + kAttD);
+      vreg[2 * i + 1] = *reinterpret_cast<const f32x4*>(row + kAttD + 4);
     }
-    const float* col = base + (size_t)(kt * kAttKT + vt * 16) * (3 * kAttD) + 2 * kAttD + vd;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) vreg[j] = col[(size_t)j * (3 * kAttD)];
   };
-  auto publish = [&](int buf) {
-    float* sk = smem + buf * kAx3StageWords;
-    float* sv = sk + kAttKT * kAx3LdK;
+  auto publish = [&](int pbuf) {                               // pbuf = 0/1: which pair buffer (2 tiles each)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int idx = tid + i * 256;
-      const int key = idx >> 4, c8 = idx & 15;
+      float* sk = smem + (2 * pbuf + i) * kAx3StageWords;
       f16x8 hi, lo;
       split8(kreg[2 * i], kreg[2 * i + 1], hi, lo);
-      *reinterpret_cast<f16x8*>(sk + key * kAx3LdK + c8 * 4) = hi;
-      *reinterpret_cast<f16x8*>(sk + key * kAx3LdK + 64 + c8 * 4) = lo;
-    }
-    // g^T row vd, K step vt: position 8h' + 4a + b  <-  key offset 8a + 4h' + b
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      f16x8 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = vreg[8 * (j >> 2) + 4 * hh + (j & 3)];
-        const _Float16 xh = (_Float16)x;
-        hi[j] = xh;
-        lo[j] = (_Float16)(x - (float)xh);
-      }
-      *reinterpret_cast<f16x8*>(sv + vd * kAx3LdV + 8 * vt + 4 * hh) = hi;
-      *reinterpret_cast<f16x8*>(sv + vd * kAx3LdV + 16 + 8 * vt + 4 * hh) = lo;
+      *reinterpret_cast<f16x8*>(sk + kkey * kAx3LdK + kc8 * 4) = hi;
+      *reinterpret_cast<f16x8*>(sk + kkey * kAx3LdK + 64 + kc8 * 4) = lo;
     }
   };
+  auto publish_v = [&](int pbuf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float* sv = smem + (2 * pbuf + i) * kAx3StageWords + kAttKT * kAx3LdK;
+      f16x8 hi, lo;
+      split8(vreg[2 * i], vreg[2 * i + 1], hi, lo);
+      *reinterpret_cast<f16x8*>(sv + kkey * kAx3LdV + kc8 * 4) = hi;
+      *reinterpret_cast<f16x8*>(sv + kkey * kAx3LdV + 64 + kc8 * 4) = lo;
+    }
+  };
+  // transposed reads of the g tile: lane i of 16-lane group gq addresses key 4 (gq >> 1) + (i >> 2), channels 16 (gq & 1) + 4 (i & 3) .. +3
+  typedef short s16x4v __attribute__((__vector_size__(8)));
+  const int vbase = ((4 * (lane >> 5) + ((lane & 15) >> 2)) * kAx3LdV) + 8 * ((lane >> 4) & 1) + 2 * (lane & 3);
+  auto read_vt = [&](const float* sv, int word_off) -> f16x8 {     // keys {0..3} and {8..11} relative to the addressed row
+    const s16x4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(sv + vbase + word_off));
+    const s16x4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(sv + vbase + word_off + 8 * kAx3LdV));
+    typedef short s16x8v __attribute__((__vector_size__(16)));
+    const s16x8v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f16x8, ab);
+  };
 
-  const int nkt = tokens / kAttKT;
+  const int npair = tokens / (2 * kAttKT);
   fetch(0);
   publish(0);
+  publish_v(0);
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) fetch(kt + 1);
-    const float* sk = smem + buf * kAx3StageWords;
+  for (int pr = 0; pr < npair; ++pr) {
+    const int pbuf = pr & 1;
+    if (pr + 1 < npair) fetch(pr + 1);
+    const float* sk = smem + (2 * pbuf + grp) * kAx3StageWords;        // this wave's tile of the pair
     const float* sv = sk + kAttKT * kAx3LdK;
 
     f32x16 s;
@@ -149,29 +162,53 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_x3_kernel(const flo
     f16x8 ph[2], pl[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float pv = __builtin_amdgcn_exp2f(s[i] - m_run);       // <= 2^8: inside the fp16 range
-      psum += pv;
-      const _Float16 x = (_Float16)pv;
-      ph[i >> 3][i & 7] = x;
-      pl[i >> 3][i & 7] = (_Float16)(pv - (float)x);
+      s[i] = __builtin_amdgcn_exp2f(s[i] - m_run);                 // <= 2^8: inside the fp16 range
+      psum += s[i];
     }
     l_run += psum;
+    split8(f32x4{s[0], s[1], s[2], s[3]}, f32x4{s[4], s[5], s[6], s[7]}, ph[0], pl[0]);
+    split8(f32x4{s[8], s[9], s[10], s[11]}, f32x4{s[12], s[13], s[14], s[15]}, ph[1], pl[1]);
 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const f16x8 vh = *reinterpret_cast<const f16x8*>(sv + (32 * dt + r) * kAx3LdV + 8 * t + 4 * h);
-        const f16x8 vl = *reinterpret_cast<const f16x8*>(sv + (32 * dt + r) * kAx3LdV + 16 + 8 * t + 4 * h);
+        const f16x8 vh = read_vt(sv, 16 * t * kAx3LdV + 16 * dt);            // channels 32 dt .., keys 16 t ..
+        const f16x8 vl = read_vt(sv, 16 * t * kAx3LdV + 16 * dt + 64);
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[t], o[dt], 0, 0, 0);
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[t], o[dt], 0, 0, 0);
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[t], o[dt], 0, 0, 0);
       }
 
-    if (kt + 1 < nkt) {
-      publish(buf ^ 1);
+    if (pr + 1 < npair) {
+      publish(pbuf ^ 1);
+      publish_v(pbuf ^ 1);
       __syncthreads();
     }
+  }
+
+  // merge the two key streams: waves 4-7 hand (m, l, O^T) to waves 0-3 through LDS ([wq][66 values][64 lanes])
+  __syncthreads();
+  float* sx = smem + (size_t)wq * 66 * 64 + lane;
+  if (grp == 1) {
+    sx[0] = m_run;
+    sx[64] = l_run;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sx[(2 + dt * 16 + i) * 64] = o[dt][i];
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  {
+    const float m1 = sx[0], l1 = sx[64];
+    const float m = fmaxf(m_run, m1);
+    const float s0 = __builtin_amdgcn_exp2f(m_run - m), s1 = __builtin_amdgcn_exp2f(m1 - m);
+    l_run = l_run * s0 + l1 * s1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] = o[dt][i] * s0 + sx[(2 + dt * 16 + i) * 64] * s1;
   }
 
   // y[q][d], d = 32 dt + (i & 3) + 8 (i >> 2) + 4h: four consecutive channels per register quad
@@ -188,6 +225,7 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_x3_kernel(const flo
 }
 
 inline hipError_t launch_nonlocal_attention_x3(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
+  if (tokens % (2 * kAttKT) != 0) return hipErrorInvalidValue;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {
@@ -196,7 +234,7 @@ inline hipError_t launch_nonlocal_attention_x3(const float* qkv, float* out, int
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
-  hipLaunchKernelGGL(nonlocal_attention_x3_kernel, dim3(batch * (tokens / 128)), dim3(256), kAx3SmemBytes, stream, qkv, out, tokens);
+  hipLaunchKernelGGL(nonlocal_attention_x3_kernel, dim3(batch * (tokens / 128)), dim3(512), kAx3SmemBytes, stream, qkv, out, tokens);
   return hipGetLastError();
 }
 

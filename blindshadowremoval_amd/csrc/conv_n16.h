@@ -126,12 +126,10 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     if constexpr (H == 0) {
       *reinterpret_cast<f32x4*>(dst_f32) = v;
     } else {
-      f16x4 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        hi[e] = (_Float16)v[e];
-        lo[e] = (_Float16)(v[e] - (float)hi[e]);
-      }
+      f16x2 h0, l0, h1, l1;
+      split2(f32x2{v[0], v[1]}, h0, l0);
+      split2(f32x2{v[2], v[3]}, h1, l1);
+      const f16x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
       *reinterpret_cast<f16x4*>(dst_h16) = hi;
       *reinterpret_cast<f16x4*>(dst_h16 + 64) = lo;
     }

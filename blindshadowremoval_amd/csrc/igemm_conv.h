@@ -24,6 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef BSR_PAIR_S2
+#define BSR_PAIR_S2 1
+#endif
+
 namespace bsr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -101,6 +105,11 @@ struct ConvCfg {
   static constexpr int BN = WN * NI * 32;
   static constexpr int BM = WM * MI * 32;
   static constexpr int NPH = TR ? 4 : 1;
+  // stride-2 layers read 16-channel (64-byte) chunks: two consecutive chunks are the halves of one 128-byte line.  Fetched nine taps
+  // apart the second half misses in L2 (PMC, round 2: TCC hit rate 0.48, down1 read 521 MB for 268 MB of input); fetched together
+  // (PAIR) down1 reads 309 MB = the halo-inclusive minimum.  Time is unchanged (down1 229 us either way, down2 +4 %): the layer is
+  // bound by its per-tile prologue, not by this traffic.
+  static constexpr bool PAIR = S == 2 && CC == 16 && INB == 1 && BSR_PAIR_S2;
   static constexpr int IN_FLOATS = IH * IW * LDP;
   static constexpr int W_FLOATS = BN * LDP;
   static constexpr int SMEM_BYTES = (INB * IN_FLOATS + 3 * W_FLOATS) * 4;
@@ -119,6 +128,7 @@ struct ConvCfg {
 template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
 __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
+  constexpr bool PAIR = C::PAIR;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH, G = C::G;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   f32x4 in_regs[C::IN_PER_THREAD];
+  f32x4 in_regs2[PAIR ? C::IN_PER_THREAD : 1];      // PAIR: the odd chunk of a pair, fetched together with the even one
   f32x4 w_regs[C::W_PER_THREAD];
   const int nsteps = p.nchunk * T;
 
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
 
   // prologue: steps 0 and 1 staged synchronously
   fetch_in(0, in_regs);
+  if constexpr (PAIR) { if (p.nchunk > 1) fetch_in(1, in_regs2); }
   fetch_w(0, w_regs);
   store_in(0, in_regs);
   store_w(0, w_regs);
@@ -285,7 +297,16 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       // (1) issue the global loads of step s+2 (and of the next input tile) — landed by the write point below
 #ifndef BSR_NO_STAGE
       if (has2) fetch_w(s + 2, w_regs);
-      if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs);
+      if constexpr (PAIR) {
+        // chunks 2k and 2k+1 cover the two halves of the same 128-byte lines: both are requested together (the second request
+        // hits the line the first one brought into L2) instead of nine taps apart, when the line has long been evicted
+        if (fetch_now && (ch & 1)) {
+          fetch_in(ch + 1, in_regs);
+          if (ch + 2 < p.nchunk) fetch_in(ch + 2, in_regs2);
+        }
+      } else {
+        if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs);
+      }
 #endif
       __builtin_amdgcn_sched_barrier(0);
 
@@ -322,7 +343,11 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
       // (3) one barrier per step publishes what was staged and frees the slot read in this step
       __syncthreads();
       if (INB == 1 && t == T - 1 && more) {          // single input buffer: swap it between chunks (2 barriers)
-        store_in(0, in_regs);
+        if constexpr (PAIR) {
+          if (ch & 1) store_in(0, in_regs); else store_in(0, in_regs2);
+        } else {
+          store_in(0, in_regs);
+        }
         __syncthreads();
         read_frags(((T * G) & 1), tap_offset(0), w_n1);
       }

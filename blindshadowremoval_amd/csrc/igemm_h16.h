@@ -23,6 +23,10 @@
 
 #include "igemm_conv.h"
 
+#ifndef BSR_PAIR_S2_H16
+#define BSR_PAIR_S2_H16 0
+#endif
+
 namespace bsr {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -52,6 +56,7 @@ struct H16Cfg {
   // Conflict-free for ds_read_b128: two 128-B rows fill one 256-B bank row and the 8 even (odd) rows of every 16-lane group
   // get 8 different slots.
   static constexpr bool SWZ = NSPLIT == 2 && CC == 32 && T > 1;
+  static constexpr bool PAIR = S == 2 && CC == 16 && INB == 1 && BSR_PAIR_S2_H16;   // igemm_conv.h's paired half-line fetch: removes the same over-fetch here, but costs 4-11 % of time (longer prologue) -> off
   static constexpr int LDPW = SWZ ? 32 : LDP;                    // words per weight row
   static constexpr int W_WORDS = BN * LDPW;
   // Weights by LDS-DMA (multi-tap layers): with 16-bit operands a (chunk, tap) step is only NI * G * NSPLIT' matrix instructions
@@ -78,15 +83,24 @@ struct H16Cfg {
   static_assert(W_WORDS % 4 == 0, "weight image is copied in 16-byte pieces");
 };
 
-// hi = fp16(x) (round to nearest even), lo = fp16(x - hi)
+// hi = fp16(x) (round to nearest even), lo = fp16(x - hi).  Written on 2-wide vectors so that gfx950 selects its packed
+// conversions: v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32 = 5 VALU instructions per pair of values
+// (9 element by element).  The split runs beside the fp16 matrix stream and is what the 16-bit kernels are bound by once the
+// matrix work has shrunk by 16/3, so it is kept as lean as the ISA allows.
+__device__ __forceinline__ void split2(const f32x2 x, f16x2& hi, f16x2& lo) {
+  hi = __builtin_convertvector(x, f16x2);
+  lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), f16x2);
+}
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+  f16x2 h[4], l[4];
+  split2(f32x2{a[0], a[1]}, h[0], l[0]);
+  split2(f32x2{a[2], a[3]}, h[1], l[1]);
+  split2(f32x2{b[0], b[1]}, h[2], l[2]);
+  split2(f32x2{b[2], b[3]}, h[3], l[3]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const _Float16 ha = (_Float16)a[i], hb = (_Float16)b[i];
-    hi[i] = ha;
-    hi[4 + i] = hb;
-    lo[i] = (_Float16)(a[i] - (float)ha);
-    lo[4 + i] = (_Float16)(b[i] - (float)hb);
+    hi[2 * i] = h[i][0]; hi[2 * i + 1] = h[i][1];
+    lo[2 * i] = l[i][0]; lo[2 * i + 1] = l[i][1];
   }
 }
 
@@ -95,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   using C = H16Cfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT>;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, LDPW = C::LDPW, BN = C::BN, NPH = C::NPH, G = C::G, LO = C::LO;
   constexpr bool SWZ = C::SWZ;
+  constexpr bool PAIR = C::PAIR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
   float* s_w = smem + INB * C::IN_WORDS;
@@ -229,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   f32x4 in_regs[2 * C::IN_PER_THREAD];
+  f32x4 in_regs2[PAIR ? 2 * C::IN_PER_THREAD : 1];      // PAIR: the odd chunk of a pair, fetched together with the even one
   f32x4 w_regs[C::W_PER_THREAD];
   const int nsteps = p.nchunk * T;
 
@@ -241,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     if (nsteps > 1) dma_w(1, w_n1);
     if (nsteps > 2) dma_w(2, w_n2);
     fetch_in(0, in_regs);
+    if constexpr (PAIR) { if (p.nchunk > 1) fetch_in(1, in_regs2); }
     store_in(0, in_regs);
     __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
     __syncthreads();
@@ -310,7 +327,14 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
       } else {
         if (has2) fetch_w(s + 2, w_regs);
       }
-      if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs);
+      if constexpr (PAIR) {      // the two 64-byte halves of a 128-byte line are requested together (igemm_conv.h)
+        if (fetch_now && (ch & 1)) {
+          fetch_in(ch + 1, in_regs);
+          if (ch + 2 < p.nchunk) fetch_in(ch + 2, in_regs2);
+        }
+      } else {
+        if (fetch_now) fetch_in(kRing1x1 ? ch + 2 : ch + 1, in_regs);
+      }
       __builtin_amdgcn_sched_barrier(0);
 
       const int ph = TR ? (((t / 3 == 1) ? 2 : 0) + ((t % 3 == 1) ? 1 : 0)) : 0;
@@ -355,9 +379,17 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
 #ifdef H16_DIAG_NO_VMWAIT
         __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));
 #else
+        // input-tile loads issued after the awaited DMA (in this step or the previous one): they may stay in flight
+        int n_in = 0;
+        if (near_fetch && more) {
+          if constexpr (PAIR) n_in = (ch & 1) ? (ch + 2 < p.nchunk ? 2 : 1) : 0;
+          else n_in = 1;
+        }
         if (!has3) {
           __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
-        } else if (near_fetch && more) {
+        } else if (n_in == 2) {
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW + 2 * NIN));
+        } else if (n_in == 1) {
           __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW + NIN));
         } else {
           __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW));
@@ -370,7 +402,11 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         __syncthreads();
       }
       if (INB == 1 && t == T - 1 && more) {
-        store_in(0, in_regs);
+        if constexpr (PAIR) {
+          if (ch & 1) store_in(0, in_regs); else store_in(0, in_regs2);
+        } else {
+          store_in(0, in_regs);
+        }
         if constexpr (DMAW) {
           __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(C::W_DMA_PER_WAVE));      // the tile's ds_writes are done; this step's DMA may stay in flight
           __builtin_amdgcn_s_barrier();
