@@ -246,7 +246,7 @@ H16_LAYERS = (["down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_u
 
 
 # layers that run split-precision (hi/lo fp16 planes, three fp16 matrix instructions per K group) in BOTH 16-bit modes = pack.X3_LAYERS + attention
-X3_LAYERS = (["res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w", "attention")] + ["heads", "clr_conv1"])
+X3_LAYERS = (["res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w", "attention")] + ["heads", "clr_conv1", "conv1"])
 
 
 def group_peak(layers, dtype):
@@ -282,7 +282,8 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
         label = gname
         if gpeak != PEAK_F32_MFMA_TFLOPS:          # the 16-bit instantiations (csrc/igemm_h16.h, attention_x3.h, gemm_nloop / conv_n16 with H = 2)
             label = (gname.replace("igemm_conv_kernel", "igemm_h16_kernel").replace("nonlocal_attention_kernel", "nonlocal_attention_x3_kernel")
-                     .replace("gemm_nloop_kernel", "gemm_nloop_kernel<..,H=2>").replace("conv_n16_kernel<", "conv_n16_kernel<H=2,"))
+                     .replace("gemm_nloop_kernel", "gemm_nloop_kernel<..,H=2>").replace("conv_n16_kernel<", "conv_n16_kernel<H=2,")
+                     .replace("stem7_kernel", "stem7_kernel<4,H=2>"))
         gbytes = 4e-9 * sum(LAYER_IO_FLOATS[n] for n in layers) * B
         groups[label] = {"ms": round(ms, 4), "launches": len(layers), "tflops": round(gflop / ms, 2), "peak": round(gpeak, 1),
                          "frac": round(gflop / ms / gpeak, 4), "alg_GBps": round(gbytes / ms * 1e3, 1), "hbm_frac": round(gbytes / ms * 1e3 / PEAK_HBM_GBPS, 4),

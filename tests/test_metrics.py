@@ -38,3 +38,27 @@ def test_hip_path_fails_loudly_without_its_library(monkeypatch, tmp_path):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU path"):
             Generator().load_weights(init_weights(1))
+
+
+def test_ssim_matches_an_independent_windowed_form():
+    """tf.image.ssim's definition restated directly: for every 11x11 window (VALID) the Gaussian-weighted means, variances and
+    covariance, the SSIM index per window and channel, averaged — explicit loops in float64, no shared code with metrics.ssim's
+    banded-matrix filter.  (The reference's UCB step prints this metric: train_test_GSC.py:724.)"""
+    rng = np.random.default_rng(4)
+    a = rng.random((1, 20, 23, 3))
+    b = np.clip(a + 0.1 * rng.standard_normal(a.shape), 0, 1)
+    x = np.arange(11) - 5.0
+    g = np.exp(-x ** 2 / (2 * 1.5 ** 2))
+    g /= g.sum()
+    w = np.outer(g, g)
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    vals = []
+    for c in range(3):
+        for i in range(20 - 10):
+            for j in range(23 - 10):
+                pa, pb = a[0, i:i + 11, j:j + 11, c], b[0, i:i + 11, j:j + 11, c]
+                ma, mb = (w * pa).sum(), (w * pb).sum()
+                va, vb, cab = (w * pa * pa).sum() - ma * ma, (w * pb * pb).sum() - mb * mb, (w * pa * pb).sum() - ma * mb
+                vals.append((2 * ma * mb + c1) / (ma * ma + mb * mb + c1) * (2 * cab + c2) / (va + vb + c2))
+    got = float(M.ssim(torch.from_numpy(a), torch.from_numpy(b)))
+    assert abs(got - float(np.mean(vals))) < 1e-6
