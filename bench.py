@@ -273,7 +273,16 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
             layer_ms[name] = layer_ms.get(name, 0.0) + ms / n_rep
     gen.set_timing(False)
     groups = {}
-    for gname, layers in KERNEL_GROUPS.items():
+    kgroups = dict(KERNEL_GROUPS)
+    if dtype != "f32":
+        # the 16-bit kernels use 32-channel K chunks everywhere, so clr_up1 (261 -> 288 channels, NI = 2) shares the dominant instantiation
+        dom_key = [k for k in kgroups if "up2, up3, clr_up3" in k][0]
+        oth_key = [k for k in kgroups if "other instantiations" in k][0]
+        kgroups.pop(dom_key)
+        kgroups.pop(oth_key)
+        kgroups["igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=2,CC=32> (transposed 3x3: up2, up3, clr_up3, clr_up1)"] = ["up2", "up3", "clr_up3", "clr_up1"]
+        kgroups["igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=1,CC=32> (transposed 3x3: up1, clr_up2)"] = ["up1", "clr_up2"]
+    for gname, layers in kgroups.items():
         ms = sum(layer_ms.get(n, 0.0) for n in layers)
         if ms <= 0:
             continue

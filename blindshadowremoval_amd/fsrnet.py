@@ -129,6 +129,7 @@ class FSRNet(object):
             self.gen.load_weights(weights)
         self.log = Logging(config, png_threads=4)
         self.timings: Dict[str, float] = {}      # wall-clock split of the last test / testFFHQ loop (see _loop)
+        self.post_threads = 8                    # threads that post-process the items of one UCB batch
 
     # -- checkpoint -------------------------------------------------------------------------
     def _restore(self) -> int:
@@ -213,15 +214,31 @@ class FSRNet(object):
             torch.cuda.synchronize(self.gen._device)
             tm["forward_s"] += time.perf_counter() - t0
             tm["forwards"] += 1
+            post = [None] * len(pending)
+            if ucb and postprocess:
+                # train_test_GSC.py:424-748 on the host, one independent item per call: the items of a batch are post-processed by
+                # a few threads (numpy / torch release the GIL in the heavy parts), logged and saved in order afterwards
+                from .ucb_post import ucb_postprocess
+                t1 = time.perf_counter()
+
+                def one(j):
+                    step, _, _, box = pending[j]
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        return ucb_postprocess(im[j].numpy(), gt[j].numpy(), con_h[j], mask_h[j], np.asarray(box).reshape(-1)[:4],
+                                               self._read_masks(mask_files[step % len(mask_files)]))
+                if len(pending) > 1 and self.post_threads > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=min(self.post_threads, len(pending))) as ex:
+                        post = list(ex.map(one, range(len(pending))))
+                else:
+                    post = [one(j) for j in range(len(pending))]
+                tm["post_s"] += time.perf_counter() - t1
             for j, (step, name, _, box) in enumerate(pending):
                 sl = slice(j, j + 1)
                 losses: Dict[str, float] = {}
                 t1 = time.perf_counter()
-                if ucb and postprocess:                                        # train_test_GSC.py:424-748 on the host
-                    from .ucb_post import ucb_postprocess
-                    with np.errstate(invalid="ignore", divide="ignore"):
-                        losses, f = ucb_postprocess(im[j].numpy(), gt[j].numpy(), con_h[j], mask_h[j], np.asarray(box).reshape(-1)[:4],
-                                                    self._read_masks(mask_files[step % len(mask_files)]))
+                if ucb and postprocess:
+                    losses, f = post[j]
                     figs = [torch.from_numpy(a) for a in f]
                     shown = figs
                 elif ucb:

@@ -29,6 +29,8 @@ sfx = "" if dtype == "f32" else "_" + dtype
 # algorithmic activation bytes per image of the layers whose launches are summarised below: input read once + output written once (fp32)
 LAYER_IO_MB = {"up2": (64 * 64 * 160 + 128 * 128 * 64) * 4e-6, "up3": (128 * 128 * 128 + 256 * 256 * 64) * 4e-6,
                "clr_up3": (128 * 128 * 96 + 256 * 256 * 64) * 4e-6}
+if dtype != "f32":          # 32-channel K chunks everywhere: clr_up1 runs on the same instantiation (bench.py's 16-bit kernel groups)
+    LAYER_IO_MB["clr_up1"] = (32 * 32 * 261 + 64 * 64 * 128) * 4e-6
 
 
 def load(d, name):
@@ -61,7 +63,7 @@ out = m[cols].round(3)
 out.to_csv(os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.csv" % (tag, sfx)))
 is33 = out.index.str.contains("<3, 3")          # the 3x3 / stride-2 3x3 / transposed 3x3 launches (roofline kernel class)
 dom = out[out.index.str.contains("<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32")]           # igemm_{conv,h16}_kernel<3,3,1,TR,...,NI=2,CC=32>: up2, up3, clr_up3
-alg = sum(LAYER_IO_MB.values()) * 32 * 1e6 / 3
+alg = sum(LAYER_IO_MB.values()) * 32 * 1e6 / len(LAYER_IO_MB)
 summary = {
     "batch": 32, "dtype": dtype, "kernel_src_sha16": source_sha16(),
     "dominant_kernel_rows": list(dom.index),
