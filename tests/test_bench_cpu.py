@@ -63,3 +63,22 @@ def test_roofline_tables_are_consistent():
     assert sorted(grouped) == sorted(bench.LAYER_MMAC)
     assert abs(2e-3 * sum(bench.LAYER_MMAC[n] for n in bench.LAYERS_3X3) - 2e-3 * (16.78 + 3.15) - bench.GFLOP_3X3_PER_IMAGE) < 0.01
     assert bench.physical_cores() >= 1
+
+
+def test_under_torchrun_the_ranks_already_exist():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` — WORLD_SIZE is set, so
+    bench.py must NOT start ranks of its own, and stdout must carry exactly one JSON line (rank 0's)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--backend", "gloo", "--stub", "--batch", "1", "--steps", "2", "--warmup", "1",
+                        "--repeats", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["stub"] is True and j["config"]["global_batch"] == 2

@@ -70,8 +70,10 @@ def test_dataset_feed_layout():
 
 
 @pytest.mark.gpu
-def test_config1_end_to_end(tmp_path, golden_dir):
-    """BASELINE config 1: the sample_imgs face through Dataset -> FSRNet.testFFHQ on the GPU, against the oracle."""
+@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
+def test_config1_end_to_end(tmp_path, golden_dir, dtype):
+    """BASELINE config 1: the sample_imgs face (a REAL image with its real, 60 %-zero uv map) through Dataset -> FSRNet.testFFHQ on
+    the GPU, against the oracle — on the fp32 path and on the split-precision f32x3 path, same tolerance."""
     import torch
     from blindshadowremoval_amd.fsrnet import Config, FSRNet
     from blindshadowremoval_amd.weights import init_weights
@@ -81,7 +83,7 @@ def test_config1_end_to_end(tmp_path, golden_dir):
     cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "sample_imgs", "*")]
     w = init_weights(1)
     ds = D.Dataset(cfg, "test", rows=10)
-    res = FSRNet(cfg, weights=w).testFFHQ(ds)
+    res = FSRNet(cfg, weights=w, dtype=dtype).testFFHQ(ds)
     assert len(res) == 1 and os.path.isfile(os.path.join(str(tmp_path), "test", "02165_02165-result.png"))
     row, _ = D.build_row(REF_SAMPLE + ".png", REF_SAMPLE + ".npy")
     ref = test_step_ffhq(GeneratorOracle(w), torch.from_numpy(row)[None])
