@@ -88,6 +88,7 @@ struct ConvArgs {
   const float* res1;    // optional residual, NHWC at the output resolution, added before the activation
   int res1_cs, res1_c;  // channel stride; channels [0,res1_c) are read
   int tiles_x, tiles_y; // M tiles per image
+  int n_blocks;         // igemm_h16_kernel: > 0 = 1-D grid with the N block as the FASTEST index (the N blocks of a tile share its input through L2)
 #ifdef BSR_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
 #endif

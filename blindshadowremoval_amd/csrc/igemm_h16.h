@@ -122,11 +122,16 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   const int wm = wave / WN, wn = wave % WN;
 
   int bid = blockIdx.x;
+  int nb = blockIdx.y;
+  if (p.n_blocks > 0) {            // N block fastest: the workgroups that re-read one input tile are dispatched together
+    nb = bid % p.n_blocks;
+    bid /= p.n_blocks;
+  }
   const int tile_x = bid % p.tiles_x;
   bid /= p.tiles_x;
   const int tile_y = bid % p.tiles_y;
   const int img = bid / p.tiles_y;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = nb * BN;
   const int y0 = tile_y * TH, x0 = tile_x * TW;
   const int iy0 = TR ? y0 - 1 : y0 * S - p.pad_t;
   const int ix0 = TR ? x0 - 1 : x0 * S - p.pad_l;
@@ -494,7 +499,9 @@ inline hipError_t launch_igemm_h16(ConvArgs a, int batch, hipStream_t stream) {
   const int mh = TR ? a.H : a.Ho, mw = TR ? a.W : a.Wo;
   a.tiles_x = mw / TW;
   a.tiles_y = mh / TH;
-  dim3 grid(a.tiles_x * a.tiles_y * batch, (a.n_store + C::BN - 1) / C::BN);
+  const int nblk = (a.n_store + C::BN - 1) / C::BN;
+  a.n_blocks = nblk > 1 ? nblk : 0;
+  dim3 grid(a.tiles_x * a.tiles_y * batch * nblk, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }

@@ -3,6 +3,10 @@
 helpers `face_crop_and_resize`, `generate_face_region`: /root/reference/utils.py:356-433, 255-276;
 `generate_uv_map`, `generate_offset_map`: /root/reference/warp.py:194-232).
 
+`Dataset(config, 'test', dset='sfw' | 'sfw_video')` is the counterpart of the TSM script's loaders
+(/root/reference/dataset_with_TSM.py:19-79, 225-287, 289-583): elements `[1,2,256,256,17]` (frame + mirror) / `[1,10,256,256,13]`
+(ten frames of a video) for `FSRNetTSM.testsfw` / `testsfw_video`.
+
 It yields what `FSRNet.testFFHQ` / `test` consume: `.name_list` and `.feed`, an iterator of
 `(img[1,R,256,256,16], box[1,4], name)` with channel layout [img3, gt3, uvm3, reg_in3, reg_out3, face1]
 (SURVEY.md Appendix D).  No TensorFlow / OpenCV: PNGs are decoded with PIL and the three OpenCV calls on the path are
@@ -71,9 +75,17 @@ def gaussian_blur5(a: np.ndarray) -> np.ndarray:
     return sum(k[i] * tmp[i:i + a.shape[0], :] for i in range(5))
 
 
-def face_crop_and_resize(img0: np.ndarray, lm0: np.ndarray, fsize: int):
+# left/right landmark correspondence of the 68-point scheme (utils.py:360-364, 1-based there)
+LM_REVERSE = np.array([17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 28, 29, 30, 31, 36, 35, 34, 33,
+                       32, 46, 45, 44, 43, 48, 47, 40, 39, 38, 37, 42, 41, 55, 54, 53, 52, 51, 50, 49, 60, 59, 58, 57, 56, 65, 64, 63, 62, 61, 68,
+                       67, 66], np.int32) - 1
+
+
+def face_crop_and_resize(img0: np.ndarray, lm0: np.ndarray, fsize: int, with_mirror: bool = False):
     """utils.face_crop_and_resize with aug=False (utils.py:356-433): crop box from the landmark extent (x1.4, shifted up
-    by 20 %), zero-extend when it leaves the image, resize to fsize; landmarks normalised by the box size."""
+    by 20 %), zero-extend when it leaves the image, resize to fsize; landmarks normalised by the box size.
+    `with_mirror` also returns the landmarks of the horizontally flipped crop (utils.py:383-385,401-410,433), which the TSM
+    loaders pair with `flip(crop)`."""
     # dtype flow mirrors the reference: landmarks stay float32, the box centre is float32 arithmetic (int() truncation of
     # e.g. 127.999998 vs 128.0 changes the crop), the half-length is promoted to float64 by the `* 1.4` (numpy-1.x
     # scalar rules, the reference's environment)
@@ -85,6 +97,13 @@ def face_crop_and_resize(img0: np.ndarray, lm0: np.ndarray, fsize: int):
     box = [int(center[0]) - int(length), int(center[1]) - int(length * 1.2),
            int(center[0]) + int(length), int(center[1]) + int(length) + int(length) - int(length * 1.2)]
     box0 = list(box)
+    lm_m = None
+    if with_mirror:
+        lm_m = np.array(lm, np.float32)
+        lm_m[:, 0] = np.float32(w) - lm_m[:, 0]
+        lm_m = lm_m[LM_REVERSE, :]
+        lm_m[:, 0] = lm_m[:, 0] - np.float32(w - box[2])          # box_m = [W - box[2], box[1], W - box[0], box[3]]
+        lm_m[:, 1] = lm_m[:, 1] - np.float32(box[1])
     lm[:, 0] = lm[:, 0] - np.float32(box[0])
     lm[:, 1] = lm[:, 1] - np.float32(box[1])
     px = max(-box[0], box[2] - w) if (box[0] < 0 or box[2] > w) else 0
@@ -99,6 +118,8 @@ def face_crop_and_resize(img0: np.ndarray, lm0: np.ndarray, fsize: int):
         img = resize_linear(img, fsize)
     else:
         img = np.zeros((fsize, fsize, img.shape[2]))
+    if with_mirror:
+        return img, lm / np.float32(length * 2), lm_m / np.float32(length * 2), box0
     return img, lm / np.float32(length * 2), box0
 
 
@@ -154,10 +175,77 @@ def build_row(img_path: str, lm_path: str, gt_path: Optional[str] = None, size: 
     return np.concatenate([crop, uvm, reg_in, reg_out, face], axis=2).astype(np.float32), np.asarray(box, np.float32)
 
 
+def _maps(lm: np.ndarray, size: int):
+    """uvm, reg_in, reg_out, face of one set of normalised landmarks (dataset_with_TSM.py:256-259)."""
+    uv, lm_ref = _face_model()
+    return (generate_uv_map(lm, uv, size), generate_offset_map(lm, lm_ref, size), generate_offset_map(lm_ref, lm, size),
+            generate_face_region(lm, size))
+
+
+def imread_gray(path: str) -> np.ndarray:
+    """cv2.imread(path, 0): 8-bit grey levels, NOT divided by 255 (dataset_with_TSM.py:243: label values 0 / 1 / 2)."""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("L"), np.float64)
+
+
+def build_sfw_pair(label_path: str, size: int = 256) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """`parse_fn_test_sfw` of /root/reference/dataset_with_TSM.py:225-287: one SFW frame + its mirror image as a group of two,
+    `[2, size, size, 17]` = [img3, cmap3, mask1, uvm3, reg_in3, reg_out3, face1].  Files: `<f>_label.png` (mask), `<f>_label_cmap.png`,
+    `<f>.png`, `<f>.npy`."""
+    stem = label_path.rsplit(".", 1)[0]
+    frame = stem[:-6]                                                   # strips "_label"
+    img = imread_rgb(frame + ".png")
+    cmap = imread_rgb(stem + "_cmap.png")
+    mask = imread_gray(label_path)[:, :, None]
+    crop, lm, lm_m, box = face_crop_and_resize(np.concatenate([img, cmap, mask], axis=2), np.load(frame + ".npy"), size, with_mirror=True)
+    uvm, reg_in, reg_out, face = _maps(lm, size)
+    img1 = np.concatenate([crop, uvm, reg_in, reg_out, face], axis=2)
+    uvm_m, reg_in_m, reg_out_m, face_m = _maps(lm_m, size)
+    img2 = np.concatenate([img1[:, ::-1, :7], uvm_m, reg_in_m, reg_out_m, face_m], axis=2)      # cv2.flip(img1[:, :, :7], 1)
+    return np.stack([img1, img2], axis=0).astype(np.float32)[None], np.asarray(box, np.float32)[None], np.array([(frame + ".png").encode()])
+
+
+def sfw_video_frames(frame: int) -> List[int]:
+    """The ten frame numbers `parse_fn_test_sfw_video` groups with `frame` (dataset_with_TSM.py:325-382)."""
+    if frame < 3:
+        off = (2, 4, 6, 8, 10, 12, 14, 16, 1)
+    elif frame < 5:
+        off = (1, 3, 5, 7, 9, 11, 13, 15, -2)
+    elif frame < 7:
+        off = (1, 3, 5, 7, 9, 11, 13, -2, -4)
+    elif frame < 9:
+        off = (1, 3, 5, 7, 9, 11, -2, -4, -6)
+    elif frame > 100:
+        off = (-1, -3, -5, -7, -9, -11, -2, -4, -6)
+    else:
+        off = (1, 3, 5, 7, 9, -2, -4, -6, -8)
+    return [frame] + [frame + o for o in off]
+
+
+def build_sfw_video(label_path: str, size: int = 256) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """`parse_fn_test_sfw_video` (dataset_with_TSM.py:289-583): ten frames of one video as a group, `[10, size, size, 13]` =
+    [img3, uvm3, reg_in3, reg_out3, face1] each; the box returned is the LAST frame's (the reference overwrites `box`)."""
+    stem = label_path.rsplit(".", 1)[0]                                  # the reference names frames <n>.png / <n>.npy and lists <n>.png's label
+    folder, first = os.path.dirname(stem), int(os.path.basename(stem).split("_")[0].split(".")[0])
+    rows, box = [], None
+    for f in sfw_video_frames(first):
+        base = os.path.join(folder, str(f))
+        if not os.path.isfile(base + ".png"):
+            raise FileNotFoundError("SFW video group of frame %d needs %s.png (the reference blocks on input() here)" % (first, base))
+        crop, lm, box = face_crop_and_resize(imread_rgb(base + ".png"), np.load(base + ".npy"), size)
+        uvm, reg_in, reg_out, face = _maps(lm, size)
+        rows.append(np.concatenate([crop, uvm, reg_in, reg_out, face], axis=2))
+    return np.stack(rows, axis=0).astype(np.float32)[None], np.asarray(box, np.float32)[None], np.array([(os.path.join(folder, str(first)) + ".png").encode()])
+
+
 def build_element(job) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """One dataset element `(img[1,R,size,size,16], box[1,4], name[1])` from a job `(lm_path, gt_path, sibling lm paths, size)`.
     Top-level so that worker processes can run it (the rows of an element never depend on another element)."""
     lm_path, gt_path, siblings, size = job
+    if gt_path == "<sfw>":
+        return build_sfw_pair(lm_path, size)
+    if gt_path == "<sfw_video>":
+        return build_sfw_video(lm_path, size)
     img_path = os.path.splitext(lm_path)[0] + ".png"
     row0, box = build_row(img_path, lm_path, gt_path, size)
     rows = [row0]
@@ -179,9 +267,9 @@ class Dataset:
 
     def __init__(self, config, mode: str = "test", dset=None, ucb: bool = False, rows: int = 1, seed: int = 0,
                  workers: int = 0, prefetch: Optional[int] = None):
-        if mode != "test" or dset is not None:
-            raise NotImplementedError("only the GSC test loaders are provided (training / SFW loaders are out of scope)")
-        self.config, self.mode, self.ucb, self.rows = config, mode, ucb, rows
+        if mode != "test" or dset not in (None, "sfw", "sfw_video"):
+            raise NotImplementedError("only the test loaders are provided (GSC: dset=None; TSM: dset='sfw' | 'sfw_video'); training loaders are out of scope")
+        self.config, self.mode, self.ucb, self.rows, self.dset = config, mode, ucb, rows, dset
         self._rng = random.Random(seed)
         if workers < 0:
             workers = min(os.cpu_count() or 1, 16)
@@ -189,9 +277,10 @@ class Dataset:
         self.prefetch = int(prefetch) if prefetch is not None else max(2, 2 * self.workers)
         self._pool = None
         self.name_list: List[str] = []
-        for d in config.DATA_DIR_TEST:                                     # dataset.py:55-61
+        pattern = "*.npy" if dset is None else "*_label.png"               # dataset.py:55-61 | dataset_with_TSM.py:63
+        for d in config.DATA_DIR_TEST:
             for folder in sorted(glob.glob(d), key=natural_key):
-                self.name_list += sorted(glob.glob(os.path.join(folder, "*.npy")), key=natural_key)
+                self.name_list += sorted(glob.glob(os.path.join(folder, pattern)), key=natural_key)
         self.feed: Iterator = self._iterate()
 
     def _gt_path(self, lm_path: str) -> Optional[str]:
@@ -203,6 +292,10 @@ class Dataset:
     def _jobs(self):
         """Jobs in name_list order; the sibling draws consume the seeded RNG in that order whatever the worker count."""
         size = self.config.IMG_SIZE
+        if self.dset is not None:                                          # TSM loaders: the element is a group of 2 / 10 coupled frames
+            for label in self.name_list:
+                yield (label, "<" + self.dset + ">", [], size)
+            return
         for lm_path in self.name_list:
             sibs = []
             if self.rows > 1:

@@ -182,3 +182,30 @@ def test_resize_linear_is_opencv_inter_linear():
         t = torch.from_numpy(a).permute(2, 0, 1)[None]
         want = torch.nn.functional.interpolate(t, size=(256, 256), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
         assert np.abs(D.resize_linear(a, 256) - want).max() < 1e-12
+
+
+def test_tsm_loaders_match_the_reference_parsers(golden_dir):
+    """Dataset(config, 'test', dset='sfw' | 'sfw_video') against tests/golden/sfw_elements.npz — the output of the reference's OWN
+    `parse_fn_test_sfw` / `parse_fn_test_sfw_video` (/root/reference/dataset_with_TSM.py:225-287, 289-583) on the synthetic SFW
+    folder tests/golden/sfw_synth (tools/make_sfw_fixture.py; every 4th pixel + per-channel sums are stored)."""
+    z = np.load(os.path.join(golden_dir, "sfw_elements.npz"))
+    cfg = type("C", (), {"DATA_DIR_TEST": [os.path.join(golden_dir, "sfw_synth", "*")], "IMG_SIZE": 256})()
+    ds = D.Dataset(cfg, "test", dset="sfw")
+    assert [os.path.basename(n) for n in ds.name_list] == ["1_label.png", "10_label.png"]          # natural order
+    for n in (1, 10):
+        img, box, name = next(ds.feed)
+        assert img.shape == (1, 2, 256, 256, 17) and img.dtype == np.float32 and name[0].endswith(b"/%d.png" % n)
+        assert np.abs(img[0][:, ::4, ::4, :] - z["pair%d" % n]).max() < 2e-6
+        assert np.abs(img[0].astype(np.float64).sum(axis=(1, 2)) - z["pair%d_sum" % n]).max() < 2e-2
+        assert np.array_equal(box[0], z["pair%d_box" % n])
+        # the mirror row really is the flipped frame with the mirrored landmark maps
+        assert np.array_equal(img[0, 1, :, :, :7], img[0, 0, :, ::-1, :7]) and not np.array_equal(img[0, 1, ..., 7:], img[0, 0, :, ::-1, 7:])
+    dv = D.Dataset(cfg, "test", dset="sfw_video", workers=2)
+    for n in (1, 10):
+        img, box, name = next(dv.feed)
+        assert img.shape == (1, 10, 256, 256, 13)
+        assert np.abs(img[0][:, ::4, ::4, :] - z["video%d" % n]).max() < 2e-6
+        assert np.abs(img[0].astype(np.float64).sum(axis=(1, 2)) - z["video%d_sum" % n]).max() < 2e-2
+        assert np.array_equal(box[0], z["video%d_box" % n])
+    assert D.sfw_video_frames(1) == [1, 3, 5, 7, 9, 11, 13, 15, 17, 2] and D.sfw_video_frames(10) == [10, 11, 13, 15, 17, 19, 8, 6, 4, 2]
+    assert D.sfw_video_frames(150)[:3] == [150, 149, 147]

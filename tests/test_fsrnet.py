@@ -144,6 +144,35 @@ def test_tsm_harness_steps(tmp_path):
 
 
 @pytest.mark.gpu
+def test_tsm_loops_over_the_sfw_loaders(tmp_path, golden_dir):
+    """The TSM script's two test loops end to end: `Dataset(config, 'test', dset='sfw' | 'sfw_video')` (pinned to the reference's
+    own parsers by tests/test_dataset.py) -> `FSRNetTSM.testsfw` / `testsfw_video` (train_with_TSM.py:619-748) on the synthetic
+    SFW folder, outputs against the TSM oracle on the same elements."""
+    import os
+    from blindshadowremoval_amd import dataset as D
+    from blindshadowremoval_amd.fsrnet import Config, FSRNetTSM
+    from oracle.gsc_oracle import GeneratorTSMOracle
+    w = init_weights(1, variant="tsm")
+    cfg = Config(0)
+    cfg.CHECKPOINT_DIR = str(tmp_path)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "sfw_synth", "*")]
+    fsr = FSRNetTSM(cfg, weights=w)
+    res = fsr.testsfw(D.Dataset(cfg, "test", dset="sfw", workers=2))
+    assert len(res) == 2 and all(0.0 <= r[1]["auc"] <= 1.0 and np.isfinite(r[1]["psnr"]) for r in res)
+    el = torch.from_numpy(next(D.Dataset(cfg, "test", dset="sfw").feed)[0][0])                      # [2,256,256,17]
+    img, _, _, uv, reg, face = torch.split(el, [3, 3, 1, 3, 6, 1], dim=3)
+    ref = GeneratorTSMOracle(w)(img, uv, reg, 2, True)
+    assert float((res[0][2][1].cpu() - ref[1].clamp(0, 1)).abs().max()) <= 1e-3
+    vid = fsr.testsfw_video(D.Dataset(cfg, "test", dset="sfw_video", workers=2))
+    assert len(vid) == 2 and vid[0][2][1].shape == (10, 256, 256, 3)
+    el = torch.from_numpy(next(D.Dataset(cfg, "test", dset="sfw_video").feed)[0][0])                # [10,256,256,13]
+    img, uv, reg, face = torch.split(el, [3, 3, 6, 1], dim=3)
+    ref = GeneratorTSMOracle(w)(img, uv, reg, 10, True)
+    assert float((vid[0][2][1].cpu() - ref[1].clamp(0, 1)).abs().max()) <= 1e-3
+    assert len([f for f in os.listdir(os.path.join(str(tmp_path), "test")) if f.endswith("-result.png")]) == 2      # same names for both loops
+
+
+@pytest.mark.gpu
 def test_tsm_512_frames():
     """BASELINE config 5 names 512x512 frames: the kernels are size-generic (S = 64 attention over 4096 tokens)."""
     from blindshadowremoval_amd import GeneratorTSM
