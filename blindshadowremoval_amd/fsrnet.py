@@ -78,12 +78,13 @@ class Logging(object):
         """clip*255, grey -> 3 channels, take batch row 0, concatenate horizontally (utils.py:217-233).
         Returned as RGB uint8 (the reference swaps to BGR only because cv2.imwrite expects BGR)."""
         column = []
-        for img in fig:
-            img = torch.clamp(img[:1].detach().float().cpu(), 0.0, 1.0) * 255
-            if img.shape[3] == 1:
-                img = torch.cat([img, img, img], dim=3)
-            column.append(img[0, :, :, :3])
-        return np.rint(torch.cat(column, dim=1).numpy()).astype(np.uint8)
+        for img in fig:          # numpy on the host: tiny torch CPU ops cost milliseconds each on a many-core box (intra-op thread pool)
+            a = (img[:1].detach().float().cpu().numpy() if isinstance(img, torch.Tensor) else np.asarray(img, np.float32)[:1])
+            a = np.clip(a, 0.0, 1.0) * np.float32(255)
+            if a.shape[3] == 1:
+                a = np.repeat(a, 3, axis=3)
+            column.append(a[0, :, :, :3])
+        return np.rint(np.concatenate(column, axis=1)).astype(np.uint8)
 
     def save_img(self, fig: Sequence[torch.Tensor], fname: str) -> str:
         strip = self.get_imgs(fig)
@@ -208,7 +209,9 @@ class FSRNet(object):
             rows = torch.cat([self._split_row0(p[2]) for p in pending], dim=0)
             im, gt, uv, reg, face = torch.split(rows, list(SPLIT_FFHQ), dim=3)
             dev = "cuda:%d" % self.gen._device
-            gs, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg, chuck=4 if ucb else 1, training=False)
+            rows_d = rows.to(dev)                                   # ONE host-to-device copy of the packed rows; the channel slices are cut on the GPU
+            im_d, _, uv_d, _, _ = torch.split(rows_d, list(SPLIT_FFHQ), dim=3)
+            gs, con_rgb, _, mask_pred = self.gen(im_d, uv_d, reg, chuck=4 if ucb else 1, training=False)
             if ucb and postprocess:
                 con_h, mask_h = con_rgb.cpu().numpy(), mask_pred.cpu().numpy()
             torch.cuda.synchronize(self.gen._device)
