@@ -11,6 +11,12 @@
 //   O^T[d][q]   += sum_key g[key][d] * P^T[key][q]      A = g tile (LDS), B = P (registers), no LDS round trip.
 // The d index of the four O^T tiles is interleaved (tile dt, row i  <->  d = 4*i + dt) so one ds_read_b128
 // of g[key][4i..4i+3] feeds four MFMAs.
+//
+// Round 2: a workgroup is 8 waves = 128 queries x TWO key streams (waves 0-3 take the even 32-key tiles, waves 4-7 the odd ones,
+// each with its own running max / sum / O^T, merged through LDS at the end).  With one wave per SIMD the softmax VALU work, the
+// LDS publish and the barrier of every tile sat between that wave's two MFMA phases with nothing to fill the matrix pipe; with two
+// waves per SIMD on different tiles the partner's MFMAs run meanwhile (fp32 MFMAs starve a co-resident wave's VALU to one issue
+// per ~25 cycles, but a tile's ~65 VALU instructions still fit inside the partner's 8 192-cycle MFMA phase).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "igemm_conv.h"
@@ -21,12 +27,16 @@ constexpr int kAttD = 128;        // C/2 of the 257-channel NonLocalBlock (/root
 constexpr int kAttKT = 32;        // keys per LDS stage
 constexpr int kAttLdK = kAttD + 4;
 constexpr float kRescaleThreshold = 8.f;   // log2 units
-constexpr int kAttStageFloats = kAttKT * kAttLdK + kAttKT * kAttD;
-constexpr int kAttSmemBytes = 2 * kAttStageFloats * 4;
+constexpr int kAttStageFloats = kAttKT * kAttLdK + kAttKT * kAttD;     // one 32-key tile: phi rows (padded) + g rows
+constexpr int kAttSmemBytes = 4 * kAttStageFloats * 4;                  // two tile PAIRS (double buffer)
+static_assert(kAttSmemBytes <= 160 * 1024, "LDS budget");
+static_assert(66 * 64 * 4 <= 4 * kAttStageFloats, "merge scratch fits the staging buffers");
 
-__global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
+__global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3;                    // key stream (even / odd tiles), query block of 32
   const int h = lane >> 5, r = lane & 31;
   // Workgroup -> (image, query block).  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2;
   // all query blocks of an image re-read the same K/V (1 MB), so they are given ids that are congruent mod 8 and thus share
@@ -46,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float*
     }
   }
   const float* base = qkv + (size_t)img * tokens * (3 * kAttD);
-  const int q = qb * 128 + wave * 32 + r;
+  const int q = qb * 128 + wq * 32 + r;
 
   // theta fragment of this lane's query: element j of group g is channel 8g + 4h + j
   f32x4 qf[kAttD / 8];
@@ -61,39 +71,41 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float*
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  constexpr int V4_PER_STAGE = kAttKT * kAttD / 4;      // 1024 float4 per operand -> 4 per thread
-  f32x4 kreg[V4_PER_STAGE / 256], vreg[V4_PER_STAGE / 256];
-  auto fetch = [&](int kt) {
+  // staging of a tile PAIR (2p, 2p+1) by 512 threads: 2 x 1024 float4 per operand -> 4 + 4 per thread; float4 i of a thread belongs
+  // to tile 2p + (i >> 1)
+  constexpr int V4_PER_TILE = kAttKT * kAttD / 4;       // 1024
+  f32x4 kreg[4], vreg[4];
+  auto fetch = [&](int pr) {
 #pragma unroll
-    for (int i = 0; i < V4_PER_STAGE / 256; ++i) {
-      const int idx = tid + i * 256;
+    for (int i = 0; i < 4; ++i) {
+      const int idx = (tid + i * 512) & (V4_PER_TILE - 1), tile = 2 * pr + ((tid + i * 512) >> 10);
       const int key = idx / (kAttD / 4), c4 = idx % (kAttD / 4);
-      const float* row = base + (size_t)(kt * kAttKT + key) * (3 * kAttD);
+      const float* row = base + (size_t)(tile * kAttKT + key) * (3 * kAttD);
       kreg[i] = *reinterpret_cast<const f32x4*>(row + kAttD + c4 * 4);
       vreg[i] = *reinterpret_cast<const f32x4*>(row + 2 * kAttD + c4 * 4);
     }
   };
-  auto publish = [&](int buf) {
-    float* sk = smem + buf * kAttStageFloats;
-    float* sv = sk + kAttKT * kAttLdK;
+  auto publish = [&](int pbuf) {
 #pragma unroll
-    for (int i = 0; i < V4_PER_STAGE / 256; ++i) {
-      const int idx = tid + i * 256;
+    for (int i = 0; i < 4; ++i) {
+      const int idx = (tid + i * 512) & (V4_PER_TILE - 1), sel = (tid + i * 512) >> 10;
       const int key = idx / (kAttD / 4), c4 = idx % (kAttD / 4);
+      float* sk = smem + (2 * pbuf + sel) * kAttStageFloats;
+      float* sv = sk + kAttKT * kAttLdK;
       *reinterpret_cast<f32x4*>(sk + key * kAttLdK + c4 * 4) = kreg[i];
       *reinterpret_cast<f32x4*>(sv + key * kAttD + c4 * 4) = vreg[i];
     }
   };
 
-  const int nkt = tokens / kAttKT;
+  const int npair = tokens / (2 * kAttKT);
   fetch(0);
   publish(0);
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) fetch(kt + 1);
-    const float* sk = smem + buf * kAttStageFloats;
+  for (int pr = 0; pr < npair; ++pr) {
+    const int pbuf = pr & 1;
+    if (pr + 1 < npair) fetch(pr + 1);
+    const float* sk = smem + (2 * pbuf + grp) * kAttStageFloats;      // this wave's tile of the pair
     const float* sv = sk + kAttKT * kAttLdK;
 
     // S^T tile: rows = keys (A from LDS), cols = queries (B from registers)
@@ -110,8 +122,7 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float*
     // online softmax for this lane's query: 16 keys here + 16 in lane^32.  Logits are in the log2 domain (theta was
     // pre-scaled by log2 e), so P = exp2(s - m) is one v_exp_f32 per element.  The running maximum is only raised — and O^T, l
     // rescaled — when some query's tile maximum exceeds it by more than kRescaleThreshold (P <= 2^8 stays far inside
-    // fp32 range): fp32 VALU work cannot hide under the matrix pipe on gfx950, so the 64 rescale multiplies are skipped
-    // on almost every tile.
+    // fp32 range).
     float mx = s[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
@@ -143,10 +154,34 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float*
       for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[dt], s[i], o[dt], 0, 0, 0);
     }
 
-    if (kt + 1 < nkt) {
-      publish(buf ^ 1);
+    if (pr + 1 < npair) {
+      publish(pbuf ^ 1);
       __syncthreads();
     }
+  }
+
+  // merge the two key streams: waves 4-7 hand (m, l, O^T) to waves 0-3 through LDS ([wq][66 values][64 lanes])
+  __syncthreads();
+  float* sx = smem + (size_t)wq * 66 * 64 + lane;
+  if (grp == 1) {
+    sx[0] = m_run;
+    sx[64] = l_run;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sx[(2 + dt * 16 + i) * 64] = o[dt][i];
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  {
+    const float m1 = sx[0], l1 = sx[64];
+    const float m = fmaxf(m_run, m1);
+    const float s0 = __builtin_amdgcn_exp2f(m_run - m), s1 = __builtin_amdgcn_exp2f(m1 - m);
+    l_run = l_run * s0 + l1 * s1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] = o[dt][i] * s0 + sx[(2 + dt * 16 + i) * 64] * s1;
   }
 
   // combine the two key halves' partial sums, normalise, store y[q][d], d = 4*row + dt
@@ -162,6 +197,7 @@ __global__ __launch_bounds__(256, 1) void nonlocal_attention_kernel(const float*
 }
 
 inline hipError_t launch_nonlocal_attention(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
+  if (tokens % (2 * kAttKT) != 0) return hipErrorInvalidValue;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {
@@ -170,7 +206,7 @@ inline hipError_t launch_nonlocal_attention(const float* qkv, float* out, int ba
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
-  hipLaunchKernelGGL(nonlocal_attention_kernel, dim3(batch * (tokens / 128)), dim3(256), kAttSmemBytes, stream, qkv, out, tokens);
+  hipLaunchKernelGGL(nonlocal_attention_kernel, dim3(batch * (tokens / 128)), dim3(512), kAttSmemBytes, stream, qkv, out, tokens);
   return hipGetLastError();
 }
 
