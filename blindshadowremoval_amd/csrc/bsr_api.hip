@@ -195,9 +195,10 @@ struct Launcher {
   }
 
   // KH,KW,S,TR,TH,TW,WM,WN,MI,NI,CC,PF_IN
+  // io (f16 mode only): bit 0 = `in` is an fp16 tensor, bit 1 = `out` is written as fp16 (the fp16 activation pack of configs[3])
   template <int KH, int KW, int S, bool TR, int NI, int CC, int INB>
   void conv(int cls, const char* name, const float* in, int in_cs, int in_coff, int k_pad, int H, int W, float* out, int out_cs,
-            int out_coff, int n_store, int act) {
+            int out_coff, int n_store, int act, int io = 0) {
     if (rc != BSR_OK) return;
     using C = bsr::ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
     constexpr bool k33 = (KH == 3 && KW == 3);
@@ -242,8 +243,12 @@ struct Launcher {
       check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
     else if (nsplit == 2)
       check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 2>(a, h->B, s), name);
-    else if constexpr (k33)
-      check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1>(a, h->B, s), name);
+    else if constexpr (k33) {
+      if (io == 3) check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1, 3>(a, h->B, s), name);
+      else if (io == 2) check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1, 2>(a, h->B, s), name);
+      else if (io == 1) check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1, 1>(a, h->B, s), name);
+      else check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1, 0>(a, h->B, s), name);
+    }
     end();
   }
   // 1x1 conv as a resident-activation GEMM (K = NCH*32) over all N
@@ -288,8 +293,10 @@ struct Launcher {
     begin(cls, name);
     if (h->dtype == BSR_DTYPE_F32)
       check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW, 0>(a, h->B, s), name);
+    else if (h->dtype == BSR_DTYPE_F16)
+      check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW, 2, true>(a, h->B, s), name);      // f16 mode: its input tensor is fp16
     else
-      check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW, 2>(a, h->B, s), name);      // split precision in both 16-bit modes
+      check(bsr::launch_conv_n16<KH, KW, GS, TAIL, RW, 2>(a, h->B, s), name);            // split precision
     end();
   }
 };
@@ -507,7 +514,9 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     if (L.rc == BSR_OK) {
       bsr::StemArgs a{inputs, ws + p.x1, l.w, l.b, H, W, 0, 0};
       L.begin(K_CONV7, "conv1");
-      if (x3)
+      if (h->dtype == BSR_DTYPE_F16)
+        L.check((bsr::launch_stem7<4, 2, true>(a, B, s)), "conv1");                 // x1 stored as fp16
+      else if (x3)
         L.check(bsr::launch_stem7<4, 2>(a, B, s), "conv1");
       else
         L.check(bsr::launch_stem7<4, 0>(a, B, s), "conv1");
@@ -515,9 +524,14 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     }
   }
   // down1..3 = Conv(stride 2) (model.py:207-209,231-233); x2 / x3 land in their skip-concat slots (model.py:244-245)
-  L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down1", ws + p.x1, 32, 0, 32, H, W, ws + p.c3, 128, 64, 64, 1);
-  L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down2", ws + p.c3, 128, 64, 64, H2, W2, ws + p.c2, 160, 96, 64, 1);
-  L.conv<3, 3, 2, false, 3, 16, 1>(K_CONV3, "down3", ws + p.c2, 160, 96, 64, H4, W4, ws + p.xa, V.cs_a, 0, 96, 1);
+  // f16 mode (the fp16 pack of BASELINE configs[3]): the full- / half- / quarter-resolution tensors between the 3x3-conv layers —
+  // x1, c3 = [up2 | x2], c2 = [up1 | x3], y, f1, f2, f — live in HBM as fp16 (same workspace slots, first half used); the
+  // 1/8-resolution trunk (xa, t1, t2, r*, y3x, qkv, att) and the four outputs stay fp32.  IO16: 1 = fp16 input, 2 = fp16 output.
+  const bool p16 = h->dtype == BSR_DTYPE_F16;
+  const int io_both = p16 ? 3 : 0, io_in = p16 ? 1 : 0, io_out = p16 ? 2 : 0;
+  L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down1", ws + p.x1, 32, 0, 32, H, W, ws + p.c3, 128, 64, 64, 1, io_both);
+  L.conv<3, 3, 2, false, 2, 16, 1>(K_CONV3, "down2", ws + p.c3, 128, 64, 64, H2, W2, ws + p.c2, 160, 96, 64, 1, io_both);
+  L.conv<3, 3, 2, false, 3, 16, 1>(K_CONV3, "down3", ws + p.c2, 160, 96, 64, H4, W4, ws + p.xa, V.cs_a, 0, 96, 1, io_in);
   // uv = resize(uv, [h,w]); x = cat[x, uv] (model.py:237-238) and the uv slot of cat[x_hole, bmask, uv] (model.py:259)
   glue_begin("uv_resize8");
   hipLaunchKernelGGL(bsr::uv_resize8_kernel, dim3((unsigned)((ncell * 3 + 255) / 256)), dim3(256), 0, s, uv, H, W, ws + p.xa, V.cs_a, V.uv_a,
@@ -577,9 +591,9 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   res_block(2, ws + p.r[1], V.cs_r, V.c_r);
 
   // greyscale decoder: up1..3 = ConvT (model.py:243-245)
-  L.conv<3, 3, 1, true, 1, 24, 1>(K_CONVT, "up1", ws + p.r[2], V.cs_r, 0, V.cs_r, H8, W8, ws + p.c2, 160, 0, 96, 1);
-  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1);
-  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1);
+  L.conv<3, 3, 1, true, 1, 24, 1>(K_CONVT, "up1", ws + p.r[2], V.cs_r, 0, V.cs_r, H8, W8, ws + p.c2, 160, 0, 96, 1, io_out);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1, io_both);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1, io_both);
   // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
   L.conv16<7, 1, false, false, 2>(K_CONV7, "heads", ws + p.ybuf, 64, H, W, ws + p.qh, 16, 0, nullptr, nullptr, nullptr, nullptr);
   glue_begin("heads_post");
@@ -598,9 +612,9 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   res_block(5, ws + p.r[4], V.cs_h, V.c_h);
 
   // colour decoder (model.py:264-269)
-  L.conv<3, 3, 1, true, 2, 24, 1>(K_CONVT, "clr_up1", ws + p.r[5], V.cs_h, 0, V.cs_h, H8, W8, ws + p.f1, 128, 0, 128, 1);
-  L.conv<3, 3, 1, true, 1, 32, 1>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1);
-  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1);
+  L.conv<3, 3, 1, true, 2, 24, 1>(K_CONVT, "clr_up1", ws + p.r[5], V.cs_h, 0, V.cs_h, H8, W8, ws + p.f1, 128, 0, 128, 1, io_out);
+  L.conv<3, 3, 1, true, 1, 32, 1>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1, io_both);
+  L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1, io_both);
   // clr_conv1 (3x3 over cat[gs, f]) + clr_conv2 + clr_conv3 + dif, one kernel (model.py:267-269,288)
   L.conv16<3, 3, true, true, 2>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, H, W, nullptr, 0, 1, gs, inputs, con_rgb, dif);
   if (L.rc == BSR_OK) h->ran = true;
@@ -642,7 +656,8 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Plan& p = h->plan;
   const int B = h->B, H = h->H, W = h->W;
-  struct Src { size_t off; int hh, ww, cs, coff, c; };
+  struct Src { size_t off; int hh, ww, cs, coff, c; bool half; };
+  const bool p16 = h->dtype == BSR_DTYPE_F16;          // the tensors the f16 mode keeps as fp16 (forward_impl)
   Src src{};
   std::string nm(name);
   auto res_idx = [&](const char* prefix) -> int {
@@ -651,28 +666,28 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
     return -1;
   };
   int i;
-  if (nm == "x1") src = {p.x1, H, W, 32, 0, 32};
-  else if (nm == "x2") src = {p.c3, H / 2, W / 2, 128, 64, 64};
-  else if (nm == "x3") src = {p.c2, H / 4, W / 4, 160, 96, 64};
+  if (nm == "x1") src = {p.x1, H, W, 32, 0, 32, p16};
+  else if (nm == "x2") src = {p.c3, H / 2, W / 2, 128, 64, 64, p16};
+  else if (nm == "x3") src = {p.c2, H / 4, W / 4, 160, 96, 64, p16};
   else if (nm == "x0") src = {p.xa, H / 8, W / 8, h->var.cs_a, 0, h->var.c_a};
   else if ((i = res_idx("res")) >= 0) src = {p.r[i], H / 8, W / 8, i < 3 ? h->var.cs_r : h->var.cs_h, 0, i < 3 ? h->var.c_r : h->var.c_h};
   else if ((i = res_idx("att")) >= 0) src = {p.att[i], H / 8, W / 8, 128, 0, 128};
   else if ((i = res_idx("y3x")) >= 0) src = {p.y3[i], H / 8, W / 8, CS_Y3X, 0, CS_Y3X};
-  else if (nm == "up1") src = {p.c2, H / 4, W / 4, 160, 0, 96};
-  else if (nm == "up2") src = {p.c3, H / 2, W / 2, 128, 0, 64};
-  else if (nm == "y") src = {p.ybuf, H, W, 64, 0, 64};
+  else if (nm == "up1") src = {p.c2, H / 4, W / 4, 160, 0, 96, p16};
+  else if (nm == "up2") src = {p.c3, H / 2, W / 2, 128, 0, 64, p16};
+  else if (nm == "y") src = {p.ybuf, H, W, 64, 0, 64, p16};
   else if (nm == "d32") src = {p.probe, H / 8, W / 8, 2, 0, 1};
   else if (nm == "bmask") src = {p.probe, H / 8, W / 8, 2, 1, 1};
   else if (nm == "xh") src = {p.xh, H / 8, W / 8, h->var.cs_h, 0, h->var.c_h};
-  else if (nm == "f1") src = {p.f1, H / 4, W / 4, 128, 0, 128};
-  else if (nm == "f2") src = {p.f2, H / 2, W / 2, 96, 0, 96};
-  else if (nm == "f") src = {p.cf, H, W, CS_CF, 0, 64};
+  else if (nm == "f1") src = {p.f1, H / 4, W / 4, 128, 0, 128, p16};
+  else if (nm == "f2") src = {p.f2, H / 2, W / 2, 96, 0, 96, p16};
+  else if (nm == "f") src = {p.cf, H, W, CS_CF, 0, 64, p16};
   else return fail(BSR_ERR_STATE, std::string("bsr_probe: unknown probe '") + name + "'");
   const size_t npix = (size_t)B * src.hh * src.ww;
   shape4[0] = B; shape4[1] = src.hh; shape4[2] = src.ww; shape4[3] = src.c;
   if (npix * src.c > cap_floats) return fail(BSR_ERR_ARG, "bsr_probe: destination too small");
   hipLaunchKernelGGL(bsr::slice_copy_kernel, dim3((unsigned)((npix * src.c + 255) / 256)), dim3(256), 0, s, h->ws + src.off, src.cs, src.coff,
-                     src.c, dst, npix);
+                     src.c, dst, npix, src.half ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return BSR_OK;
 }

@@ -58,8 +58,11 @@ struct ConvN16Cfg {
 // when the staged registers are written to LDS, the weight image is pack_taps_h16's, and one tap of a 32-channel chunk is ONE
 // K = 32 step of three instructions (hi.hi + hi.lo + lo.hi) instead of eight fp32 ones.  Lane (r = l & 15, q = l >> 4) holds
 // k = 8q .. 8q+7 of A and B; C/D is the fp32 instruction's layout, so the gs K group and the fused 1x1 tail stay as they are.
-template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0>
+// IN16 (with H = 2, the f16 mode): p.in is an fp16 tensor (in_cs counts halves).  Its values ARE the hi plane — the lo plane and the
+// weight-hi x input-lo instruction disappear: 2 instead of 3 matrix instructions per tap, 8-byte loads instead of 16.
+template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0, bool IN16 = false>
 __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
+  static_assert(!IN16 || H == 2, "fp16 input belongs to the 16-bit kernel");
   using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, TW = C::TW, TH = C::TH, MT = C::MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -103,28 +106,44 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   const unsigned lds_h = (unsigned)((hrow * IW + hcol) * LDP + c4 * 4) * 4u;
   auto fetch_in = [&](const Tile& d, int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
     const int iy0 = d.y0 - p.pad_t, ix0 = d.x0 - p.pad_l;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.in + (((ptrdiff_t)d.img * p.H + iy0) * p.W + ix0) * p.in_cs);
+    constexpr unsigned IB = IN16 ? 2u : 4u;                     // bytes per input element
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(reinterpret_cast<const float*>(
+        reinterpret_cast<const char*>(p.in) + (((ptrdiff_t)d.img * p.H + iy0) * p.W + ix0) * p.in_cs * (ptrdiff_t)IB));
     const bool colm_ok = ix0 + pxm >= 0 && ix0 + pxm < p.W;
-    const unsigned voff_m = colm_ok ? (unsigned)(pxm * p.in_cs + c4 * 4) * 4u : kLaneOff;
+    const unsigned voff_m = colm_ok ? (unsigned)(pxm * p.in_cs + c4 * 4) * IB : kLaneOff;
 #pragma unroll
     for (int row = 0; row < C::IH; ++row) {
       const int iy = iy0 + row;
       if (iy >= 0 && iy < p.H) {
-        regs[row] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_m, (unsigned)((row * p.W) * p.in_cs + ch * 32) * 4u, 0));
+        if constexpr (IN16) {
+          typedef unsigned u32x2v __attribute__((__vector_size__(8)));
+          const u32x2v t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_m, (unsigned)((row * p.W) * p.in_cs + ch * 32) * IB, 0);
+          regs[row] = f32x4{__uint_as_float(t[0]), __uint_as_float(t[1]), 0.f, 0.f};       // 4 halves in the first two words
+        } else {
+          regs[row] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_m, (unsigned)((row * p.W) * p.in_cs + ch * 32) * IB, 0));
+        }
       } else {
         regs[row] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     if (HALO_W) {
       const bool halo_ok = tid < HALO_V4 && iy0 + hrow >= 0 && iy0 + hrow < p.H && ix0 + hcol >= 0 && ix0 + hcol < p.W;
-      const unsigned voff_h = halo_ok ? (unsigned)((hrow * p.W + hcol) * p.in_cs + c4 * 4) * 4u : kLaneOff;
-      regs[C::IH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_h, (unsigned)(ch * 32) * 4u, 0));
+      const unsigned voff_h = halo_ok ? (unsigned)((hrow * p.W + hcol) * p.in_cs + c4 * 4) * IB : kLaneOff;
+      if constexpr (IN16) {
+        typedef unsigned u32x2v __attribute__((__vector_size__(8)));
+        const u32x2v t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_h, (unsigned)(ch * 32) * IB, 0);
+        regs[C::IH] = f32x4{__uint_as_float(t[0]), __uint_as_float(t[1]), 0.f, 0.f};
+      } else {
+        regs[C::IH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_h, (unsigned)(ch * 32) * IB, 0));
+      }
     }
   };
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   auto put = [&](char* dst_f32, char* dst_h16, const f32x4& v) {      // 4 channels of one pixel: fp32, or hi | lo fp16 planes
     if constexpr (H == 0) {
       *reinterpret_cast<f32x4*>(dst_f32) = v;
+    } else if constexpr (IN16) {
+      *reinterpret_cast<f32x2*>(dst_h16) = f32x2{v[0], v[1]};      // already fp16: straight into the hi plane
     } else {
       f16x2 h0, l0, h1, l1;
       split2(f32x2{v[0], v[1]}, h0, l0);
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         xh[0][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt]);
-        xl[0][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + 16);
+        if constexpr (!IN16) xl[0][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + 16);
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -288,14 +307,14 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             xh[nx][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + ((tn / KW) * IW + (tn % KW)) * LDP);
-            xl[nx][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + ((tn / KW) * IW + (tn % KW)) * LDP + 16);
+            if constexpr (!IN16) xl[nx][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + ((tn / KW) * IW + (tn % KW)) * LDP + 16);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[cu], xh[cu][mt], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xl[cu][mt], acc[mt], 0, 0, 0);
+          if constexpr (!IN16) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xl[cu][mt], acc[mt], 0, 0, 0);
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xh[cu][mt], acc[mt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -383,10 +402,10 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #endif
 }
 
-template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0>
+template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0, bool IN16 = false>
 inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream) {
   using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
-  auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW, H>;
+  auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW, H, IN16>;
   static PerDeviceOnce once;               // .value = workgroups the device holds at once (2 per CU: LDS-bound)
   const int dev = PerDeviceOnce::current();
   int resident = dev >= 0 && once.done[dev] ? once.value[dev] : 0;

@@ -194,12 +194,12 @@ __global__ void lrelu_copy_kernel(const float* __restrict__ x, int x_cs, float* 
 }
 
 // dense copy of a channel slice of an NHWC buffer (debug probes only)
-__global__ void slice_copy_kernel(const float* __restrict__ src, int cs, int coff, int c, float* __restrict__ dst, size_t npix) {
+__global__ void slice_copy_kernel(const float* __restrict__ src, int cs, int coff, int c, float* __restrict__ dst, size_t npix, int src_is_f16) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= npix * c) return;
   const size_t pix = gid / c;
   const int ch = (int)(gid % c);
-  dst[gid] = src[pix * cs + coff + ch];
+  dst[gid] = src_is_f16 ? (float)reinterpret_cast<const _Float16*>(src)[pix * cs + coff + ch] : src[pix * cs + coff + ch];
 }
 
 }  // namespace bsr

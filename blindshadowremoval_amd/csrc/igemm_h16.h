@@ -104,9 +104,14 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
   }
 }
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>
+// IO (NSPLIT = 1 only — the fp16 pack of BASELINE configs[3]): bit 0 = the INPUT tensor is fp16 in HBM (in_cs / in_coff count halves; a
+// staged piece is one 16-byte load that goes to LDS unconverted — the fp32 form rounds the same values to fp16 at this point, so
+// nothing is lost), bit 1 = the OUTPUT is written as fp16 (out_cs / out_coff count halves).  Both halve that tensor's HBM bytes.
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT, int IO = 0>
 __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   using C = H16Cfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT>;
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  static_assert(IO == 0 || NSPLIT == 1, "fp16 activation I/O belongs to the f16 mode");
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, LDPW = C::LDPW, BN = C::BN, NPH = C::NPH, G = C::G, LO = C::LO;
   constexpr bool SWZ = C::SWZ;
   constexpr bool PAIR = C::PAIR;
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   const int y0 = tile_y * TH, x0 = tile_x * TW;
   const int iy0 = TR ? y0 - 1 : y0 * S - p.pad_t;
   const int ix0 = TR ? x0 - 1 : x0 * S - p.pad_l;
-  const float* in_img = p.in + (size_t)img * p.H * p.W * p.in_cs + p.in_coff;
+  // IN16: p.in is an fp16 tensor; element offsets are the same, byte offsets half
+  const char* in_img_b = reinterpret_cast<const char*>(p.in) + ((size_t)img * p.H * p.W * p.in_cs + p.in_coff) * (IN16 ? 2 : 4);
 
   int a_base[MI], b_base[NI];
 #pragma unroll
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
     const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-    in_goff[i] = (unsigned)(((iyc * p.W + ixc) * p.in_cs + q * 8) * 4);
+    in_goff[i] = (unsigned)(((iyc * p.W + ixc) * p.in_cs + q * 8) * (IN16 ? 2 : 4));
     in_loff[i] = idx0 < C::IN_V8 ? pix * LDP + q * 4 : -1;            // words: 8 halves = 4 words per piece and plane
     in_okmask |= (ok ? 1u : 0u) << i;
   }
@@ -191,11 +197,11 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     w_off[i] = (unsigned)((idx0 < C::W_V4 ? idx0 : C::W_V4 - 1) * 16);
   }
   auto fetch_in = [&](int ch, f32x4 (&regs)[2 * C::IN_PER_THREAD]) {
-    const char* base = reinterpret_cast<const char*>(in_img + ch * CC);
+    const char* base = in_img_b + (size_t)ch * CC * (IN16 ? 2 : 4);
 #pragma unroll
     for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-      regs[2 * i] = *reinterpret_cast<const f32x4*>(base + in_goff[i]);
-      regs[2 * i + 1] = *reinterpret_cast<const f32x4*>(base + in_goff[i] + 16);
+      regs[2 * i] = *reinterpret_cast<const f32x4*>(base + in_goff[i]);              // IN16: these 16 bytes are the piece's 8 halves
+      if constexpr (!IN16) regs[2 * i + 1] = *reinterpret_cast<const f32x4*>(base + in_goff[i] + 16);
     }
   };
   auto store_in = [&](int off, const f32x4 (&regs)[2 * C::IN_PER_THREAD]) {
@@ -203,11 +209,15 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     for (int i = 0; i < C::IN_PER_THREAD; ++i) {
       if (in_loff[i] >= 0) {
         f32x4 a = regs[2 * i], b = regs[2 * i + 1];
-        if (!((in_okmask >> i) & 1u)) { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }      // TF SAME zero padding
-        f16x8 hi, lo;
-        split8(a, b, hi, lo);
-        *reinterpret_cast<f16x8*>(s_in + off + in_loff[i]) = hi;
-        if (NSPLIT == 2) *reinterpret_cast<f16x8*>(s_in + off + in_loff[i] + LO) = lo;
+        if (!((in_okmask >> i) & 1u)) { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }      // TF SAME zero padding (all-zero bits are 0.0 in fp16 too)
+        if constexpr (IN16) {
+          *reinterpret_cast<f32x4*>(s_in + off + in_loff[i]) = a;
+        } else {
+          f16x8 hi, lo;
+          split8(a, b, hi, lo);
+          *reinterpret_cast<f16x8*>(s_in + off + in_loff[i]) = hi;
+          if (NSPLIT == 2) *reinterpret_cast<f16x8*>(s_in + off + in_loff[i] + LO) = lo;
+        }
       }
     }
   };
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         // The image of step s+2 (DMA issued at the top of step s-1) must have landed before this barrier publishes it.  vmcnt
         // retires in issue order: younger than that DMA are this step's DMA (step s+3) and an input-tile fetch issued in this or
         // the previous step; they may stay in flight.
-        constexpr int NW = C::W_DMA_PER_WAVE, NIN = 2 * C::IN_PER_THREAD;
+        constexpr int NW = C::W_DMA_PER_WAVE, NIN = (IN16 ? 1 : 2) * C::IN_PER_THREAD;      // load instructions of one input-tile fetch
         const bool near_fetch = T > 1 && (t == kInFetchTap || t == kInFetchTap + 1);      // compile-time once t is unrolled
 #ifdef H16_DIAG_NO_VMWAIT
         __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));
@@ -445,8 +455,9 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   static_assert(TW == 32, "epilogue assumes one tile row per 32-pixel MFMA tile");
   constexpr int SX = TR ? 2 : 1;
   const size_t blk_pix = (size_t)img * p.Ho * p.Wo + (size_t)(SX * y0) * p.Wo + SX * x0;
-  const unsigned lane_out = ((unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r) * 4u;
-  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.out + blk_pix * p.out_cs + p.out_coff);
+  constexpr unsigned OB = OUT16 ? 2u : 4u;                       // bytes per output element
+  const unsigned lane_out = ((unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r) * OB;
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.out) + (blk_pix * p.out_cs + p.out_coff) * OB));
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
@@ -469,8 +480,11 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = SX * ((i & 3) + 8 * (i >> 2));
-          const unsigned soff = (tile_off + (unsigned)k * (unsigned)p.out_cs) * 4u;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, voff, soff, 0);
+          const unsigned soff = (tile_off + (unsigned)k * (unsigned)p.out_cs) * OB;
+          if constexpr (OUT16)
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[i]), orsrc, voff, soff, 0);
+          else
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, voff, soff, 0);
         }
       }
 #ifdef BSR_STAMPS
@@ -485,10 +499,10 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
 #endif
 }
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT, int IO = 0>
 inline hipError_t launch_igemm_h16(ConvArgs a, int batch, hipStream_t stream) {
   using C = H16Cfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT>;
-  auto kern = igemm_h16_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT>;
+  auto kern = igemm_h16_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, NSPLIT, IO>;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (C::SMEM_BYTES > 48 * 1024 && (dev < 0 || !once.done[dev])) {

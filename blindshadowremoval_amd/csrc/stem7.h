@@ -34,7 +34,8 @@ struct StemCfg {
   static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS) * 4;
 };
 
-template <int RW, int H = 0>
+// OUT16 (f16 mode): x1 is written as fp16 (its consumer, down1, rounds it to fp16 anyway): half the bytes of the largest early tensor.
+template <int RW, int H = 0, bool OUT16 = false>
 __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
   using C = StemCfg<RW, H>;
   constexpr int ROWF = C::ROWF;
@@ -130,8 +131,10 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
   __builtin_amdgcn_s_setprio(3);
   // raw-buffer stores (igemm_conv.h): SGPR offset per element, one constant lane offset
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned lane_out = ((unsigned)(4 * h) * 32u + (unsigned)r) * 4u;
-  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.out + (((size_t)img * p.H + y0 + wave_u * RW) * p.W + x0) * 32);
+  constexpr unsigned OB = OUT16 ? 2u : 4u;
+  const unsigned lane_out = ((unsigned)(4 * h) * 32u + (unsigned)r) * OB;
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(reinterpret_cast<const float*>(
+      reinterpret_cast<const char*>(p.out) + (((size_t)img * p.H + y0 + wave_u * RW) * p.W + x0) * 32 * OB));
 #pragma unroll
   for (int mi = 0; mi < RW; ++mi) {
     f32x16 v = acc[mi];
@@ -144,17 +147,20 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int k = (i & 3) + 8 * (i >> 2);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, lane_out, ((unsigned)(mi * p.W + k) * 32u) * 4u, 0);
+      if constexpr (OUT16)
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[i]), orsrc, lane_out, ((unsigned)(mi * p.W + k) * 32u) * OB, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, lane_out, ((unsigned)(mi * p.W + k) * 32u) * OB, 0);
     }
   }
 }
 
-template <int RW, int H = 0>
+template <int RW, int H = 0, bool OUT16 = false>
 inline hipError_t launch_stem7(StemArgs a, int batch, hipStream_t stream) {
   using C = StemCfg<RW, H>;
   a.tiles_x = a.W / C::TW;
   a.tiles_y = a.H / C::TH;
-  hipLaunchKernelGGL((stem7_kernel<RW, H>), dim3(a.tiles_x * a.tiles_y * batch), dim3(256), C::SMEM_BYTES, stream, a);
+  hipLaunchKernelGGL((stem7_kernel<RW, H, OUT16>), dim3(a.tiles_x * a.tiles_y * batch), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }
 

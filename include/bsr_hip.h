@@ -33,7 +33,9 @@ typedef struct bsr_handle bsr_handle;
 #define BSR_ERR_STATE 4    /* probe requested before any forward, unknown probe name, ... */
 
 #define BSR_DTYPE_F32 0
-#define BSR_DTYPE_F16 1     /* BASELINE configs[3]: fp16 operands (fp32 accumulate, fp32 HBM storage) on the 3x3-conv path via v_mfma_f32_32x32x16_f16; the rest stays fp32 */
+#define BSR_DTYPE_F16 1     /* BASELINE configs[3]: fp16 operands (fp32 accumulate) on the 3x3-conv path via v_mfma_f32_32x32x16_f16, with the tensors between
+                               those layers kept as fp16 in the library's workspace; trunk, 1x1 / attention kernels (split precision) and all
+                               inputs / outputs of the ABI stay fp32.  ~1.3e-3 absolute accuracy */
 #define BSR_DTYPE_F32X3 2   /* split-precision fp32: every operand of the 3x3-conv path is split into hi + lo fp16 halves at staging time and contracted
                                with three fp16 matrix instructions (hi.hi + hi.lo + lo.hi, fp32 accumulate): fp32-class accuracy (~2^-22 per product) at
                                16/3 of the fp32 matrix rate.  Activations / outputs stay fp32.  Requires |activations| < 65504. */
