@@ -44,23 +44,34 @@ for _i in range(6):
     LAYER_MMAC["res%d.c3q" % _i] = 4 * 33.69            # conv3 + theta | phi | g (composed offline into one K = 128 GEMM)
     LAYER_MMAC["res%d.attention" % _i] = 2 * 134.22
     LAYER_MMAC["res%d.w" % _i] = 33.69
-# Algorithmic activation floats per 256x256 image of each launch: every input element read once + every output element written once
-# (weights, 12 MB in all, stay in L2).  x 4 bytes x images / time = the algorithmic HBM rate of the launch.
+# Algorithmic activation ELEMENTS per 256x256 image of each launch, (read, written): every input element read once + every output
+# element written once (weights, 12 MB in all, stay in L2).  x bytes per element x images / time = the algorithmic HBM rate.
 def _io(hw_in, c_in, hw_out, c_out):
-    return hw_in * hw_in * c_in + hw_out * hw_out * c_out
+    return (hw_in * hw_in * c_in, hw_out * hw_out * c_out)
 
 
-LAYER_IO_FLOATS = {"conv1": _io(256, 3, 256, 32), "down1": _io(256, 32, 128, 64), "down2": _io(128, 64, 64, 64), "down3": _io(64, 64, 32, 96),
-                   "up1": _io(32, 257, 64, 96), "up2": _io(64, 160, 128, 64), "up3": _io(128, 128, 256, 64), "heads": _io(256, 64, 256, 16),
-                   "clr_up1": _io(32, 261, 64, 128), "clr_up2": _io(64, 128, 128, 96), "clr_up3": _io(128, 96, 256, 64),
-                   "clr_conv1": _io(256, 64 + 1 + 3, 256, 4)}
+LAYER_IO_ELEMS = {"conv1": _io(256, 3, 256, 32), "down1": _io(256, 32, 128, 64), "down2": _io(128, 64, 64, 64), "down3": _io(64, 64, 32, 96),
+                  "up1": _io(32, 257, 64, 96), "up2": _io(64, 160, 128, 64), "up3": _io(128, 128, 256, 64), "heads": _io(256, 64, 256, 16),
+                  "clr_up1": _io(32, 261, 64, 128), "clr_up2": _io(64, 128, 128, 96), "clr_up3": _io(128, 96, 256, 64),
+                  "clr_conv1": _io(256, 64 + 1 + 3, 256, 4)}
 for _i in range(6):
     _cin = (99, 257, 257, 261, 261, 261)[_i]
-    LAYER_IO_FLOATS["res%d.conv1" % _i] = _io(32, _cin, 32, 128)
-    LAYER_IO_FLOATS["res%d.conv2" % _i] = _io(32, 128, 32, 128)
-    LAYER_IO_FLOATS["res%d.c3q" % _i] = _io(32, 128 + _cin, 32, 288 + 384)          # + the block input (skip folded into y3x)
-    LAYER_IO_FLOATS["res%d.attention" % _i] = _io(32, 384, 32, 128)
-    LAYER_IO_FLOATS["res%d.w" % _i] = _io(32, 128 + 288, 32, 264)
+    LAYER_IO_ELEMS["res%d.conv1" % _i] = _io(32, _cin, 32, 128)
+    LAYER_IO_ELEMS["res%d.conv2" % _i] = _io(32, 128, 32, 128)
+    LAYER_IO_ELEMS["res%d.c3q" % _i] = _io(32, 128 + _cin, 32, 288 + 384)          # + the block input (skip folded into y3x)
+    LAYER_IO_ELEMS["res%d.attention" % _i] = _io(32, 384, 32, 128)
+    LAYER_IO_ELEMS["res%d.w" % _i] = _io(32, 128 + 288, 32, 264)
+# f16 mode: bytes per element of each launch's (input, output) tensor — the fp16 activation pack; everything else 4 / 4
+F16_IO_BYTES = {"conv1": (4, 2), "down1": (2, 2), "down2": (2, 2), "down3": (2, 4), "up1": (4, 2), "up2": (2, 2), "up3": (2, 2), "heads": (2, 4),
+                "clr_up1": (4, 2), "clr_up2": (2, 2), "clr_up3": (2, 2), "clr_conv1": (2, 4)}
+
+
+def layer_bytes(name, dtype):
+    bi, bo = F16_IO_BYTES.get(name, (4, 4)) if dtype == "f16" else (4, 4)
+    ei, eo = LAYER_IO_ELEMS[name]
+    return ei * bi + eo * bo
+
+
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 # the "3x3-conv path" of north_star / SURVEY §8d: 3x3, stride-2 3x3 and transposed 3x3 layers (clr_conv1's launch also carries the fused 1x1 tail)
@@ -293,7 +304,7 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
             label = (gname.replace("igemm_conv_kernel", "igemm_h16_kernel").replace("nonlocal_attention_kernel", "nonlocal_attention_x3_kernel")
                      .replace("gemm_nloop_kernel", "gemm_nloop_kernel<..,H=2>").replace("conv_n16_kernel<", "conv_n16_kernel<H=2,")
                      .replace("stem7_kernel", "stem7_kernel<4,H=2>"))
-        gbytes = 4e-9 * sum(LAYER_IO_FLOATS[n] for n in layers) * B
+        gbytes = 1e-9 * sum(layer_bytes(n, dtype) for n in layers) * B
         groups[label] = {"ms": round(ms, 4), "launches": len(layers), "tflops": round(gflop / ms, 2), "peak": round(gpeak, 1),
                          "frac": round(gflop / ms / gpeak, 4), "alg_GBps": round(gbytes / ms * 1e3, 1), "hbm_frac": round(gbytes / ms * 1e3 / PEAK_HBM_GBPS, 4),
                          "gflop": gflop}
@@ -305,13 +316,19 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
     peak33 = group_peak(["up3"], dtype)
     t_all = sum(layer_ms.values())
     glue_ms = sum(ms for n, ms in layer_ms.items() if n not in LAYER_MMAC)
-    rf = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
-          "hbm_view": {"alg_GBps": dom["alg_GBps"], "peak_GBps": PEAK_HBM_GBPS, "frac": dom["hbm_frac"],
-                       "note": "algorithmic activation bytes (input read once + output written once) / device time of the same launches"},
+    # the dominant kernel is priced against both roofs; `bound` names the nearer one (fp32 kernels: the fp32 matrix pipe; the 16-bit
+    # kernels of f32x3 / f16: HBM once the matrix work has shrunk by 16/3 or 16)
+    mfma_view = {"achieved_TFLOPs": dom["tflops"], "peak_TFLOPs": peak, "frac": dom["frac"]}
+    hbm_view = {"alg_GBps": dom["alg_GBps"], "peak_GBps": PEAK_HBM_GBPS, "frac": dom["hbm_frac"],
+                "note": "algorithmic activation bytes (input read once + output written once) / device time of the same launches"}
+    hbm_bound = dom["hbm_frac"] > dom["frac"]
+    rf = {"bound": "hbm" if hbm_bound else "mfma", "achieved": dom["alg_GBps"] if hbm_bound else dom["tflops"],
+          "peak": PEAK_HBM_GBPS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+          "frac": dom["hbm_frac"] if hbm_bound else dom["frac"], "traffic": None, "mfma_view": mfma_view, "hbm_view": hbm_view,
           "kernel": dom_name + " — the largest kernel instantiation, %.0f %% of the forward's device time" % (100 * dom["ms"] / t_all),
           "launches_per_forward": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
           "algorithmic_gflop_per_launch": round(dom["gflop"] / dom["launches"], 2),
-          "path_3x3": {"achieved": round(path, 2), "peak": round(peak33, 1), "frac": round(path / peak33, 4), "launches": len(LAYERS_3X3), "ms": round(t33, 4),
+          "path_3x3": {"achieved": round(path, 2), "peak": round(peak33, 1), "frac": round(path / peak33, 4), "unit": "TFLOP/s", "launches": len(LAYERS_3X3), "ms": round(t33, 4),
                        "algorithmic_gflop": round(GFLOP_3X3_PER_IMAGE * B, 2)},
           "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all, 2), "all_kernels_ms": round(t_all, 4),
           "kernel_groups": {k: {kk: vv for kk, vv in v.items() if kk != "gflop"} for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},

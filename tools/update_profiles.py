@@ -37,12 +37,13 @@ rf = b["roofline"]
 cb = b.get("cpu_baseline") or {}
 head = ("* `%s_bench_n1%s.json` — `python bench.py%s` (N = 1, %d steps, %d warm-up): **%.0f images/s**, %.3f ms per %d-image forward "
         "(repeats: min %.3f / median %.3f ms); dominant kernel `%s`: **%.1f TFLOP/s = %.1f %% of its %.0f TFLOP/s matrix peak** "
-        "(avg launch %.4f ms — compare the rocprofv3 average below; algorithmic HBM rate %.0f GB/s), whole 3x3-conv path %.1f TFLOP/s (%.1f %%), "
+        "(avg launch %.4f ms — compare the rocprofv3 average below; algorithmic HBM rate %.0f GB/s = %.1f %% of 8 TB/s; nearer roof: %s), whole 3x3-conv path %.1f TFLOP/s (%.1f %%), "
         "all kernels %.1f TFLOP/s; CPU oracle %s images/s on %s host threads.\n"
         "* `%s_kernel_stats%s.csv` — `rocprofv3 --kernel-trace --stats -- python3 bench.py%s --no-cpu-baseline --no-secondary --repeats 1` (%d forwards). Per forward:\n\n"
         % (tag, sfx, "" if dtype == "f32" else " --dtype " + dtype, b["steps"], b["warmup"], b["value"], b["ms_per_step"], b["config"]["images_per_gpu_per_step"],
-           b["repeats"]["ms_per_step_min"], b["repeats"]["ms_per_step_median"], rf["kernel"].split(" — ")[0], rf["achieved"], 100 * rf["frac"], rf["peak"],
-           rf["avg_launch_ms"], rf["hbm_view"]["alg_GBps"], rf["path_3x3"]["achieved"], 100 * rf["path_3x3"]["frac"], rf["all_kernels_tflops"],
+           b["repeats"]["ms_per_step_min"], b["repeats"]["ms_per_step_median"], rf["kernel"].split(" — ")[0], rf["mfma_view"]["achieved_TFLOPs"],
+           100 * rf["mfma_view"]["frac"], rf["mfma_view"]["peak_TFLOPs"],
+           rf["avg_launch_ms"], rf["hbm_view"]["alg_GBps"], 100 * rf["hbm_view"]["frac"], rf["bound"], rf["path_3x3"]["achieved"], 100 * rf["path_3x3"]["frac"], rf["all_kernels_tflops"],
            cb.get("value"), cb.get("cores"), tag, sfx, "" if dtype == "f32" else " --dtype " + dtype, nfwd))
 block = "<!-- BEGIN %s%s TABLE -->\n%s%s\n<!-- END %s%s TABLE -->" % (tag, sfx, head, "\n".join(rows), tag, sfx)
 readme = os.path.join(ROOT, "profiles", "README.md")
