@@ -336,10 +336,16 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
     return rf, dom_name
 
 
+# kernel-group label (KERNEL_GROUPS / the 16-bit relabelling) -> substring of the rocprofv3 kernel names of that group
+GROUP_KERNEL_KEY = (("up2, up3, clr_up3", "<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32"), ("gemm_nloop", "gemm_nloop_kernel"), ("attention", "attention"),
+                    ("(res*.conv2)", "<3, 3, 1, false"), ("(down1-3)", "<3, 3, 2, false"), ("clr_conv1", "conv_n16_kernel<3, 3"),
+                    ("heads", "conv_n16_kernel<7, 1"), ("stem7", "stem7_kernel"), ("(res*.conv1)", "<1, 1, 1, false"))
+
+
 def attach_traffic(rf, dom_name, B, dtype):
-    """HBM bytes per launch of the transposed-conv kernel from the committed PMC passes (tools/pmc_traffic.py; separate rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE runs as MI355X_MICROARCH.md prescribes).  Reported only while the kernel sources still hash to
-    what the passes were taken on and the roofline kernel is that one; otherwise null with the reason."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py; separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs as MI355X_MICROARCH.md prescribes).  Reported only while the kernel sources still hash to what
+    the passes were taken on; otherwise null with the reason."""
     from blindshadowremoval_amd.build import source_sha16
     sha = source_sha16()
     sfx = "" if dtype == "f32" else "_" + dtype
@@ -349,16 +355,20 @@ def attach_traffic(rf, dom_name, B, dtype):
             continue
         with open(tpath) as ft:
             t = json.load(ft)
-        if "up2, up3, clr_up3" not in dom_name:
-            rf["traffic_note"] = "the PMC passes cover the transposed-conv kernel (up2, up3, clr_up3); the dominant kernel of this run is another one"
-        elif B == t.get("batch") and t.get("kernel_src_sha16") == sha:
-            rf["traffic"] = t.get("dominant_kernel_hbm_bytes_per_launch")
-            rf["traffic_note"] = ("HBM bytes per launch of the same kernel (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/%s_pmc_traffic%s.csv, "
-                                  "taken on kernel sources %s = this build); algorithmic activation bytes per launch (input read once, output written once): %.3g"
-                                  % (tag, sfx, sha, t.get("dominant_kernel_algorithmic_bytes_per_launch", 0.0)))
-        else:
+        key = [k for g, k in GROUP_KERNEL_KEY if g in dom_name]
+        rows = [v for k, v in (t.get("per_kernel") or {}).items() if key and key[0] in k]
+        if B != t.get("batch") or t.get("kernel_src_sha16") != sha:
             rf["traffic_note"] = ("profiles/%s_pmc_traffic%s.json was measured on kernel sources %s / batch %s, this build is %s / batch %d: not reported"
                                   % (tag, sfx, t.get("kernel_src_sha16"), t.get("batch"), sha, B))
+        elif not rows:
+            rf["traffic_note"] = "profiles/%s_pmc_traffic%s.json has no rows for the dominant kernel of this run" % (tag, sfx)
+        else:
+            n = sum(v["launches_per_forward"] for v in rows)
+            rf["traffic"] = sum(v["hbm_bytes_per_forward"] for v in rows) / max(n, 1)
+            rf["traffic_note"] = ("HBM bytes per launch of the same kernel (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/%s_pmc_traffic%s.csv: %d "
+                                  "launches per forward, taken on kernel sources %s = this build; the memory-side counters include Infinity-Cache hits); "
+                                  "algorithmic bytes per launch (input read once, output written once): %.4g"
+                                  % (tag, sfx, n, sha, rf["hbm_view"]["alg_GBps"] * 1e9 * rf["avg_launch_ms"] * 1e-3))
         return
 
 

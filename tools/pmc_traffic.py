@@ -64,8 +64,10 @@ out.to_csv(os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.csv" % (tag, sfx)))
 is33 = out.index.str.contains("<3, 3")          # the 3x3 / stride-2 3x3 / transposed 3x3 launches (roofline kernel class)
 dom = out[out.index.str.contains("<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32")]           # igemm_{conv,h16}_kernel<3,3,1,TR,...,NI=2,CC=32>: up2, up3, clr_up3
 alg = sum(LAYER_IO_MB.values()) * 32 * 1e6 / len(LAYER_IO_MB)
+per_kernel = {k: {"launches_per_forward": int(r["launches_per_forward"]), "hbm_bytes_per_forward": float(r["hbm_MB_per_forward"] * 1e6)}
+              for k, r in out.iterrows()}
 summary = {
-    "batch": 32, "dtype": dtype, "kernel_src_sha16": source_sha16(),
+    "batch": 32, "dtype": dtype, "kernel_src_sha16": source_sha16(), "per_kernel": per_kernel,
     "dominant_kernel_rows": list(dom.index),
     "dominant_kernel_hbm_bytes_per_launch": float(dom["hbm_MB_per_forward"].sum() * 1e6 / max(dom["launches_per_forward"].sum(), 1)),
     "dominant_kernel_algorithmic_bytes_per_launch": alg,
