@@ -88,6 +88,7 @@ constexpr Variant kGSC{false, 99, 120, 96, 257, 264, 261, 264, 258};
 // 16-bit matrix-core modes (BSR_DTYPE_F16 / BSR_DTYPE_F32X3): K chunks are 32 channels, so the 257 / 261-wide tensors get stride 288
 constexpr Variant kGSC16{false, 99, 128, 96, 257, 288, 261, 288, 258};
 constexpr Variant kTSM{true, 291, 312, 288, 291, 312, 877, 888, 874};
+constexpr Variant kTSM16{true, 291, 320, 288, 291, 320, 877, 896, 874};          // TSM widths at the 16-bit kernels' 32-channel granularity
 constexpr int CS_CF = 64;    // f = clr_up3 output; the gs channel of cat[gs, f] (model.py:267) is read from the gs output
 
 struct Plan {  // float offsets into the workspace for a (B,H,W) problem
@@ -407,8 +408,10 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   {   // GSC or TSM weights?  (res0.conv1 has K = 120 -> 5 chunks of 24, or K = 312 -> 13)
     auto it = h->layers.find("res0.conv1");
     if (it == h->layers.end()) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob has no 'res0.conv1'"); }
-    h->var = it->second.nchunk == 13 ? kTSM : (dtype == BSR_DTYPE_F32 ? kGSC : kGSC16);
-    if (h->var.tsm && dtype != BSR_DTYPE_F32) { bsr_destroy(h); return fail(BSR_ERR_ARG, "bsr_create: the TSM variant is implemented for BSR_DTYPE_F32 only"); }
+    // res0.conv1: GSC K = 120 (5 x 24) | 128 (4 x 32, 16-bit modes); TSM K = 312 (13 x 24) | 320 (10 x 32)
+    const int nch = it->second.nchunk;
+    if (dtype == BSR_DTYPE_F32) h->var = nch == 13 ? kTSM : kGSC;
+    else h->var = nch == 10 ? kTSM16 : kGSC16;
   }
   *out = h;
   return BSR_OK;

@@ -35,13 +35,15 @@ X3_LAYERS = tuple("res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q"
 
 def geometry(variant: str = "gsc", dtype: str = "f32") -> Dict[str, Tuple[int, int, int]]:
     """name -> (CC, k_pad, n_pad): must match the launch table in csrc/bsr_api.hip.  The TSM variant
-    (/root/reference/model_with_TSM.py) only widens the K of the layers fed by the ShareLayer concats: 291 -> 312, 877 -> 888.
+    (/root/reference/model_with_TSM.py) only widens the K of the layers fed by the ShareLayer concats: 291 -> 312, 877 -> 888
+    (320 / 896 in the 16-bit modes).
     The 16-bit modes use 32-channel K chunks, so the 257 / 261-wide trunk tensors get stride 288 instead of 264 (kGSC16)."""
     tsm = variant == "tsm"
     h16 = dtype != "f32"
-    if tsm and h16:
-        raise ValueError("the TSM variant is packed for dtype 'f32' only")
-    k_a, k_r, k_h = (312, 312, 888) if tsm else ((128, 288, 288) if h16 else (120, 264, 264))
+    if tsm:
+        k_a, k_r, k_h = (320, 320, 896) if h16 else (312, 312, 888)
+    else:
+        k_a, k_r, k_h = (128, 288, 288) if h16 else (120, 264, 264)
     cu = 32 if h16 else 24
     g: Dict[str, Tuple[int, int, int]] = {
         "conv1": (32, 32, 32) if h16 else (24, 24, 32), "down1": (16, 32, 64), "down2": (16, 64, 64), "down3": (16, 64, 96),

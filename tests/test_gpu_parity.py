@@ -175,14 +175,14 @@ def test_wider_input_512(gen_w):
     run_and_compare(gen, w, inp, uv)
 
 
-@pytest.mark.parametrize("frame,share", [(2, True), (4, True), (2, False)])
-def test_tsm_variant_matches_oracle(frame, share):
+@pytest.mark.parametrize("frame,share,dtype", [(2, True, "f32"), (4, True, "f32"), (2, False, "f32"), (2, True, "f32x3"), (4, True, "f32x3")])
+def test_tsm_variant_matches_oracle(frame, share, dtype):
     """BASELINE config 5 path: TSM generator = GSC net + ShareLayer (offset warp -> group max|mean -> inverse warp),
     /root/reference/model_with_TSM.py:199-325, against the TSM oracle whose warp is pinned to the reference's scipy form."""
     from blindshadowremoval_amd import GeneratorTSM
     from oracle.gsc_oracle import GeneratorTSMOracle
     w = init_weights(1, variant="tsm")
-    gen = GeneratorTSM().load_weights(w)
+    gen = GeneratorTSM(dtype=dtype).load_weights(w)
     torch.manual_seed(13 + frame)
     B = 4
     inp, uv = torch.rand(B, 256, 256, 3), torch.rand(B, 256, 256, 3)
@@ -269,14 +269,15 @@ def test_config3_rank_shape_f16_batch32():
     gen.close()
 
 
-def test_config4_rank_shape_tsm_512_batch8():
+@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
+def test_config4_rank_shape_tsm_512_batch8(dtype):
     """BASELINE configs[4] = 64 frames of 512x512 over 8 GPUs through the TSM generator: the PER-RANK shape (B = 8, 512x512,
-    frame = 2) on one GPU against the TSM oracle (4096-token attention, 64x64 ShareLayer warp)."""
+    frame = 2) on one GPU against the TSM oracle (4096-token attention, 64x64 ShareLayer warp) — fp32 and split-precision paths."""
     from blindshadowremoval_amd import GeneratorTSM
     from oracle.gsc_oracle import GeneratorTSMOracle
     from parity_util import FLIP_TOL, TOL
     w = init_weights(1, variant="tsm")
-    gen = GeneratorTSM().load_weights(w)
+    gen = GeneratorTSM(dtype=dtype).load_weights(w)
     g = torch.Generator().manual_seed(33)
     B, S = 8, 512
     inp, uv = torch.rand(B, S, S, 3, generator=g), torch.rand(B, S, S, 3, generator=g)
