@@ -321,10 +321,10 @@ class FSRNetTSM(object):
     SPLIT_SFW = (3, 3, 1, 3, 6, 1)        # img, cmap, mask, uv, reg, face   (train_with_TSM.py:675)
     SPLIT_VIDEO = (3, 3, 6, 1)            # img, uv, reg, face               (train_with_TSM.py:727)
 
-    def __init__(self, config: Config, weights: Optional[Dict[str, np.ndarray]] = None):
+    def __init__(self, config: Config, weights: Optional[Dict[str, np.ndarray]] = None, dtype: str = "f32"):
         from .model import GeneratorTSM
         self.config = config
-        self.gen = GeneratorTSM(device=config.GPU_INDEX if torch.cuda.is_available() else None)
+        self.gen = GeneratorTSM(device=config.GPU_INDEX if torch.cuda.is_available() else None, dtype=dtype)
         if weights is not None:
             self.gen.load_weights(weights)
         self.log = Logging(config, png_threads=4)
