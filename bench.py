@@ -428,8 +428,8 @@ def run_rank(args):
         dev = torch.device("cpu")
     real_stdout = None
     if distributed:
-        # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the ONE JSON line by pointing
-        # fd 1 at stderr for the lifetime of the rank and writing the line to the saved descriptor at the end
+        # RCCL prints a version banner on stdout (through C stdio, flushed at exit): keep stdout for the ONE JSON line by pointing
+        # fd 1 at stderr for the rest of the process and writing the line to the saved descriptor
         sys.stdout.flush()
         real_stdout = os.dup(1)
         os.dup2(2, 1)
@@ -588,8 +588,8 @@ def run_rank(args):
         dist.barrier()
         dist.destroy_process_group()
     if real_stdout is not None:
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
+        # fd 1 is NOT pointed back at the real stdout: RCCL's banner sits in the C stdio buffer until the process exits and would be
+        # flushed into it after the JSON line
         os.close(real_stdout)
     return result
 
