@@ -45,13 +45,26 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source into blindshadowremoval_amd/libbsr_hip.so; returns its path."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", LIB_PATH + ".tmp"] + [os.path.join(PKG_DIR, s) for s in SOURCES]
-    res = subprocess.run(cmd, cwd=PKG_DIR, capture_output=True, text=True)
-    if verbose or res.returncode != 0:
-        print(" ".join(cmd))
-        print(res.stdout + res.stderr)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed building libbsr_hip.so:\n" + res.stderr[-4000:])
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    # several ranks of one node may get here together (bench.py --gpus N, torchrun): one of them compiles, the others wait on
+    # the lock and find the library fresh
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return LIB_PATH
+            tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+                   "-o", tmp] + [os.path.join(PKG_DIR, s) for s in SOURCES]
+            res = subprocess.run(cmd, cwd=PKG_DIR, capture_output=True, text=True)
+            if verbose or res.returncode != 0:
+                print(" ".join(cmd))
+                print(res.stdout + res.stderr)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed building libbsr_hip.so:\n" + res.stderr[-4000:])
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
