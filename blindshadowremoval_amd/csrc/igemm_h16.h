@@ -26,6 +26,15 @@
 #ifndef BSR_PAIR_S2_H16
 #define BSR_PAIR_S2_H16 0
 #endif
+#ifndef BSR_DMA_ASM
+#define BSR_DMA_ASM 1
+#endif
+#ifndef BSR_H16_AREUSE
+#define BSR_H16_AREUSE 1    // transposed convs: taps that read the same input offset run back to back and share their A fragments
+#endif
+#ifndef BSR_H16_RING
+#define BSR_H16_RING 4      // slots of the LDS-DMA weight ring: the image of step s + RING - 1 is requested at the top of step s
+#endif
 
 namespace bsr {
 
@@ -67,7 +76,7 @@ struct H16Cfg {
   static constexpr int W_CHUNKS = (W_WORDS * 4 + 1023) / 1024;   // 1 KiB = one wave-instruction of 64 lanes x 16 B
   static constexpr int W_DMA_PER_WAVE = (W_CHUNKS + 3) / 4;
   static constexpr int W_SLOT_WORDS = DMAW ? W_CHUNKS * 256 : W_WORDS;
-  static constexpr int W_SLOTS = DMAW ? 4 : 3;
+  static constexpr int W_SLOTS = DMAW ? BSR_H16_RING : 3;
   static constexpr int SMEM_BYTES = (INB * IN_WORDS + W_SLOTS * W_SLOT_WORDS) * 4;
   static constexpr int IN_V8 = IH * IW * (CC / 8);               // 8-channel (32-byte) pieces of one input-tile chunk
   static constexpr int IN_PER_THREAD = (IN_V8 + 255) / 256;
@@ -77,6 +86,7 @@ struct H16Cfg {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(BM == TH * TW, "M tile must equal the spatial tile");
   static_assert(CC % 16 == 0, "channel chunk must be a multiple of the 16-wide K group");
+  static_assert(!TR || ((T * (CC / 16)) % 2 == 0), "fragment slot parity");
   static_assert(!TR || (KH == 3 && KW == 3 && S == 1), "transposed path is ConvT(3, stride 2)");
   static_assert(INB == 1 || (T == 1 ? INB == 3 : INB == 2), "input buffers: 1, or 2 (taps > 1) / 3 (1x1)");
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
@@ -244,16 +254,43 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     const int c = min(wave + 4 * i, C::W_CHUNKS - 1);
     dma_src[i] = (unsigned)min(c * 1024 + lane * 16, C::W_WORDS * 4 - 16);
   }
-  auto dma_w = [&](int step, int off) {
+  auto dma_w = [&](int step, int off) {      // step = index of the packed (chunk, tap) weight image
+#ifdef H16_DIAG_DMA_SAME
+    step = 0;
+#endif
     const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDPW);
 #pragma unroll
     for (int i = 0; i < C::W_DMA_PER_WAVE; ++i) {
+#ifdef H16_DIAG_DMA_HALF
+      if (i & 1) continue;
+#endif
       const int c = min(wave + 4 * i, C::W_CHUNKS - 1);                              // wave-uniform
+#if BSR_DMA_ASM
+      // Written as asm on purpose: behind __builtin_amdgcn_global_load_lds hipcc 7.2 puts a full s_waitcnt lgkmcnt(0) in front of
+      // the first matrix instruction after every later ds_read (it no longer tracks which LDS reads are outstanding once an LDS-DMA
+      // is), which exposes the fragment reads of every step.  The waits this kernel needs for the DMAs are the explicit counted ones.
+      const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w + off + c * 256);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :: "v"(dma_src[i]), "s"(base), "s"(lds_addr) : "memory");
+#else
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_src[i]),
                                        (__attribute__((address_space(3))) void*)(s_w + off + c * 256), 16, 0, 0);
+#endif
     }
   };
 
+  // Transposed conv: the 9 taps read only 4 different input offsets ((1,1): taps 0 1 3 4, (1,0): 2 5, (0,1): 6 7, (0,0): 8).  Run in
+  // that order, a tap group keeps its A fragments in registers and LDS serves 4 instead of 9 A reads per chunk; the 16-bit kernels
+  // are bound by LDS read bandwidth (1 KiB of fragments per matrix instruction = the LDS peak at the full matrix rate).
+  constexpr bool AREUSE = TR && INB == 1 && C::DMAW && BSR_H16_AREUSE;
+  auto tap_at = [&](int q) -> int {          // execution position -> tap
+    if (!AREUSE) return q;
+    constexpr int ord[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8};
+    return ord[q % 9];
+  };
+  auto img_of = [&](int ch, int q) -> int {      // weight image of execution position q (may run into the next chunks)
+    return (ch + q / T) * T + tap_at(q % T);
+  };
 #ifdef BSR_STAMPS
   unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0;
   unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -263,14 +300,21 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   f32x4 w_regs[C::W_PER_THREAD];
   const int nsteps = p.nchunk * T;
 
-  int w_cur = 0, w_n1 = C::W_SLOT_WORDS, w_n2 = 2 * C::W_SLOT_WORDS, w_n3 = 3 * C::W_SLOT_WORDS;
+  constexpr int R = C::W_SLOTS;                      // DMA ring: slot i holds step s + i, the last one receives step s + R - 1
+  int w_cur = 0, w_n1 = C::W_SLOT_WORDS, w_n2 = 2 * C::W_SLOT_WORDS;
+  int w_far[R > 3 ? R - 3 : 1];                      // slots of steps s + 3 .. s + R - 1
+#pragma unroll
+  for (int i = 3; i < R; ++i) w_far[i - 3] = i * C::W_SLOT_WORDS;
   int in_cur = 0, in_n1 = (INB > 1) ? C::IN_WORDS : 0, in_n2 = (INB > 2) ? 2 * C::IN_WORDS : 0;
 
   // prologue: the first steps staged synchronously
   if constexpr (DMAW) {
-    dma_w(0, w_cur);
-    if (nsteps > 1) dma_w(1, w_n1);
-    if (nsteps > 2) dma_w(2, w_n2);
+    dma_w(img_of(0, 0), w_cur);
+    if (nsteps > 1) dma_w(img_of(0, 1), w_n1);
+    if (nsteps > 2) dma_w(img_of(0, 2), w_n2);
+#pragma unroll
+    for (int i = 3; i < R - 1; ++i)
+      if (nsteps > i) dma_w(img_of(0, i), w_far[i - 3]);
     fetch_in(0, in_regs);
     if constexpr (PAIR) { if (p.nchunk > 1) fetch_in(1, in_regs2); }
     store_in(0, in_regs);
@@ -317,6 +361,104 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     }
     return ((t / KW) * IW + (t % KW)) * LDP;
   };
+  if constexpr (AREUSE) {
+    f16x8 aH[G][MI], aL[G][MI];                       // A fragments of the current input offset, one set per K group
+    auto read_a = [&](int g, int a_off) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        aH[g][mi] = *reinterpret_cast<const f16x8*>(s_in + a_base[mi] + a_off + g * 8);
+        if (NSPLIT == 2) aL[g][mi] = *reinterpret_cast<const f16x8*>(s_in + a_base[mi] + a_off + g * 8 + LO);
+      }
+    };
+    auto read_b = [&](int slot, int w_off_, int g) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if constexpr (SWZ) {
+          bh[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + w_off_ + b_sw[ni][g]);
+          bl[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + w_off_ + b_sw[ni][2 + g]);
+        } else {
+          bh[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + w_off_ + g * 8);
+          if (NSPLIT == 2) bl[slot][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + w_off_ + g * 8 + LO);
+        }
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g) read_a(g, tap_offset(tap_at(0)));
+    read_b(0, w_cur, 0);
+    __builtin_amdgcn_s_setprio(0);
+#ifdef BSR_STAMPS
+    st1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int ch = 0; ch < p.nchunk; ++ch) {
+      const bool more = ch + 1 < p.nchunk;
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        const int t = tap_at(q);
+        const int s = ch * T + q;
+        constexpr int kInFetchTap = T - 4;
+        const bool hasD = s + R - 1 < nsteps;
+#ifndef H16_DIAG_NO_DMA
+        if (hasD) dma_w(img_of(ch, q + R - 1), w_far[R - 4]);
+#endif
+        if (q == kInFetchTap && more) fetch_in(ch + 1, in_regs);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ph = ((t / 3 == 1) ? 2 : 0) + ((t % 3 == 1) ? 1 : 0);
+        const bool a_last = q + 1 < T && tap_offset(tap_at(q + 1 < T ? q + 1 : q)) != tap_offset(t);      // the next tap reads another input offset
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int cur = (q * G + g) & 1, nxt = cur ^ 1;
+          if (g + 1 < G) {
+            read_b(nxt, w_cur, g + 1);
+          } else if (q + 1 < T) {
+            read_b(nxt, w_n1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              if (NSPLIT == 2) {
+                acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aL[g][mi], bh[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+                acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH[g][mi], bl[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+              }
+              acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH[g][mi], bh[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          if (a_last) {                 // in place, behind the last instructions that read the old fragments
+            read_a(g, tap_offset(tap_at(q + 1 < T ? q + 1 : q)));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // The image of step s+2 must have landed before this barrier publishes it (see the other path).  LDS reads still in
+        // flight here (the next step's first B fragments, a tap group's new A fragments) are of slots / tiles nobody overwrites
+        // before the next barrier, so lgkmcnt is left alone.
+        constexpr int NW = (R - 3) * C::W_DMA_PER_WAVE, NIN = (IN16 ? 1 : 2) * C::IN_PER_THREAD;
+        const bool near_fetch = q >= kInFetchTap && q <= kInFetchTap + R - 3;
+#ifndef H16_DIAG_NO_VMWAIT
+        if (!hasD) {
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+        } else if (near_fetch && more) {
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm(NW + NIN));
+        } else {
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm(NW));
+        }
+#endif
+        __builtin_amdgcn_s_barrier();
+        if (q == T - 1 && more) {
+          store_in(0, in_regs);
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));
+          __builtin_amdgcn_s_barrier();
+#pragma unroll
+          for (int g = 0; g < G; ++g) read_a(g, tap_offset(tap_at(0)));
+          read_b((T * G) & 1, w_n1, 0);
+        }
+        const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = w_far[0];
+#pragma unroll
+        for (int i = 0; i + 1 < R - 3; ++i) w_far[i] = w_far[i + 1];
+        w_far[R - 4] = tw;
+      }
+    }
+  } else {
   read_frags(0, in_cur + tap_offset(0), w_cur, 0);
   __builtin_amdgcn_s_setprio(0);
 #ifdef BSR_STAMPS
@@ -334,10 +476,14 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
       constexpr int kInStoreTap = (INB == 2) ? T - 2 : T - 1;
       const bool fetch_now = kRing1x1 ? has2 : (T > 1 && t == kInFetchTap && more);
       const bool stage_in = kRing1x1 ? has2 : (INB == 2 && t == kInStoreTap && more);
-      const bool has3 = s + 3 < nsteps;
+      const bool has3 = s + R - 1 < nsteps;              // a step is left to request
       if constexpr (DMAW) {
 #ifndef H16_DIAG_NO_DMA
-        if (has3) dma_w(s + 3, w_n3);
+#ifdef H16_DMA_UNCOND
+        dma_w(min(s + R - 1, nsteps - 1), w_far[R - 4]);
+#else
+        if (has3) dma_w(s + R - 1, w_far[R - 4]);
+#endif
 #endif
       } else {
         if (has2) fetch_w(s + 2, w_regs);
@@ -386,11 +532,11 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
       }
 
       if constexpr (DMAW) {
-        // The image of step s+2 (DMA issued at the top of step s-1) must have landed before this barrier publishes it.  vmcnt
-        // retires in issue order: younger than that DMA are this step's DMA (step s+3) and an input-tile fetch issued in this or
-        // the previous step; they may stay in flight.
-        constexpr int NW = C::W_DMA_PER_WAVE, NIN = (IN16 ? 1 : 2) * C::IN_PER_THREAD;      // load instructions of one input-tile fetch
-        const bool near_fetch = T > 1 && (t == kInFetchTap || t == kInFetchTap + 1);      // compile-time once t is unrolled
+        // The image of step s+2 (DMA issued at the top of step s+3-R) must have landed before this barrier publishes it.  vmcnt
+        // retires in issue order: younger than that DMA are the R-3 DMAs of steps s+3 .. s+R-1 and an input-tile fetch issued
+        // since; they may stay in flight.
+        constexpr int NW = (R - 3) * C::W_DMA_PER_WAVE, NIN = (IN16 ? 1 : 2) * C::IN_PER_THREAD;      // load instructions of one input-tile fetch
+        const bool near_fetch = T > 1 && t >= kInFetchTap && t <= kInFetchTap + R - 3;      // compile-time once t is unrolled
 #ifdef H16_DIAG_NO_VMWAIT
         __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));
 #else
@@ -423,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
           store_in(0, in_regs);
         }
         if constexpr (DMAW) {
-          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(C::W_DMA_PER_WAVE));      // the tile's ds_writes are done; this step's DMA may stay in flight
+          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));      // the tile's ds_writes are done (lgkmcnt); DMAs may stay in flight
           __builtin_amdgcn_s_barrier();
         } else {
           __syncthreads();
@@ -431,7 +577,10 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         read_frags(((T * G) & 1), tap_offset(0), w_n1, 0);
       }
       if constexpr (DMAW) {
-        const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = w_n3; w_n3 = tw;
+        const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = w_far[0];
+#pragma unroll
+        for (int i = 0; i + 1 < R - 3; ++i) w_far[i] = w_far[i + 1];
+        w_far[R - 4] = tw;
         if (T > 1 && INB == 2 && t == T - 1) { const int ti = in_cur; in_cur = in_n1; in_n1 = ti; }
       } else {
         const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = tw;
@@ -445,6 +594,8 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) { bh[0][ni] = bh[1][ni]; bl[0][ni] = bl[1][ni]; }
     }
+  }
+
   }
 
   __builtin_amdgcn_s_setprio(3);

@@ -9,9 +9,9 @@
 using namespace bsr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int KH, int KW, int S, bool TR, int NI, int CC, int INB, int NSPLIT, int TH = 4, int MI = 1>
+template <int KH, int KW, int S, bool TR, int NI, int CC, int INB, int NSPLIT, int TH = 4, int MI = 1, int WM = 4, int WN = 1>
 int run(const char* name, int B, int H, int W, int Cin, int Cout) {
-  using C = H16Cfg<KH, KW, S, TR, TH, 32, 4, 1, MI, NI, CC, INB, NSPLIT>;
+  using C = H16Cfg<KH, KW, S, TR, TH, 32, WM, WN, MI, NI, CC, INB, NSPLIT>;
   const int T = KH * KW, nchunk = Cin / CC, n_pad = ((Cout + C::BN - 1) / C::BN) * C::BN;
   const int Ho = TR ? 2 * H : H / S, Wo = TR ? 2 * W : W / S;
   size_t n_in = (size_t)B * H * W * Cin, n_out = (size_t)B * Ho * Wo * Cout, n_w = (size_t)nchunk * T * n_pad * C::LDP;
@@ -35,7 +35,7 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   float best = 1e9;
   for (int it = 0; it < 6; ++it) {
     CK(hipEventRecord(e0));
-    CK((launch_igemm_h16<KH, KW, S, TR, TH, 32, 4, 1, MI, NI, CC, INB, NSPLIT>(a, B, 0)));
+    CK((launch_igemm_h16<KH, KW, S, TR, TH, 32, WM, WN, MI, NI, CC, INB, NSPLIT>(a, B, 0)));
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it > 0) best = std::min(best, ms);
   }
@@ -55,11 +55,10 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
 
 int main() {
   if (run<3, 3, 1, true, 2, 32, 1, 2>("up3 x3", 32, 128, 128, 128, 64)) return 1;
-  if (run<3, 3, 1, true, 1, 32, 1, 2, 8, 2>("up3 x3 m256", 32, 128, 128, 128, 64)) return 1;
-  if (run<3, 3, 1, true, 1, 32, 1, 2, 8, 2>("clr_up3 m256", 32, 128, 128, 96, 64)) return 1;
-  if (run<3, 3, 1, true, 1, 32, 1, 2, 8, 2>("up2 m256", 32, 64, 64, 160, 64)) return 1;
-  if (run<3, 3, 1, true, 1, 32, 1, 1, 8, 2>("up3 f16 m256", 32, 128, 128, 128, 64)) return 1;
+  if (run<3, 3, 1, true, 1, 32, 1, 2, 4, 2, 2, 2>("up3 x3 w22", 32, 128, 128, 128, 64)) return 1;
   if (run<3, 3, 1, true, 2, 32, 1, 1>("up3 f16", 32, 128, 128, 128, 64)) return 1;
+  if (run<3, 3, 1, true, 1, 32, 1, 1, 4, 2, 2, 2>("up3 f16 w22", 32, 128, 128, 128, 64)) return 1;
+  if (run<3, 3, 1, true, 1, 32, 1, 2, 4, 2, 2, 2>("up2 x3 w22", 32, 64, 64, 160, 64)) return 1;
   if (run<3, 3, 1, true, 2, 32, 1, 2>("clr_up3 x3", 32, 128, 128, 96, 64)) return 1;
   if (run<3, 3, 1, true, 2, 32, 1, 2>("up2 x3", 32, 64, 64, 160, 64)) return 1;
   if (run<3, 3, 1, true, 1, 32, 1, 2>("clr_up2 x3", 32, 64, 64, 128, 96)) return 1;
