@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   f32x4 w_regs[C::W_PER_THREAD], w_regs1[C::W_PER_THREAD];
   fetch_w(0, w_regs);
   if (nsteps > 1) fetch_w(1, w_regs1);
+  // bias slice -> LDS (keeps bias loads out of the MFMA loop's vmcnt queue).  Issued BEFORE the A fragments: loads return in
+  // order, and behind them this copy would hold the first barrier until the whole activation tile has arrived.
+  for (int i = tid; i < (t1 - t0) * 32; i += 256) s_bias[i] = p.bias[t0 * 32 + i];
   f32x4 afr[H ? 1 : NCH * G];
   f16x8 ahi[H ? NCH * G : 1], alo[H == 2 ? NCH * G : 1];
   if constexpr (H == 0) {
@@ -108,7 +111,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
       if (H == 2) alo[g] = lo;
     }
   }
-  for (int i = tid; i < (t1 - t0) * 32; i += 256) s_bias[i] = p.bias[t0 * 32 + i];   // keeps bias loads out of the MFMA loop's vmcnt queue
   store_w(0, w_regs);
   if (nsteps > 1) store_w(C::W_FLOATS, w_regs1);
   __syncthreads();
