@@ -546,15 +546,19 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
           if constexpr (PAIR) n_in = (ch & 1) ? (ch + 2 < p.nchunk ? 2 : 1) : 0;
           else n_in = 1;
         }
+        // INB == 1: the LDS reads still in flight here (the next step's first fragments) are of a tile / ring slot nobody
+        // overwrites before the next barrier, and no ds_write is pending, so lgkmcnt is left alone
+#define BSR_WAIT_STEP(n) do { if constexpr (INB == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(n)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(n)); } while (0)
         if (!has3) {
-          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
+          BSR_WAIT_STEP(0);
         } else if (n_in == 2) {
-          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW + 2 * NIN));
+          BSR_WAIT_STEP(NW + 2 * NIN);
         } else if (n_in == 1) {
-          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW + NIN));
+          BSR_WAIT_STEP(NW + NIN);
         } else {
-          __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(NW));
+          BSR_WAIT_STEP(NW);
         }
+#undef BSR_WAIT_STEP
 #endif
 #ifndef H16_DIAG_NO_STEP_BARRIER
         __builtin_amdgcn_s_barrier();
