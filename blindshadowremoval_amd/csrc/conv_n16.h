@@ -46,7 +46,8 @@ struct ConvN16Cfg {
   static constexpr int IN_FLOATS = IH * IW * LDP;
   static constexpr int W_FLOATS = T * 16 * LDP;
   static constexpr int GS_FLOATS = GS ? (TH + 2) * (TW + 2) + 2 : 0;
-  static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS + GS_FLOATS) * 4;
+  static constexpr int TAIL_FLOATS = TAIL ? 352 + TH * TW * 3 : 0;   // for the variant that keeps them in LDS: the fused tail's weights (337 floats) + the tile's input pixels
+  static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS + GS_FLOATS + TAIL_FLOATS) * 4;
   static constexpr int IN_V4 = IH * IW * (CC / 4);
   static constexpr int IN_PER_THREAD = IH + 1;                   // one float4 per tile row + one halo-column load
   static constexpr int W_V4 = W_FLOATS / 4;
@@ -69,6 +70,10 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   float* s_in = smem;
   float* s_w = smem + C::IN_FLOATS;
   float* s_gs = s_w + C::W_FLOATS;
+  float* s_tail = s_gs + C::GS_FLOATS;
+  // The split-precision variant needs ~290 VGPRs with the fused tail's 15 per-lane weights held across the tile loop and spilled them
+  // (reloaded per tile from scratch: +45 % HBM traffic); it reads them from a 1.4-KB LDS copy at each epilogue instead.
+  constexpr bool TAIL_LDS = TAIL && H == 2 && !IN16;
 
 #ifdef BSR_STAMPS
   unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st_epi = 0, rt0 = __builtin_amdgcn_s_memrealtime();
@@ -210,7 +215,9 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   float tw2[4], tw3[4];
   f32x4 tb2 = {0.f, 0.f, 0.f, 0.f};
   float tb3[3] = {0.f, 0.f, 0.f};
-  if (TAIL) {
+  if constexpr (TAIL_LDS) {
+    for (int i = tid; i < 337; i += 256) s_tail[i] = p.tail_w[i];
+  } else if (TAIL) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       tw2[e] = p.tail_w[(4 * q + e) * 16 + r];
@@ -241,7 +248,14 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     const bool has_next = tile + (int)gridDim.x < ntiles;
     const Tile nxt = decode(has_next ? tile + (int)gridDim.x : tile);
     float tin[MT][3];
-    if (TAIL) {   // the input pixels for the final grayscale difference (lanes q == 0 use them), latency hidden by the MFMA loop
+    float tin_st[3] = {0.f, 0.f, 0.f};
+    if constexpr (TAIL_LDS) {   // the same pixels through LDS (3 registers instead of 12 across the MFMA loops): row-contiguous loads now, ds_write at the chunk-0 barrier
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int f = tid + e * 256, row = f / (TW * 3), col = f % (TW * 3);
+        tin_st[e] = p.inputs[(((size_t)cur.img * p.H + cur.y0 + row) * p.W + cur.x0) * 3 + col];
+      }
+    } else if (TAIL) {   // the input pixels for the final grayscale difference (lanes q == 0 use them), latency hidden by the MFMA loop
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const size_t pix = ((size_t)cur.img * p.H + cur.y0 + wave * RW + mt / 2) * p.W + cur.x0 + (mt % 2) * 16 + r;
@@ -289,33 +303,36 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
       }
       } else {
       // one K = 32 step per tap: A = weight row r, k = 8q..8q+7 (16 bytes of the hi plane, lo plane 64 bytes further), B = pixel r
-      f16x8 wh[2], wl[2], xh[2][MT], xl[2][MT];
+      // hi planes are read one tap ahead (two register sets); the lo planes of the split-precision form are read at the start of
+      // their own tap into ONE set and consumed by the last instructions of the tap (register budget: see TAIL_LDS above)
+      f16x8 wh[2], wl, xh[2][MT], xl[MT];
       wh[0] = *reinterpret_cast<const f16x8*>(s_w + w_base);
-      wl[0] = *reinterpret_cast<const f16x8*>(s_w + w_base + 16);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        xh[0][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt]);
-        if constexpr (!IN16) xl[0][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + 16);
-      }
+      for (int mt = 0; mt < MT; ++mt) xh[0][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt]);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const int cu = t & 1, nx = cu ^ 1;
+        const int toff = ((t / KW) * IW + (t % KW)) * LDP;
+        wl = *reinterpret_cast<const f16x8*>(s_w + w_base + t * 16 * LDP + 16);
+        if constexpr (!IN16) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) xl[mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + toff + 16);
+        }
         if (t + 1 < T) {
           const int tn = t + 1;
           wh[nx] = *reinterpret_cast<const f16x8*>(s_w + w_base + tn * 16 * LDP);
-          wl[nx] = *reinterpret_cast<const f16x8*>(s_w + w_base + tn * 16 * LDP + 16);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
+          for (int mt = 0; mt < MT; ++mt)
             xh[nx][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + ((tn / KW) * IW + (tn % KW)) * LDP);
-            if constexpr (!IN16) xl[nx][mt] = *reinterpret_cast<const f16x8*>(s_in + x_base[mt] + ((tn / KW) * IW + (tn % KW)) * LDP + 16);
-          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[cu], xh[cu][mt], acc[mt], 0, 0, 0);
-          if constexpr (!IN16) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xl[cu][mt], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xh[cu][mt], acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xh[cu][mt], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[cu][mt], acc[mt], 0, 0, 0);
+        if constexpr (!IN16) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cu], xl[mt], acc[mt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -337,6 +354,12 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
         store_in(in_regs);
         store_w(w_regs);
         if (ch == 1 && GS) store_gs(gs_regs);
+        if constexpr (TAIL_LDS) {
+          if (ch == 0) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) s_tail[352 + tid + e * 256] = tin_st[e];
+          }
+        }
         __syncthreads();
       }
     }
@@ -345,6 +368,20 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     const unsigned long long se0 = __builtin_amdgcn_s_memtime();
 #endif
     // epilogue: lane (pixel r of tile mt, q) holds channels 4q .. 4q+3
+    if constexpr (TAIL_LDS) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tw2[e] = s_tail[(4 * q + e) * 16 + r];
+        tw3[e] = s_tail[272 + (4 * q + e) * 3 + (r < 3 ? r : 0)];
+      }
+      tb2 = *reinterpret_cast<const f32x4*>(s_tail + 256 + 4 * q);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tb3[c] = s_tail[320 + c];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tin[mt][c] = s_tail[352 + ((wave * RW + mt / 2) * TW + (mt % 2) * 16 + r) * 3 + c];
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const size_t row_pix = ((size_t)cur.img * p.H + cur.y0 + wave * RW + mt / 2) * p.W + cur.x0;
