@@ -35,6 +35,9 @@
 #ifndef BSR_H16_RING
 #define BSR_H16_RING 4      // slots of the LDS-DMA weight ring: the image of step s + RING - 1 is requested at the top of step s
 #endif
+#ifndef BSR_H16_RING_F16
+#define BSR_H16_RING_F16 8  // the same for NSPLIT = 1 (f16 mode): its steps are a third as long, so the same latency spans more of them
+#endif
 
 namespace bsr {
 
@@ -76,7 +79,7 @@ struct H16Cfg {
   static constexpr int W_CHUNKS = (W_WORDS * 4 + 1023) / 1024;   // 1 KiB = one wave-instruction of 64 lanes x 16 B
   static constexpr int W_DMA_PER_WAVE = (W_CHUNKS + 3) / 4;
   static constexpr int W_SLOT_WORDS = DMAW ? W_CHUNKS * 256 : W_WORDS;
-  static constexpr int W_SLOTS = DMAW ? BSR_H16_RING : 3;
+  static constexpr int W_SLOTS = DMAW ? (NSPLIT == 1 ? BSR_H16_RING_F16 : BSR_H16_RING) : 3;
   static constexpr int SMEM_BYTES = (INB * IN_WORDS + W_SLOTS * W_SLOT_WORDS) * 4;
   static constexpr int IN_V8 = IH * IW * (CC / 8);               // 8-channel (32-byte) pieces of one input-tile chunk
   static constexpr int IN_PER_THREAD = (IN_V8 + 255) / 256;
@@ -245,9 +248,13 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     }
   };
 
-  // LDS-DMA of one step's weight image into ring slot `off`: wave w copies 1-KiB pieces w, w+4, ... (a piece index past the
-  // image re-copies the last piece; a last piece shorter than 1 KiB spills into the slot's padding with clamped sources)
+  // LDS-DMA of one step's weight image into ring slot `off`: wave w copies 1-KiB pieces w, w+4, ... (a last piece shorter than
+  // 1 KiB spills into the slot's padding with clamped sources).  When the piece count is not a multiple of 4 the waves past the
+  // remainder issue one instruction fewer per step (`dma_full` false) — each piece costs the CU's LDS-DMA path ~70 cycles, so none
+  // is copied twice — and their counted waits allow correspondingly fewer instructions in flight.
   constexpr bool DMAW = C::DMAW;
+  constexpr int WREM = C::W_CHUNKS % 4;
+  const bool dma_full = WREM == 0 || wave < WREM;
   unsigned dma_src[C::W_DMA_PER_WAVE];
 #pragma unroll
   for (int i = 0; i < C::W_DMA_PER_WAVE; ++i) {
@@ -264,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
 #ifdef H16_DIAG_DMA_HALF
       if (i & 1) continue;
 #endif
-      const int c = min(wave + 4 * i, C::W_CHUNKS - 1);                              // wave-uniform
+      if (i == C::W_DMA_PER_WAVE - 1 && !dma_full) continue;                         // wave-uniform
+      const int c = min(wave + 4 * i, C::W_CHUNKS - 1);
 #if BSR_DMA_ASM
       // Written as asm on purpose: behind __builtin_amdgcn_global_load_lds hipcc 7.2 puts a full s_waitcnt lgkmcnt(0) in front of
       // the first matrix instruction after every later ds_read (it no longer tracks which LDS reads are outstanding once an LDS-DMA
@@ -435,12 +443,13 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         constexpr int NW = (R - 3) * C::W_DMA_PER_WAVE, NIN = (IN16 ? 1 : 2) * C::IN_PER_THREAD;
         const bool near_fetch = q >= kInFetchTap && q <= kInFetchTap + R - 3;
 #ifndef H16_DIAG_NO_VMWAIT
+        constexpr int NW1 = (R - 3) * (C::W_DMA_PER_WAVE - 1);          // waves that skip the last piece
         if (!hasD) {
           __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
         } else if (near_fetch && more) {
-          __builtin_amdgcn_s_waitcnt(waitcnt_vm(NW + NIN));
+          if (dma_full) __builtin_amdgcn_s_waitcnt(waitcnt_vm(NW + NIN)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(NW1 + NIN));
         } else {
-          __builtin_amdgcn_s_waitcnt(waitcnt_vm(NW));
+          if (dma_full) __builtin_amdgcn_s_waitcnt(waitcnt_vm(NW)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(NW1));
         }
 #endif
         __builtin_amdgcn_s_barrier();
@@ -549,14 +558,15 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         // INB == 1: the LDS reads still in flight here (the next step's first fragments) are of a tile / ring slot nobody
         // overwrites before the next barrier, and no ds_write is pending, so lgkmcnt is left alone
 #define BSR_WAIT_STEP(n) do { if constexpr (INB == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(n)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(n)); } while (0)
+        constexpr int NW1 = (R - 3) * (C::W_DMA_PER_WAVE - 1);          // waves that skip the last piece
         if (!has3) {
           BSR_WAIT_STEP(0);
         } else if (n_in == 2) {
-          BSR_WAIT_STEP(NW + 2 * NIN);
+          if (dma_full) BSR_WAIT_STEP(NW + 2 * NIN); else BSR_WAIT_STEP(NW1 + 2 * NIN);
         } else if (n_in == 1) {
-          BSR_WAIT_STEP(NW + NIN);
+          if (dma_full) BSR_WAIT_STEP(NW + NIN); else BSR_WAIT_STEP(NW1 + NIN);
         } else {
-          BSR_WAIT_STEP(NW);
+          if (dma_full) BSR_WAIT_STEP(NW); else BSR_WAIT_STEP(NW1);
         }
 #undef BSR_WAIT_STEP
 #endif

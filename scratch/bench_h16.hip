@@ -63,6 +63,8 @@ int main() {
   if (run<3, 3, 1, true, 2, 32, 1, 2>("up2 x3", 32, 64, 64, 160, 64)) return 1;
   if (run<3, 3, 1, true, 1, 32, 1, 2>("clr_up2 x3", 32, 64, 64, 128, 96)) return 1;
   if (run<3, 3, 1, false, 2, 32, 1, 2>("res.conv2 x3", 32, 32, 32, 128, 128)) return 1;
+  if (run<3, 3, 1, false, 2, 32, 1, 1>("res.conv2 f16", 32, 32, 32, 128, 128)) return 1;
+  if (run<3, 3, 2, false, 2, 16, 1, 1>("down1 f16", 32, 256, 256, 32, 64)) return 1;
   if (run<3, 3, 2, false, 2, 16, 1, 2>("down1 x3", 32, 256, 256, 32, 64)) return 1;
   if (run<3, 3, 2, false, 2, 16, 1, 2>("down2 x3", 32, 128, 128, 64, 64)) return 1;
   return 0;
