@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
       // is), which exposes the fragment reads of every step.  The waits this kernel needs for the DMAs are the explicit counted ones.
       const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_w + off + c * 256);
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                   :: "v"(dma_src[i]), "s"(base), "s"(lds_addr) : "memory");
+                   :: "v"(dma_src[i]), "s"(base), "s"(lds_addr) : "memory", "m0");
 #else
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_src[i]),
                                        (__attribute__((address_space(3))) void*)(s_w + off + c * 256), 16, 0, 0);
