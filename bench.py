@@ -462,6 +462,7 @@ def run_rank(args):
     packed = [torch.empty((B, HW, HW, 4), device=dev) for _ in range(2)]          # con_rgb | dif: what callers consume
     gathered = [torch.empty((world * B, HW, HW, 4), device=dev) for _ in range(2)] if distributed else None
     pending = [None, None]
+    last = [None, None]                     # the output tuple of the last forward in each slot
 
     def forward(slot):
         if tsm:
@@ -474,6 +475,7 @@ def run_rank(args):
             pending[slot].wait()
             pending[slot] = None
         o = forward(slot)
+        last[slot] = o
         if distributed and gather and not args.no_gather:
             torch.cat((o[1], o[3]), dim=3, out=packed[slot])
             pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
@@ -522,7 +524,21 @@ def run_rank(args):
         t_g, _ = timed(args.steps, gather_only)
         owns = [None] * world
         dist.all_gather_object(owns, own)
-        extra = {"allgather": {"bytes_per_rank": packed[0].numel() * 4, "ms_alone": round(t_g / args.steps * 1e3, 4),
+        # the collective's RESULT, not only its cost: one more step, then every rank checks that its own shard of the gathered buffer is
+        # bit-identical to what it packed and that every OTHER rank's shard has the checksum that rank computed locally
+        step(0)
+        drain()
+        sync()
+        mine = gathered[0][rank * B:(rank + 1) * B]
+        ok = bool(torch.equal(mine, packed[0])) and bool(torch.equal(packed[0][..., :3], last[0][1])) and bool(torch.equal(packed[0][..., 3:], last[0][3]))
+        sums = [None] * world
+        dist.all_gather_object(sums, float(packed[0].double().sum().item()))
+        for r_, s_ in enumerate(sums):
+            ok = ok and float(gathered[0][r_ * B:(r_ + 1) * B].double().sum().item()) == s_
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+        extra = {"allgather": {"bytes_per_rank": packed[0].numel() * 4, "backend": args.backend, "verified": all(oks),
+                               "ms_alone": round(t_g / args.steps * 1e3, 4),
                                "ms_per_step_without_gather": round(t_nog / args.steps * 1e3, 4),
                                "ms_exposed_per_step": round((elapsed - t_nog) / args.steps * 1e3, 4)},
                  "per_rank_images_per_sec": [round(B * args.steps / o, 2) for o in owns]}
@@ -576,7 +592,7 @@ def run_rank(args):
                                                   with_parity=(world == 1 and not args.no_cpu_baseline))
             if args.loop and world == 1:
                 from blindshadowremoval_amd.loop_bench import loop_bench
-                result["loop"] = loop_bench(args.loop, gen)
+                result["loop"] = loop_bench(args.loop, os.path.join(ROOT, "tests", "golden"), gen)
         line = json.dumps(result) + "\n"
         if real_stdout is not None:
             sys.stdout.flush()

@@ -4,13 +4,17 @@
 // BatchNorm + LeakyReLU, /root/reference/model.py:115-177); what changes is the operand format inside the workgroup:
 //
 //  NSPLIT = 2 ("f32x3", split-precision contraction): every fp32 operand x is split at staging time into two fp16 planes,
-//      hi = fp16(x) and lo = fp16(x - hi) (x = hi + lo to ~2^-22 |x|), and a K group of 16 channels is contracted with THREE
-//      matrix instructions into the same fp32 accumulator: hi.hi + hi.lo + lo.hi (the lo.lo term, < 2^-22 relative, is dropped).
-//      The fp16 products are exact in fp32, so the result differs from the fp32 MFMA path by a few 2^-22 relative per
-//      product — fp32-class accuracy at 16/3 of the fp32 matrix rate.  Activations and outputs stay fp32 in HBM, so the
-//      kernels are drop-in for the fp32 ones; weights are split offline (pack.py, "<layer>.w2" entries).
-//      Range: |x| must stay below 65504 (fp16 max) — beyond it hi is inf; operands below 2^-14 lose relative (not absolute)
-//      precision because lo becomes subnormal (gfx950 matrix cores do not flush fp16 subnormals).
+//      hi = fp16(x) and lo = fp16(x - hi), and a K group of 16 channels is contracted with THREE matrix instructions into the
+//      same fp32 accumulator: hi.hi + hi.lo + lo.hi (the lo.lo term, <= 2^-22 relative, is dropped).  The fp16 products are exact
+//      in fp32.  Accuracy of the split itself: x - hi is at most 2^-11 |x|, and the lo plane is stored UNSCALED, so it is a
+//      NORMAL fp16 number (x = hi + lo to 2^-22 |x|) only while |x| >= 2^-3; below that lo is an fp16 subnormal (the gfx950
+//      matrix cores do not flush them) with spacing 2^-24, i.e. every operand carries an ABSOLUTE error of up to 2^-25 ~ 3e-8 —
+//      2^-17 .. 2^-20 relative for the |w| ~ 0.004 .. 0.05 of a folded conv kernel.  That is "fp32-class" only in the sense the
+//      tests state it: the same 1e-3 / 2e-5 end-to-end tolerances as the fp32 path hold with room (measured 4.5e-6 vs 4.3e-6), not
+//      2^-22 per product.  Activations and outputs stay fp32 in HBM, so the kernels are drop-in for the fp32 ones; weights are
+//      split offline (pack.py).  Range: |x| >= 65504 (fp16 max) makes hi = inf and lo = NaN where the fp32 path stays finite:
+//      weights are range-checked at pack time; activations are checked on the device — a staged operand whose hi half is not
+//      finite sets the handle's sticky range flag (BSR_ERR_RANGE from the next bsr_* call / bsr_check_range).
 //  NSPLIT = 1 ("f16", BASELINE configs[3]): hi plane only, one matrix instruction per K group, half-width LDS tiles.
 //
 // LDS row of one pixel / one output channel: [CC halves hi | CC halves lo (NSPLIT = 2) | 8 halves pad]  = LDP 32-bit words;

@@ -87,6 +87,8 @@ class Logging(object):
         return np.rint(np.concatenate(column, axis=1)).astype(np.uint8)
 
     def save_img(self, fig: Sequence[torch.Tensor], fname: str) -> str:
+        """Returns the PNG's path.  With png_threads > 0 the file is written ASYNCHRONOUSLY: it exists (and `saved` is accurate)
+        only after flush() / close() returned."""
         strip = self.get_imgs(fig)
         parts = fname.replace('\\', '/').split('/')
         stem = (parts[-2] + '_' if len(parts) > 1 else '') + parts[-1].split('.')[0]
@@ -110,8 +112,23 @@ class Logging(object):
     def flush(self) -> None:
         """Wait for every queued PNG (re-raises a writer's exception)."""
         pending, self._pending = self._pending, []
-        for f in pending:
-            f.result()
+        first = None
+        for f in pending:                        # wait for ALL of them even when one failed, then report the first failure
+            try:
+                f.result()
+            except BaseException as e:           # noqa: BLE001
+                first = first or e
+        if first is not None:
+            raise first
+
+    def close(self) -> None:
+        """flush() + shut the writer threads down."""
+        try:
+            self.flush()
+        finally:
+            if self._pool is not None:
+                self._pool.shutdown(wait=True)
+                self._pool = None
 
 
 def _name(x) -> str:
@@ -187,9 +204,14 @@ class FSRNet(object):
             out[k] = np.repeat(a[:, :, None], 3, axis=2)
         return out
 
-    def _loop(self, dataset, batch: int, ucb: bool, postprocess: bool = True):
-        self._restore()
-        start = time.time()
+    def _loop(self, dataset, batch: int, ucb: bool, postprocess: bool = True, mask_files=None):
+        try:
+            return self._loop_body(dataset, batch, ucb, postprocess, mask_files)
+        finally:
+            # also on an exception mid-loop (loader failure, missing mask): no queued PNG writer is left unobserved
+            self.log.flush()
+
+    def _loop_body(self, dataset, batch: int, ucb: bool, postprocess: bool, mask_files):
         names = list(dataset.name_list)
         num_list = len(names)
         results = []
@@ -198,9 +220,16 @@ class FSRNet(object):
         tm = {"prep_wait_s": 0.0, "forward_s": 0.0, "post_s": 0.0, "png_s": 0.0, "forwards": 0, "items": 0}
         self.timings = tm
         pending: List[Tuple[int, str, torch.Tensor, object]] = []
-        mask_files = self._ucb_masks() if ucb and postprocess else None
-        if mask_files is not None and len(mask_files) < len(set(names)):
-            raise ValueError("FSRNet.test: %d items but only %d mask files" % (len(set(names)), len(mask_files)))
+        # the reference indexes its mask lists by the loop counter (train_test_GSC.py:386-396: masks[count]): item `step` is
+        # evaluated against mask file `step`, and a shorter mask list is an error, never a wrap-around
+        if ucb and postprocess:
+            mask_files = self._ucb_masks() if mask_files is None else list(mask_files)
+            if len(mask_files) < num_list:
+                raise ValueError("FSRNet.test: %d items but only %d mask files" % (num_list, len(mask_files)))
+        else:
+            mask_files = None
+        self._restore()
+        start = time.time()
 
         def flush():
             if not pending:
@@ -228,7 +257,7 @@ class FSRNet(object):
                     step, _, _, box = pending[j]
                     with np.errstate(invalid="ignore", divide="ignore"):
                         return ucb_postprocess(im[j].numpy(), gt[j].numpy(), con_h[j], mask_h[j], np.asarray(box).reshape(-1)[:4],
-                                               self._read_masks(mask_files[step % len(mask_files)]))
+                                               self._read_masks(mask_files[step]))
                 if len(pending) > 1 and self.post_threads > 1:
                     from concurrent.futures import ThreadPoolExecutor
                     with ThreadPoolExecutor(max_workers=min(self.post_threads, len(pending))) as ex:
@@ -286,10 +315,11 @@ class FSRNet(object):
         and ``.name_list`` (dataset.py:29-30)."""
         return self._loop(dataset_val, batch, ucb=False)
 
-    def test(self, dataset_val, batch: int = 16, postprocess: bool = True):
+    def test(self, dataset_val, batch: int = 16, postprocess: bool = True, mask_files=None):
         """train_test_GSC.py:360-408 + test_step :411-748.  Returns [(name, figs, {'ssim','psnr'})] with the reference's seven
-        figures per item; ``postprocess=False`` returns the raw generator outputs [(name, [img, gs, con_rgb, dif, gt, face])]."""
-        return self._loop(dataset_val, batch, ucb=True, postprocess=postprocess)
+        figures per item; ``postprocess=False`` returns the raw generator outputs [(name, [img, gs, con_rgb, dif, gt, face])].
+        ``mask_files``: optional explicit per-item list (as ``_ucb_masks()`` returns it) instead of the folder listing."""
+        return self._loop(dataset_val, batch, ucb=True, postprocess=postprocess, mask_files=mask_files)
 
 
 def roc_auc_score(labels: np.ndarray, scores: np.ndarray) -> float:
@@ -365,13 +395,15 @@ class FSRNetTSM(object):
         start = time.time()
         names = list(dataset_val.name_list)
         results = []
-        for step, img_name in enumerate(names):
-            element = next(dataset_val.feed)
-            losses, figs = step_fn(element[0], element[1] if len(element) > 1 else None, training=False)
-            self.log.display(losses, 0, step, False, len(names))
-            self.log.save_img(figs, _name(img_name))
-            results.append((_name(img_name), losses, figs))
-        self.log.flush()
+        try:
+            for step, img_name in enumerate(names):
+                element = next(dataset_val.feed)
+                losses, figs = step_fn(element[0], element[1] if len(element) > 1 else None, training=False)
+                self.log.display(losses, 0, step, False, len(names))
+                self.log.save_img(figs, _name(img_name))
+                results.append((_name(img_name), losses, figs))
+        finally:
+            self.log.flush()
         print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
         return results
 

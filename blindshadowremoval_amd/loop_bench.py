@@ -1,7 +1,7 @@
 """End-to-end rate of the reference's test loops on this box (bench.py --loop ffhq|ucb): host input preparation (Dataset, with and
 without the worker pool) -> host-to-device -> generator forward -> the reference's post-processing -> PNG strips, i.e.
 `FSRNet.testFFHQ` (train_test_GSC.py:840-890) / `FSRNet.test` (:360-748) as a user runs them — NOT the `value` of bench.py, which
-times the forward alone on resident inputs.  The fixtures under tests/golden are the reference's own sample data
+times the forward alone on resident inputs.  The fixtures bench.py points it at (tests/golden) are the reference's own sample data
 (sample_imgs/02165; the first 20 UCB items with their seven masks), repeated to a list of ~100 items (BASELINE configs[2]: the
 UCB test set has 100 items)."""
 from __future__ import annotations
@@ -17,11 +17,12 @@ from .dataset import Dataset
 from .fsrnet import Config, FSRNet
 from .weights import init_weights
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def loop_bench(kind: str, gen=None, items: int = 100, batch: int = 16, workers: int = -1, dtype: str = "f32") -> dict:
+def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int = 16, workers: int = -1, dtype: str = "f32") -> dict:
+    """``data_root``: a folder laid out like the reference's working directory — ``sample_imgs/*``, ``UCB/train/input/*`` and
+    ``UCB_masks/UCB_input_images_*`` (bench.py passes the repo's tests/golden fixtures)."""
+    GOLDEN = data_root
     ucb = kind == "ucb"
     cfg = Config(0)
     out_dir = tempfile.mkdtemp(prefix="bsr_loop_")
@@ -35,10 +36,13 @@ def loop_bench(kind: str, gen=None, items: int = 100, batch: int = 16, workers: 
         for label, nw in (("serial_loader", 0), ("pooled_loader", workers)):
             ds = Dataset(cfg, "test", ucb=ucb, workers=nw)
             base = list(ds.name_list)
-            ds.name_list = (base * ((items + len(base) - 1) // len(base)))[:items]
+            reps = (items + len(base) - 1) // len(base)
+            ds.name_list = (base * reps)[:items]
+            # item i of the repeated list is evaluated against mask i of the equally repeated mask list (FSRNet.test indexes strictly)
+            masks = (fsr._ucb_masks()[:len(base)] * reps)[:items] if ucb else None
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
-                out = fsr.test(ds, batch=batch) if ucb else fsr.testFFHQ(ds, batch=batch)
+                out = fsr.test(ds, batch=batch, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=batch)
             dt = time.perf_counter() - t0
             tm = dict(fsr.timings)
             res[label] = {"workers": ds.workers, "items": len(out), "images_per_sec": round(len(out) / dt, 2), "seconds": round(dt, 3),

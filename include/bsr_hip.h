@@ -36,9 +36,13 @@ typedef struct bsr_handle bsr_handle;
 #define BSR_DTYPE_F16 1     /* BASELINE configs[3]: fp16 operands (fp32 accumulate) on the 3x3-conv path via v_mfma_f32_32x32x16_f16, with the tensors between
                                those layers kept as fp16 in the library's workspace; trunk, 1x1 / attention kernels (split precision) and all
                                inputs / outputs of the ABI stay fp32.  ~1.3e-3 absolute accuracy */
-#define BSR_DTYPE_F32X3 2   /* split-precision fp32: every operand of the 3x3-conv path is split into hi + lo fp16 halves at staging time and contracted
-                               with three fp16 matrix instructions (hi.hi + hi.lo + lo.hi, fp32 accumulate): fp32-class accuracy (~2^-22 per product) at
-                               16/3 of the fp32 matrix rate.  Activations / outputs stay fp32.  Requires |activations| < 65504. */
+#define BSR_DTYPE_F32X3 2   /* split-precision fp32: every operand of the matrix kernels is split into hi + lo fp16 halves at staging time and contracted
+                               with three fp16 matrix instructions (hi.hi + hi.lo + lo.hi, fp32 accumulate) at 16/3 of the fp32 matrix rate.
+                               Accuracy: x = hi + lo to 2^-22 |x| while |x| >= 2^-3; smaller operands carry an absolute error of up to 2^-25
+                               (lo is an unscaled fp16 subnormal), i.e. 2^-17..2^-20 relative for typical folded weights — the 1e-3 end-to-end
+                               parity bar holds with the fp32 path's margin (measured 4.5e-6), it is NOT 2^-22 per product.  Activations / outputs
+                               stay fp32.  Range: |activation| must stay below 65504 (fp16 max); a violation is DETECTED on the device and
+                               reported as BSR_ERR_RANGE (bsr_check_range), never silently turned into inf / NaN outputs. */
 
 /* Replaces Generator() construction + tf.train.Checkpoint(generator=...).restore(...)
  * (/root/reference/train_test_GSC.py:120, :143-148, :365, :845).

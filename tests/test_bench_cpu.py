@@ -27,6 +27,7 @@ def test_gpus2_launches_two_ranks_over_gloo():
     assert j["config"]["collective"].startswith("all_gather")
     ag = j["config"]["allgather"]
     assert ag["bytes_per_rank"] == 2 * 256 * 256 * 4 * 4 and ag["ms_alone"] > 0
+    assert ag["verified"] is True and ag["backend"] == "gloo"          # every rank's shard of the gathered buffer checked against what that rank packed
     assert len(j["config"]["per_rank_images_per_sec"]) == 2
     assert abs(j["value"] - 4 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-3      # whole-job aggregate over both ranks
     assert j["repeats"]["n"] == 2 and j["repeats"]["ms_per_step_min"] > 0

@@ -186,3 +186,40 @@ def test_tsm_512_frames():
     ref = GeneratorTSMOracle(w)(inp, uv, reg, 2, True, bmask_override=gen.probe("bmask").cpu())
     for a, b in zip(out, ref):
         assert float((a - b).abs().max()) <= 1e-3
+
+
+def test_ucb_masks_are_indexed_strictly_by_item(golden_dir, tmp_path):
+    """train_test_GSC.py:386-396 reads masks[count]: a name list longer than the mask list is an error (never a wrap-around),
+    checked before any weight is needed — runs on CPU."""
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+
+    class DS:
+        name_list = ["a.npy"] * 21
+        feed = iter(())
+    cfg = Config(0)
+    cfg.CHECKPOINT_DIR = str(tmp_path)
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    fsr = FSRNet(cfg)
+    n_masks = len(fsr._ucb_masks())
+    DS.name_list = ["a.npy"] * (n_masks + 1)
+    with pytest.raises(ValueError, match="mask files"):
+        fsr.test(DS())
+    with pytest.raises(ValueError, match="mask files"):
+        fsr.test(DS(), mask_files=fsr._ucb_masks()[:3])
+
+
+def test_logging_flush_waits_for_all_writers_and_reraises(tmp_path):
+    from blindshadowremoval_amd.fsrnet import Config, Logging
+    cfg = Config(0)
+    cfg.CHECKPOINT_DIR = str(tmp_path)
+    log = Logging(cfg, png_threads=2)
+    img = torch.rand(1, 8, 8, 3)
+    p1 = log.save_img([img], "x/one.png")
+    bad = os.path.join(str(tmp_path), "test", "x_two-result.png")
+    os.makedirs(bad)                                   # a directory where the PNG should go: this writer fails
+    log.save_img([img], "x/two.png")
+    p3 = log.save_img([img], "x/three.png")
+    with pytest.raises(Exception):
+        log.flush()
+    assert os.path.isfile(p1) and os.path.isfile(p3)   # the good ones were still waited for
+    log.close()

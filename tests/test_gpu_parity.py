@@ -385,3 +385,177 @@ def test_two_handles_on_two_streams_match_serial_runs():
             assert torch.equal(x, y)
     for g in gens:
         g.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / configs[4] at their STATED sizes on one GPU (the 8-way shard of these batches is bench.py's RCCL path; rows
+# (GSC) / frame groups (TSM) are independent, so the single-GPU result is what the 8 ranks' all-gather must re-assemble).
+
+def _slices_equal(big, small, lo, hi):
+    for a, b in zip(big, small):
+        if not torch.equal(a[lo:hi], b):
+            return False
+    return True
+
+
+def test_config3_full_size_f16_batch256():
+    """configs[3] "Batch=256 synthetic 256x256x3, fp16 MFMA conv path": ONE B = 256 forward (21 GB of workspace) must equal, bit for
+    bit, the eight B = 32 per-rank forwards of the same rows; 8 sampled rows against the fp32 oracle at the f16 tolerance; the
+    size-independent output properties on all 256."""
+    from blindshadowremoval_amd import Generator
+    from oracle.gsc_oracle import GeneratorOracle
+    F16_TOL = 2e-3
+    weights = init_weights(1)
+    gen = Generator(dtype="f16").load_weights(weights)
+    g = torch.Generator().manual_seed(41)
+    B = 256
+    inp, uv = torch.rand(B, 256, 256, 3, generator=g), torch.rand(B, 256, 256, 3, generator=g)
+    uv[:, :, :40] = 0
+    inp_d, uv_d = inp.cuda(), uv.cuda()
+    big = [t.clone() for t in gen(inp_d, uv_d)]
+    bm_big, d32_big = gen.probe("bmask").clone(), gen.probe("d32").clone()
+    for r in range(8):                                       # the per-rank shards of the 8-GPU run
+        lo, hi = 32 * r, 32 * r + 32
+        small = gen(inp_d[lo:hi].contiguous(), uv_d[lo:hi].contiguous())
+        assert _slices_equal(big, small, lo, hi), "rank %d shard differs from the B = 256 forward" % r
+    gs, con_rgb, mask22, dif = big
+    assert all(bool(torch.isfinite(t).all()) for t in big)
+    assert float(mask22[..., 1].abs().max()) == 0.0 and float((mask22[..., 0] * mask22[..., 2]).abs().max()) == 0.0
+    gw = torch.tensor([0.2989, 0.5870, 0.1140], device="cuda")
+    assert float((dif - ((con_rgb * gw).sum(-1, keepdim=True) - (inp_d * gw).sum(-1, keepdim=True))).abs().max()) < 1e-5
+    rows = [0, 31, 32, 100, 127, 128, 200, 255]
+    oracle, pr = GeneratorOracle(weights), {}
+    oracle(inp[rows], uv[rows], probes=pr)
+    assert float((d32_big[rows].cpu() - pr["d32"]).abs().max()) <= F16_TOL
+    flips = bm_big[rows].cpu() != pr["bmask"]
+    assert not flips.any() or float((pr["d32"][flips] - 0.1).abs().max()) < F16_TOL
+    ref = oracle(inp[rows], uv[rows], bmask_override=bm_big[rows].cpu())
+    for a, b, name in zip(big, ref, ("gs", "con_rgb", "mask22", "dif")):
+        err = float((a[rows].cpu() - b).abs().max())
+        print("configs[3] B=256 f16 %s max abs err %.3e" % (name, err))
+        assert err <= F16_TOL, name
+    gen.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32"])
+def test_config4_full_size_tsm_512_batch64(dtype):
+    """configs[4] "512x512 frames batch=64" through the TSM generator, frame = 2 (train_with_TSM.py:676): ONE B = 64 forward must
+    equal bit for bit the eight B = 8 per-rank forwards (shards on frame-group boundaries); two frame groups (4 images) from both
+    ends of the batch against the TSM oracle at 1e-3."""
+    from blindshadowremoval_amd import GeneratorTSM
+    from oracle.gsc_oracle import GeneratorTSMOracle
+    from parity_util import FLIP_TOL, TOL
+    w = init_weights(1, variant="tsm")
+    gen = GeneratorTSM(dtype=dtype).load_weights(w)
+    g = torch.Generator().manual_seed(43)
+    B, S = 64, 512
+    inp, uv = torch.rand(B, S, S, 3, generator=g), torch.rand(B, S, S, 3, generator=g)
+    reg = torch.nn.functional.interpolate((torch.rand(B, 6, 9, 9, generator=g) - 0.5) * 0.2, size=(S, S), mode="bicubic",
+                                          align_corners=True).permute(0, 2, 3, 1).contiguous()
+    reg[..., 2] = 0
+    reg[..., 5] = 0
+    inp_d, uv_d, reg_d = inp.cuda(), uv.cuda(), reg.cuda()
+    big = [t.clone() for t in gen(inp_d, uv_d, reg_d, 2, True)]
+    bm_big, d32_big = gen.probe("bmask").clone(), gen.probe("d32").clone()
+    for r in range(8):
+        lo, hi = 8 * r, 8 * r + 8
+        small = gen(inp_d[lo:hi].contiguous(), uv_d[lo:hi].contiguous(), reg_d[lo:hi].contiguous(), 2, True)
+        assert _slices_equal(big, small, lo, hi), "rank %d shard differs from the B = 64 forward" % r
+    assert all(bool(torch.isfinite(t).all()) for t in big)
+    rows = [0, 1, 62, 63]                                   # frame groups 0 and 31
+    oracle, pr = GeneratorTSMOracle(w), {}
+    oracle(inp[rows], uv[rows], reg[rows], 2, True, probes=pr)
+    assert float((d32_big[rows].cpu() - pr["d32"]).abs().max()) <= TOL
+    bm = bm_big[rows].cpu()
+    flips = bm != pr["bmask"]
+    assert not flips.any() or float((pr["d32"][flips] - 0.1).abs().max()) < FLIP_TOL
+    ref = oracle(inp[rows], uv[rows], reg[rows], 2, True, bmask_override=bm)
+    for a, b, name in zip(big, ref, ("gs", "con_rgb", "mask22", "dif")):
+        err = float((a[rows].cpu() - b).abs().max())
+        print("configs[4] B=64 512x512 TSM %s %s max abs err %.3e" % (dtype, name, err))
+        assert err <= TOL, name
+    gen.close()
+
+
+@pytest.mark.parametrize("H,W", [(288, 256), (320, 512)])
+def test_heights_that_are_not_powers_of_two(gen_w, H, W):
+    """The C ABI accepts H % 32 == 0, W % 256 == 0: 288x256 (1152 tokens) and 320x512 (2560 tokens) exercise the attention
+    kernel's XCD remap with a block count that is not a power of two and every conv grid with a ragged tile count."""
+    from parity_util import run_and_compare
+    gen, w = gen_w
+    torch.manual_seed(H)
+    inp, uv = torch.rand(2, H, W, 3), torch.rand(2, H, W, 3)
+    out, ref, errs, nflip = run_and_compare(gen, w, inp, uv, want_probes=("x0", "res2", "res5", "y", "f"))
+    assert out[1].shape == (2, H, W, 3)
+
+
+def test_f16_handle_is_reusable_across_shapes():
+    """One f16 handle across B / H / W changes (the workspace keeps fp16 data in half of each slot and a shape change clears only the
+    channel-pad lanes): every forward equals, bit for bit, the same call on a fresh handle."""
+    from blindshadowremoval_amd import Generator
+    w = init_weights(1)
+    gen = Generator(dtype="f16").load_weights(w)
+    g = torch.Generator().manual_seed(51)
+    for (B, H, W) in ((8, 256, 256), (2, 256, 256), (1, 256, 512), (3, 288, 256), (8, 256, 256)):
+        inp, uv = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
+        a = [t.clone() for t in gen(inp, uv)]
+        fresh = Generator(dtype="f16").load_weights(w)
+        b = fresh(inp, uv)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), (B, H, W)
+        fresh.close()
+    gen.close()
+
+
+def test_tsm_f16_mode_tracks_the_oracle():
+    """GeneratorTSM(dtype="f16") (the kTSM16 channel plan with fp16 intermediate tensors) against the fp32 TSM oracle at the f16
+    tolerance — the combination FSRNetTSM(dtype="f16") would run."""
+    from blindshadowremoval_amd import GeneratorTSM
+    from oracle.gsc_oracle import GeneratorTSMOracle
+    F16_TOL = 2e-3
+    w = init_weights(1, variant="tsm")
+    gen = GeneratorTSM(dtype="f16").load_weights(w)
+    g = torch.Generator().manual_seed(53)
+    B = 4
+    inp, uv = torch.rand(B, 256, 256, 3, generator=g), torch.rand(B, 256, 256, 3, generator=g)
+    reg = torch.nn.functional.interpolate((torch.rand(B, 6, 9, 9, generator=g) - 0.5) * 0.3, size=(256, 256), mode="bicubic",
+                                          align_corners=True).permute(0, 2, 3, 1).contiguous()
+    reg[..., 2] = 0
+    reg[..., 5] = 0
+    out = [t.cpu() for t in gen(inp.cuda(), uv.cuda(), reg.cuda(), 2, True)]
+    bmask, d32 = gen.probe("bmask").cpu(), gen.probe("d32").cpu()
+    oracle, pr = GeneratorTSMOracle(w), {}
+    oracle(inp, uv, reg, 2, True, probes=pr)
+    assert float((d32 - pr["d32"]).abs().max()) <= F16_TOL
+    flips = bmask != pr["bmask"]
+    assert not flips.any() or float((pr["d32"][flips] - 0.1).abs().max()) < F16_TOL
+    ref = oracle(inp, uv, reg, 2, True, bmask_override=bmask)
+    for a, b, name in zip(out, ref, ("gs", "con_rgb", "mask22", "dif")):
+        err = float((a - b).abs().max())
+        print("TSM f16 %s max abs err %.3e" % (name, err))
+        assert err <= F16_TOL, name
+    gen.close()
+
+
+def test_bench_rccl_allgather_world1():
+    """bench.py's RCCL path under the driver's `pytest -m gpu`: BSR_BENCH_FORCE_DIST=1 makes the single rank create an RCCL
+    communicator and run the double-buffered all_gather_into_tensor of the packed con_rgb|dif payload every step; bench.py itself
+    checks the gathered buffer against the packed outputs (`allgather.verified`)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BSR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--repeats", "1",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["dtype"] == "f32" and j["value"] > 0
+    assert j["config"]["collective"].startswith("all_gather")
+    ag = j["config"]["allgather"]
+    assert ag["bytes_per_rank"] == 33554432                 # 32 x 256 x 256 x 4 channels x 4 B
+    assert ag["verified"] is True and ag["backend"] == "nccl"
