@@ -17,8 +17,18 @@ calls is provided below with the semantics of SURVEY.md Appendix A, built on the
 oracle/np_loops.py (float64 explicit loops; NOT oracle/gsc_oracle.py, so that the torch oracle the GPU tests use is checked
 against an independent form driven by the reference's own control flow).  Parity therefore stays "unpinned" for A.1-A.7.
 
-Usage:  python tools/make_model_fixture.py            (writes tests/golden/model_py_gsc_64.npz, model_py_gsc_256.npz, model_py_tsm_256.npz;
-                                                        the 256x256 cases take a few minutes: the primitives are Python loops)
+Usage:  python tools/make_model_fixture.py [--backend standin|tf] [gsc64 tsm64 gsc256 tsm256]
+        (default: all four cases over the stand-in; its 256x256 cases take a few minutes: the primitives are Python loops)
+
+--backend tf  — THE PIN THAT IS MISSING HERE.  On any machine with TensorFlow 2.3 (README.md:11 of the reference; tensorflow_addons
+and cv2 are stubbed if absent, they are imported by model.py / warp.py but never executed on this path) the same cases run the
+reference's model.py / model_with_TSM.py UNMODIFIED over REAL TensorFlow: `Generator()` is built by one forward, `init_weights(seed)`
+is assigned variable by variable through the checkpoint attribute paths (train_test_GSC.py:143-148), `Generator.call(...,
+training=False)` runs on the same seeded inputs and the SAME npz keys are written, plus `backend = "tf-<version>"`.  The tests
+(tests/test_model_py_fixture.py) need no change: with such files in tests/golden the oracle and the HIP path are compared with
+TensorFlow's own op arithmetic (SAME padding, Conv2DTranspose scatter / crop, BN epsilon, LeakyReLU alpha, half-pixel resize:
+SURVEY A.1-A.7) and DESIGN.md's "parity unpinned" can be struck.  It cannot run in the build container (no TensorFlow wheel, no
+network) — `--backend tf` fails loudly there.
 """
 import contextlib
 import importlib.util
@@ -292,7 +302,86 @@ def run_reference(module_file, weights, call_args, call_kwargs=None):
     return [np.asarray(o) for o in outs]
 
 
+# ------------------------------------------------------------------------------------------------ real-TensorFlow backend
+def run_reference_tf(module_file, weights, call_args):
+    """The reference's module UNMODIFIED over real TensorFlow.  Returns ([gs, con_rgb, mask22, dif], {"d32": ...}, "tf-<version>")."""
+    try:
+        import tensorflow as tf
+    except ImportError as e:                                            # the build container: no TensorFlow
+        raise SystemExit("--backend tf needs TensorFlow (the reference pins 2.3.0, README.md:11): %s" % e)
+    for name in ("tensorflow_addons", "cv2"):                           # imported at module top (model.py:2, warp.py:2), never executed here
+        try:
+            importlib.import_module(name)
+        except ImportError:
+            sys.modules[name] = types.ModuleType(name)
+    if "scipy.ndimage.interpolation" not in sys.modules:
+        try:
+            importlib.import_module("scipy.ndimage.interpolation")
+        except ImportError:
+            import scipy.ndimage as ndi
+            shim = types.ModuleType("scipy.ndimage.interpolation")
+            shim.map_coordinates = ndi.map_coordinates
+            sys.modules["scipy.ndimage.interpolation"] = shim
+    sys.path.insert(0, REF)
+    try:
+        sys.modules.pop("warp", None)
+        spec = importlib.util.spec_from_file_location("reftf_" + module_file.replace(".py", ""), os.path.join(REF, module_file))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(REF)
+    gen = mod.Generator()
+    tens = [tf.constant(np.asarray(a, np.float32)) if isinstance(a, np.ndarray) else a for a in call_args]
+    # keyword form, exactly as the reference's call sites write it (train_test_GSC.py:871; train_with_TSM.py:676)
+    if len(tens) == 5:                                                  # model.py: (inputs, uv, reg, chuck, training)
+        args, kwargs = tens[:3], {"chuck": tens[3], "training": tens[4]}
+    else:                                                               # model_with_TSM.py: (inputs, uv, reg, frame, share, chuck, training)
+        args, kwargs = tens[:3], {"frame": tens[3], "share": tens[4], "chuck": tens[5], "training": tens[6]}
+    with contextlib.redirect_stdout(io.StringIO()):
+        gen(*args, **kwargs)                                            # Keras creates the variables on the first call
+    assigned = set()
+    for name, val in weights.items():
+        obj = gen
+        parts = name.split("/")
+        for p in parts[:-1]:
+            obj = obj[int(p)] if p.isdigit() else getattr(obj, p)      # res_stack/<i>/... : Keras tracks the Python list as a ListWrapper
+        var = getattr(obj, parts[-1])                                   # kernel / bias / gamma / beta / moving_mean / moving_variance
+        if tuple(var.shape) != tuple(np.shape(val)):
+            raise RuntimeError("%s: reference variable %s vs init_weights %s" % (name, tuple(var.shape), np.shape(val)))
+        var.assign(np.asarray(val, np.float32))
+        assigned.add(var.ref() if hasattr(var, "ref") else id(var))
+    have = {(v.ref() if hasattr(v, "ref") else id(v)) for v in gen.variables}
+    if have != assigned:
+        raise RuntimeError("%d generator variables, %d assigned: the checkpoint attribute paths do not cover the model" % (len(have), len(assigned)))
+    probes = {}
+    orig = tf.image.resize
+
+    def spy(x, size, *a, **k):
+        y = orig(x, size, *a, **k)
+        if x.shape[-1] == 1:                                            # the only 1-channel resize is d32 (model.py:256)
+            probes["d32"] = y.numpy()
+        return y
+    tf.image.resize = spy
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            outs = gen(*args, **kwargs)
+    finally:
+        tf.image.resize = orig
+    return [np.asarray(o.numpy(), np.float64) for o in outs], probes, "tf-" + tf.__version__
+
+
+BACKEND = "standin"
+
+
 def record_probes(module_file, weights, call_args):
+    """-> (outputs, {"d32"}, backend label): over real TensorFlow (--backend tf) or over the stand-in (default)."""
+    if BACKEND == "tf":
+        return run_reference_tf(module_file, weights, [np.asarray(a) if isinstance(a, np.ndarray) else a for a in call_args])
+    outs, probes = record_probes_standin(module_file, weights, call_args)
+    return outs, probes, "standin-np_loops"
+
+
+def record_probes_standin(module_file, weights, call_args):
     """Second run that also captures the 32x32 threshold input: tf.image.resize of a 1-channel map is only called for d32."""
     probes = {}
     orig = P.resize_bilinear
@@ -322,9 +411,9 @@ def synthetic_inputs(seed, B, S):
 def make_gsc(S, B, seed, path):
     w = init_weights(1)
     inp, uv = synthetic_inputs(seed, B, S)
-    (gs, con_rgb, mask22, dif), pr = record_probes("model.py", w, (t(inp, np.float64), t(uv, np.float64), None, 1, False))
+    (gs, con_rgb, mask22, dif), pr, backend = record_probes("model.py", w, (t(inp, np.float64), t(uv, np.float64), None, 1, False))
     d32 = pr["d32"]
-    np.savez_compressed(path, weights_seed=1, input_seed=seed, inputs=inp.astype(np.float16), uv=uv.astype(np.float16),
+    np.savez_compressed(path, backend=backend, weights_seed=1, input_seed=seed, inputs=inp.astype(np.float16), uv=uv.astype(np.float16),
                         gs=gs.astype(np.float32), con_rgb=con_rgb.astype(np.float32), mask22=mask22.astype(np.float32), dif=dif.astype(np.float32),
                         d32=d32.astype(np.float32), bmask=(d32.astype(np.float32) > np.float32(0.1)).astype(np.float32),
                         min_abs_d32_minus_thr=np.float32(np.abs(d32 - 0.1).min()))
@@ -342,9 +431,9 @@ def make_tsm(S, frame, seed, path):
     reg[..., 5] = 0
     reg = reg.astype(np.float16).astype(np.float32)
     args = (t(inp, np.float64), t(uv, np.float64), t(reg, np.float64), frame, True, 1, False)
-    (gs, con_rgb, mask22, dif), pr = record_probes("model_with_TSM.py", w, args)
+    (gs, con_rgb, mask22, dif), pr, backend = record_probes("model_with_TSM.py", w, args)
     d32 = pr["d32"]
-    np.savez_compressed(path, weights_seed=1, input_seed=seed, frame=frame, inputs=inp.astype(np.float16), uv=uv.astype(np.float16),
+    np.savez_compressed(path, backend=backend, weights_seed=1, input_seed=seed, frame=frame, inputs=inp.astype(np.float16), uv=uv.astype(np.float16),
                         reg=reg.astype(np.float16), gs=gs.astype(np.float32), con_rgb=con_rgb.astype(np.float32),
                         mask22=mask22.astype(np.float32), dif=dif.astype(np.float32), d32=d32.astype(np.float32),
                         bmask=(d32.astype(np.float32) > np.float32(0.1)).astype(np.float32),
@@ -354,7 +443,14 @@ def make_tsm(S, frame, seed, path):
 
 if __name__ == "__main__":
     gold = os.path.join(ROOT, "tests", "golden")
-    which = sys.argv[1:] or ["gsc64", "tsm64", "gsc256", "tsm256"]
+    argv = sys.argv[1:]
+    if "--backend" in argv:
+        i = argv.index("--backend")
+        BACKEND = argv[i + 1]
+        del argv[i:i + 2]
+        if BACKEND not in ("standin", "tf"):
+            raise SystemExit("--backend must be standin or tf")
+    which = argv or ["gsc64", "tsm64", "gsc256", "tsm256"]
     if "gsc64" in which:
         make_gsc(64, 2, 11, os.path.join(gold, "model_py_gsc_64.npz"))
     if "tsm64" in which:
