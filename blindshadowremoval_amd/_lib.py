@@ -8,7 +8,7 @@ from typing import Optional
 
 from .build import LIB_PATH
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_CLASSES = 7
 CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue", "convT3x3_ni2")
 
@@ -16,7 +16,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_destroy", "bsr_last_error", "bsr_abi_version")
+           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range")
 
 
 def load() -> ctypes.CDLL:
@@ -61,6 +61,8 @@ def load() -> ctypes.CDLL:
     lib.bsr_debug_attention.restype = c_i
     lib.bsr_debug_attention_dtype.argtypes = [c_v, c_v, c_i, c_i, c_i, c_v]
     lib.bsr_debug_attention_dtype.restype = c_i
+    lib.bsr_check_range.argtypes = [c_v, c_v]
+    lib.bsr_check_range.restype = c_i
     lib.bsr_destroy.argtypes = [c_v]
     lib.bsr_destroy.restype = None
     if lib.bsr_abi_version() != ABI_VERSION:
@@ -69,7 +71,14 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+class RangeError(RuntimeError):
+    """BSR_ERR_RANGE: an activation did not fit fp16 in a forward of a 16-bit-mode handle (include/bsr_hip.h, bsr_check_range)."""
+
+
+ERR_RANGE = 5
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().bsr_last_error()
-        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+        raise (RangeError if rc == ERR_RANGE else RuntimeError)("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

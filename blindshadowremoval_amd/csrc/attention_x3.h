@@ -35,7 +35,8 @@ constexpr int kAx3SmemBytes = 4 * kAx3StageWords * 4;                  // two ti
 static_assert(kAx3SmemBytes <= 160 * 1024, "LDS budget");
 static_assert(66 * 64 * 4 <= 4 * kAx3StageWords, "merge scratch fits the staging buffers");
 
-__global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
+__global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens,
+                                                                       unsigned* __restrict__ range_flag) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,13 +61,16 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
 
   // theta of this lane's query, pre-scaled by log2(e) (softmax in base 2), split: K step s covers channels 16s + 8h .. +7
   f16x8 qh[kAttD / 16], ql[kAttD / 16];
+  float amax = 0.f;                                            // range guard of the 16-bit modes (igemm_h16.h): theta here, phi / g at staging
 #pragma unroll
   for (int s = 0; s < kAttD / 16; ++s) {
     const float* src = base + (size_t)q * (3 * kAttD) + 16 * s + 8 * h;
     const f32x4 a = *reinterpret_cast<const f32x4*>(src) * 1.4426950408889634f;
     const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4) * 1.4426950408889634f;
     split8(a, b, qh[s], ql[s]);
+    amax = amax8(a, b, amax);
   }
+  range_report(amax, range_flag);
 
   f32x16 o[4];
 #pragma unroll
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
     }
   };
   auto publish = [&](int pbuf) {                               // pbuf = 0/1: which pair buffer (2 tiles each)
+    range_report(amax8(vreg[0], vreg[1], amax8(vreg[2], vreg[3], amax8(kreg[0], kreg[1], amax8(kreg[2], kreg[3], 0.f)))), range_flag);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float* sk = smem + (2 * pbuf + i) * kAx3StageWords;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
     }
 }
 
-inline hipError_t launch_nonlocal_attention_x3(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
+inline hipError_t launch_nonlocal_attention_x3(const float* qkv, float* out, int batch, int tokens, hipStream_t stream, unsigned* range_flag = nullptr) {
   if (tokens % (2 * kAttKT) != 0) return hipErrorInvalidValue;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
@@ -234,7 +239,7 @@ inline hipError_t launch_nonlocal_attention_x3(const float* qkv, float* out, int
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
-  hipLaunchKernelGGL(nonlocal_attention_x3_kernel, dim3(batch * (tokens / 128)), dim3(512), kAx3SmemBytes, stream, qkv, out, tokens);
+  hipLaunchKernelGGL(nonlocal_attention_x3_kernel, dim3(batch * (tokens / 128)), dim3(512), kAx3SmemBytes, stream, qkv, out, tokens, range_flag);
   return hipGetLastError();
 }
 

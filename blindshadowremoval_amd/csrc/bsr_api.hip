@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -143,6 +144,10 @@ struct bsr_handle {
   Plan plan{};
   int B = 0, H = 0, W = 0;       // shape of the last forward
   bool ran = false;
+  // Range guard of the 16-bit modes (igemm_h16.h): one word of pinned, device-mapped host memory; a kernel that stages an activation
+  // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
+  unsigned* range_flag = nullptr;
+  int dephase_pct = 0;           // igemm_conv.h dephase_start: percent of half a workgroup's matrix time (env BSR_DEPHASE, experiment)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
   std::vector<int> ev_class;
@@ -151,6 +156,10 @@ struct bsr_handle {
 };
 
 namespace {
+
+const char* const kRangeMsg =
+    "an activation exceeded the fp16 range (|x| >= 65520) in a forward of this 16-bit-mode handle: its outputs are not trustworthy "
+    "(inf / NaN where the fp32 path stays finite).  Re-run those inputs on a BSR_DTYPE_F32 handle; bsr_check_range() clears the condition";
 
 int find_layer(bsr_handle* h, const char* name, int nchunk, int taps, int ldp, int n_min, LayerW* out) {
   auto it = h->layers.find(name);
@@ -233,6 +242,8 @@ struct Launcher {
     a.pad_t = pad_before(H, KH, S);
     a.pad_l = pad_before(W, KW, S);
     a.act = act;
+    a.range_flag = h->range_flag;
+    a.dephase = h->dephase_pct;
     const int mh = TR ? H : a.Ho, mw = TR ? W : a.Wo;
     if (mh % 4 != 0 || mw % 32 != 0) {
       rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': feature map is not a multiple of the 4x32 tile");
@@ -270,6 +281,7 @@ struct Launcher {
     a.w = l.w; a.bias = l.b; a.nchunk = l.nchunk; a.n_pad = l.n_pad; a.n_store = n_store; a.act = act;
     a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c;
     a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
+    a.range_flag = h->range_flag;
     begin(cls, name);
     if (h->dtype == BSR_DTYPE_F32)
       check(bsr::launch_gemm_nloop<NI, NCH, 0>(a, pixels, kNSplit, s), name);
@@ -290,6 +302,7 @@ struct Launcher {
     a.in = in; a.in_cs = in_cs; a.H = H; a.W = W; a.w = l.w; a.bias = l.b; a.out = out; a.out_cs = out_cs; a.act = act;
     a.pad_t = (KH - 1) / 2; a.pad_l = (KW - 1) / 2;
     a.gs = gs; a.w_gs = h->clr_gs_w; a.tail_w = h->tail_w; a.inputs = inputs; a.con_rgb = con_rgb; a.dif = dif;
+    a.range_flag = h->range_flag;
     if (H % (4 * RW) != 0 || W % 32 != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': image is not a multiple of its tile"); return; }
     begin(cls, name);
     if (h->dtype == BSR_DTYPE_F32)
@@ -339,7 +352,7 @@ int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
 
 extern "C" {
 
-int bsr_abi_version(void) { return 2; }
+int bsr_abi_version(void) { return 3; }
 
 const char* bsr_last_error(void) { return g_last_error.c_str(); }
 
@@ -366,6 +379,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   bsr_handle* h = new bsr_handle();
   h->device = device;
   h->dtype = dtype;
+  if (const char* e_ = getenv("BSR_DEPHASE")) h->dephase_pct = atoi(e_);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -405,6 +419,11 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
     }
   }
   if (h->tail_w == nullptr || h->clr_gs_w == nullptr) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob lacks 'tail.w' / 'clr_conv1.gs'"); }
+  if (dtype != BSR_DTYPE_F32) {
+    e = hipHostMalloc(reinterpret_cast<void**>(&h->range_flag), 64, hipHostMallocMapped);
+    if (e != hipSuccess) { h->range_flag = nullptr; bsr_destroy(h); return fail(BSR_ERR_HIP, std::string("bsr_create: range flag: ") + hipGetErrorString(e)); }
+    *h->range_flag = 0u;
+  }
   {   // GSC or TSM weights?  (res0.conv1 has K = 120 -> 5 chunks of 24, or K = 312 -> 13)
     auto it = h->layers.find("res0.conv1");
     if (it == h->layers.end()) { bsr_destroy(h); return fail(BSR_ERR_BLOB, "bsr_create: blob has no 'res0.conv1'"); }
@@ -423,6 +442,7 @@ void bsr_destroy(bsr_handle* h) {
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   if (h->ws) hipFree(h->ws);
   if (h->d_blob) hipFree(h->d_blob);
+  if (h->range_flag) hipHostFree(h->range_flag);
   delete h;
 }
 
@@ -443,6 +463,18 @@ int bsr_reserve(bsr_handle* h, int B, int H, int W) {
     h->ran = false;
   }
   return BSR_OK;
+}
+
+int bsr_check_range(bsr_handle* h, void* stream) {
+  if (h == nullptr) return fail(BSR_ERR_ARG, "bsr_check_range: null handle");
+  if (h->range_flag == nullptr) return BSR_OK;                 // BSR_DTYPE_F32: nothing is ever converted to fp16
+  DeviceGuard guard(h->device);
+  HIP_TRY(guard.err);
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  volatile unsigned* f = h->range_flag;
+  if (*f == 0u) return BSR_OK;
+  *f = 0u;
+  return fail(BSR_ERR_RANGE, kRangeMsg);
 }
 
 int bsr_set_timing(bsr_handle* h, int enable) {
@@ -496,6 +528,8 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   if (H <= 0 || W <= 0 || H % 32 != 0 || W % 256 != 0)
     return fail(BSR_ERR_ARG, "bsr_forward: H must be a multiple of 32 and W a multiple of 256 (reference: 256x256)");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->range_flag != nullptr && *reinterpret_cast<volatile unsigned*>(h->range_flag) != 0u)
+    return fail(BSR_ERR_RANGE, kRangeMsg);      // an earlier forward overflowed fp16: sticky until bsr_check_range() acknowledges it
   DeviceGuard guard(h->device);
   HIP_TRY(guard.err);
   int rc = ensure_workspace(h, B, H, W, s);
@@ -515,7 +549,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     const bool x3 = h->dtype != BSR_DTYPE_F32;                     // split precision in both 16-bit modes
     L.rc = find_layer(h, "conv1", 1, 7, x3 ? 36 : 28, 32, &l);
     if (L.rc == BSR_OK) {
-      bsr::StemArgs a{inputs, ws + p.x1, l.w, l.b, H, W, 0, 0};
+      bsr::StemArgs a{inputs, ws + p.x1, l.w, l.b, H, W, 0, 0, h->range_flag};
       L.begin(K_CONV7, "conv1");
       if (h->dtype == BSR_DTYPE_F16)
         L.check((bsr::launch_stem7<4, 2, true>(a, B, s)), "conv1");                 // x1 stored as fp16
@@ -576,7 +610,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
       if (h->dtype == BSR_DTYPE_F32)
         L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
       else
-        L.check(bsr::launch_nonlocal_attention_x3(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention_x3");
+        L.check(bsr::launch_nonlocal_attention_x3(ws + p.qkv, ws + p.att[i], B, H8 * W8, s, h->range_flag), "attention_x3");
       L.end();
     }
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att)))

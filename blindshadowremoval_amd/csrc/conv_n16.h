@@ -34,6 +34,7 @@ struct ConvN16Args {
   float* con_rgb;       // TAIL: [B,H,W,3]
   float* dif;           // TAIL: [B,H,W,1]
   int tiles_x, tiles_y, batch;   // filled by the launcher
+  unsigned* range_flag; // H = 2: set when a staged activation does not fit fp16 (igemm_h16.h); may be null
 #ifdef BSR_STAMPS
   unsigned long long* stamps;
 #endif
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     }
   };
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  float in_amax = 0.f;                                                  // range guard of the 16-bit modes (igemm_h16.h)
   auto put = [&](char* dst_f32, char* dst_h16, const f32x4& v) {      // 4 channels of one pixel: fp32, or hi | lo fp16 planes
     if constexpr (H == 0) {
       *reinterpret_cast<f32x4*>(dst_f32) = v;
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
       split2(f32x2{v[0], v[1]}, h0, l0);
       split2(f32x2{v[2], v[3]}, h1, l1);
       const f16x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+      in_amax = amax4(v, in_amax);
       *reinterpret_cast<f16x4*>(dst_h16) = hi;
       *reinterpret_cast<f16x4*>(dst_h16 + 64) = lo;
     }
@@ -164,6 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #pragma unroll
     for (int row = 0; row < C::IH; ++row) put(base + lds_m + row * IW * LDP * 4, base + lds_m16 + row * IW * LDP * 4, regs[row]);
     if (HALO_W && tid < HALO_V4) put(base + lds_h, base + lds_h16, regs[C::IH]);
+    if constexpr (H == 2 && !IN16) {
+      range_report(in_amax, p.range_flag);
+      in_amax = 0.f;
+    }
   };
   auto fetch_w = [&](int ch, f32x4 (&regs)[C::W_PER_THREAD]) {
     const float* src = p.w + (size_t)ch * C::W_FLOATS;

@@ -103,13 +103,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
       raw[2 * g] = *reinterpret_cast<const f32x4*>(row + g * 16);
       raw[2 * g + 1] = *reinterpret_cast<const f32x4*>(row + g * 16 + 4);
     }
+    float amax = 0.f;
 #pragma unroll
     for (int g = 0; g < NCH * G; ++g) {
       f16x8 hi, lo;
       split8(raw[2 * g], raw[2 * g + 1], hi, lo);
+      amax = amax8(raw[2 * g], raw[2 * g + 1], amax);
       ahi[g] = hi;
       if (H == 2) alo[g] = lo;
     }
+    range_report(amax, p.range_flag);            // range guard of the 16-bit modes (igemm_h16.h)
   }
   store_w(0, w_regs);
   if (nsteps > 1) store_w(C::W_FLOATS, w_regs1);

@@ -89,10 +89,34 @@ struct ConvArgs {
   int res1_cs, res1_c;  // channel stride; channels [0,res1_c) are read
   int tiles_x, tiles_y; // M tiles per image
   int n_blocks;         // igemm_h16_kernel: > 0 = 1-D grid with the N block as the FASTEST index (the N blocks of a tile share its input through L2)
+  unsigned* range_flag; // 16-bit kernels: set to 1 when a staged activation does not fit fp16 (|x| >= 65520); may be null
+  int dephase;          // > 0: shader cycles the first-round workgroups of the odd wave slot wait before starting (see dephase_start)
+  int first_round;      // workgroups of the first dispatch round (2 per CU)
 #ifdef BSR_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
 #endif
 };
+
+// Multi-round grids of identical workgroups run in LOCKSTEP: the two workgroups that share a CU (one wave each per SIMD) start
+// together, share the matrix pipe through their main loops at 128 cycles per MFMA, reach their epilogues together and are replaced
+// together — so in every round the pipe idles for a whole prologue + epilogue (PMC, round 3: SQ_VALU_MFMA_BUSY_CYCLES = 79 % of
+// the GPU-active cycles on the dominant kernel although its main loop shares the pipe perfectly).  Shifting ONE of the two
+// residents by half a workgroup's life at kernel start puts one's prologue / epilogue under the other's main loop for all later
+// rounds (a slot's next workgroup starts when the previous one ends, so the offset persists).  The shifted set = first-round
+// workgroups whose waves sit in an odd hardware wave slot (HW_REG_HW_ID.wave_id: the first resident of a SIMD gets slot 0, the
+// second slot 1); correctness does not depend on that placement — a wave that sleeps is only late.
+__device__ __forceinline__ void dephase_start(const int dephase, const int first_round) {
+  if (dephase > 0) {
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin < (unsigned)first_round) {
+      const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID (4), bits [3:0] = wave_id
+      if (wave_slot & 1u) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)dephase) __builtin_amdgcn_s_sleep(16);
+      }
+    }
+  }
+}
 
 // INB = number of LDS input-tile buffers: 1 (reload synchronously at chunk boundaries), 2 (taps > 1: next chunk's
 // tile is staged one tap ahead) or 3 (1x1 convs: ring, like the weights).
@@ -138,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   // Prologue and epilogue are VALU/VMEM streams that share the SIMD with a co-resident wave's MFMA stream; at
   // equal priority they get an issue slot only every few dozen cycles (measured: a 128-store epilogue took 41k
   // cycles).  They run at raised priority; the MFMA main loop runs at priority 0.
+  dephase_start(p.dephase, p.first_round);
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -437,6 +462,14 @@ inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream) {
   a.tiles_x = mw / TW;
   a.tiles_y = mh / TH;
   dim3 grid(a.tiles_x * a.tiles_y * batch, (a.n_store + C::BN - 1) / C::BN);
+  {   // dephase (see dephase_start): a.dephase arrives as a PERCENTAGE of half a workgroup's matrix time; only grids of >= 4 rounds
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev >= 0 ? dev : 0);
+    a.first_round = 2 * cus;
+    const long long total = (long long)grid.x * grid.y;
+    const long long mfma_per_wave = (long long)a.nchunk * C::T * C::G * 4 * MI * NI;
+    a.dephase = (a.dephase > 0 && total >= 4LL * a.first_round) ? (int)(mfma_per_wave * 64 * a.dephase / 100) : 0;
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }

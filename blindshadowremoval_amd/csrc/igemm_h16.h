@@ -121,6 +121,27 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
   }
 }
 
+// Range guard of the 16-bit modes.  fp16(x) is inf for |x| >= 65520 (round to nearest even; 65504 is the largest finite value), where
+// the fp32 path stays finite.  Every kernel that converts fp32 activations keeps the running maximum of their magnitudes — one
+// v_max3_f32 with |.| source modifiers per PAIR of values, beside the 5 instructions per pair of the split itself — and a thread that
+// saw an overflowing value stores 1 to the handle's sticky flag (host-visible memory: bsr_check_range / the next bsr_forward report
+// BSR_ERR_RANGE).  NaN inputs are not flagged (v_max drops them); they propagate to the outputs visibly.
+constexpr float kF16Overflow = 65520.f;
+__device__ __forceinline__ float amax8(const f32x4& a, const f32x4& b, float m) {
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1])), m);
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[2]), __builtin_fabsf(a[3])), m);
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(b[0]), __builtin_fabsf(b[1])), m);
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(b[2]), __builtin_fabsf(b[3])), m);
+  return m;
+}
+__device__ __forceinline__ float amax4(const f32x4& a, float m) {
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1])), m);
+  return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[2]), __builtin_fabsf(a[3])), m);
+}
+__device__ __forceinline__ void range_report(float m, unsigned* flag) {
+  if (m >= kF16Overflow && flag != nullptr) *flag = 1u;
+}
+
 // IO (NSPLIT = 1 only — the fp16 pack of BASELINE configs[3]): bit 0 = the INPUT tensor is fp16 in HBM (in_cs / in_coff count halves; a
 // staged piece is one 16-byte load that goes to LDS unconverted — the fp32 form rounds the same values to fp16 at this point, so
 // nothing is lost), bit 1 = the OUTPUT is written as fp16 (out_cs / out_coff count halves).  Both halve that tensor's HBM bytes.
@@ -222,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
     }
   };
   auto store_in = [&](int off, const f32x4 (&regs)[2 * C::IN_PER_THREAD]) {
+    float amax = 0.f;                                                                // range guard: largest |x| this thread converts
 #pragma unroll
     for (int i = 0; i < C::IN_PER_THREAD; ++i) {
       if (in_loff[i] >= 0) {
@@ -232,11 +254,13 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         } else {
           f16x8 hi, lo;
           split8(a, b, hi, lo);
+          amax = amax8(a, b, amax);
           *reinterpret_cast<f16x8*>(s_in + off + in_loff[i]) = hi;
           if (NSPLIT == 2) *reinterpret_cast<f16x8*>(s_in + off + in_loff[i] + LO) = lo;
         }
       }
     }
+    if constexpr (!IN16) range_report(amax, p.range_flag);
   };
   // weights: p.w is the packed fp16 LDS image [chunk][tap][n_pad][LDP words], copied verbatim
   auto fetch_w = [&](int step, f32x4 (&regs)[C::W_PER_THREAD]) {
@@ -645,6 +669,12 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
             v[i] = y[0];
             v[i + 1] = y[1];
           }
+        }
+        if constexpr (OUT16) {                 // the fp16 activation pack converts here: range guard on what is about to be rounded
+          float amax = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; i += 4) amax = amax4(f32x4{v[i], v[i + 1], v[i + 2], v[i + 3]}, amax);
+          range_report(voff == kLaneOff ? 0.f : amax, p.range_flag);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

@@ -20,6 +20,7 @@ struct StemArgs {
   const float* bias;   // [32]
   int H, W;
   int tiles_x, tiles_y;
+  unsigned* range_flag;   // H = 2: set when an image value does not fit fp16 (igemm_h16.h); OUT16: when an output does not; may be null
 };
 
 // H = 2 (split precision, igemm_h16.h): every image value is split ONCE at staging time and kept in LDS as one 32-bit word
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
 
   // stage the weights (linear copy) and the raw image tile (zero outside the image: TF SAME padding 3/3)
   for (int i = tid; i < C::W_FLOATS / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+  float amax = 0.f;
   for (int i = tid; i < C::IN_FLOATS; i += 256) {
     const int row = i / ROWF, f = i % ROWF;
     const int px = f / 3, c = f % 3;
@@ -65,10 +67,12 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
     if constexpr (H == 0) {
       s_in[i] = v;
     } else {
+      amax = __builtin_fmaxf(__builtin_fabsf(v), amax);
       const _Float16 vh = (_Float16)v, vl = (_Float16)(v - (float)vh);
       reinterpret_cast<unsigned*>(s_in)[i] = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
     }
   }
+  if constexpr (H != 0) range_report(amax, p.range_flag);
   const float bias = p.bias[r];
   f32x16 acc[RW];
 #pragma unroll
@@ -143,6 +147,12 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
       const f32x2 y = leaky_relu2(f32x2{v[i], v[i + 1]});
       v[i] = y[0];
       v[i + 1] = y[1];
+    }
+    if constexpr (OUT16) {
+      float om = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) om = amax4(f32x4{v[i], v[i + 1], v[i + 2], v[i + 3]}, om);
+      range_report(om, p.range_flag);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

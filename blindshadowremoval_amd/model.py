@@ -24,6 +24,9 @@ from .tf_bundle import latest_checkpoint, load_generator_weights
 
 class Generator:
     def __init__(self, downsize: int = 1, n_res: int = 6, device: Optional[int] = None, dtype: str = "f32"):
+        """``dtype``: "f32" (fp32 matrix cores — the measured path and the default), "f32x3" (split-precision fp32 on the fp16 matrix
+        cores: same end-to-end tolerance, ~1.9x faster, activations must stay below 65520 in magnitude — a violation is detected on
+        the device and raised by ``check_range()`` / the next call, never silent) or "f16" (BASELINE configs[3])."""
         if dtype not in DTYPES:
             raise ValueError("dtype must be 'f32' (the measured path), 'f32x3' (split-precision fp32 on the 16-bit matrix cores) or "
                              "'f16' (fp16 operands on the 3x3-conv path, BASELINE configs[3])")
@@ -165,6 +168,17 @@ class Generator:
         _lib.check(rc, "bsr_forward_tsm")
         self._shape = (B, H, W)
         return gs, con_rgb, mask22, dif
+
+    def check_range(self) -> None:
+        """16-bit modes (dtype "f32x3" / "f16"): synchronise the current stream and raise ``_lib.RangeError`` if any forward since
+        the last call converted an activation of magnitude >= 65520 to fp16 (its outputs hold inf / NaN where the fp32 path stays
+        finite: discard them and re-run on a ``dtype="f32"`` generator).  The kernels detect this on the device (bsr_check_range in
+        include/bsr_hip.h); without a call the NEXT forward after a completed overflowing one raises instead.  No-op for "f32"."""
+        if self._handle is None:
+            raise RuntimeError("Generator has no weights: call load_weights() or restore() first")
+        with torch.cuda.device(self._device):
+            rc = self._lib.bsr_check_range(self._handle, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "bsr_check_range")
 
     # -- test / measurement hooks -----------------------------------------------------------
     def probe(self, name: str) -> torch.Tensor:

@@ -31,6 +31,7 @@ typedef struct bsr_handle bsr_handle;
 #define BSR_ERR_BLOB 2     /* malformed or mismatching packed-weight blob */
 #define BSR_ERR_HIP 3      /* a HIP runtime call failed */
 #define BSR_ERR_STATE 4    /* probe requested before any forward, unknown probe name, ... */
+#define BSR_ERR_RANGE 5    /* 16-bit modes: an activation did not fit fp16 (|x| >= 65520) — see bsr_check_range */
 
 #define BSR_DTYPE_F32 0
 #define BSR_DTYPE_F16 1     /* BASELINE configs[3]: fp16 operands (fp32 accumulate) on the 3x3-conv path via v_mfma_f32_32x32x16_f16, with the tensors between
@@ -67,6 +68,15 @@ int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int 
  * (ShareLayer, model_with_TSM.py:199-229; warp.py:134-165).  share = 0 reproduces the tf.cond(share, ...) false branch. */
 int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const float* reg, int B, int H, int W, int frame, int share,
                     float* gs, float* con_rgb, float* mask22, float* dif, void* stream);
+
+/* Range guard of BSR_DTYPE_F32X3 / BSR_DTYPE_F16.  Those modes convert fp32 activations to fp16 operands inside the kernels; a value of
+ * magnitude >= 65520 would become inf (and its lo half NaN) where the fp32 path stays finite.  Every converting kernel checks what
+ * it converts and sets a sticky, host-visible flag on the handle.  bsr_check_range synchronises `stream` (the stream the forwards
+ * ran on), returns BSR_ERR_RANGE if any forward since the last call overflowed — the outputs of those forwards must be discarded
+ * and the inputs re-run on a BSR_DTYPE_F32 handle — and clears the flag.  Without a call the condition is still not silent:
+ * bsr_forward / bsr_forward_tsm refuse with BSR_ERR_RANGE once a completed forward has raised the flag.  Always BSR_OK on a
+ * BSR_DTYPE_F32 handle.  (NaN inputs are not a range error; they propagate to the outputs.) */
+int bsr_check_range(bsr_handle* h, void* stream);
 
 /* Bytes of activation workspace the library holds for a batch of B HxW images (grown lazily by
  * bsr_forward; growth synchronises the stream — call bsr_reserve first to keep forwards allocation-free). */

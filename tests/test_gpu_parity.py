@@ -29,7 +29,7 @@ def test_library_is_the_in_tree_hip_extension():
     from blindshadowremoval_amd import _lib
     from blindshadowremoval_amd.build import LIB_PATH
     lib = _lib.load()
-    assert lib._name == LIB_PATH and lib.bsr_abi_version() == 2
+    assert lib._name == LIB_PATH and lib.bsr_abi_version() == 3
 
 
 @pytest.mark.parametrize("seed,B", [(0, 2), (7, 3)])
@@ -559,3 +559,81 @@ def test_bench_rccl_allgather_world1():
     ag = j["config"]["allgather"]
     assert ag["bytes_per_rank"] == 33554432                 # 32 x 256 x 256 x 4 channels x 4 B
     assert ag["verified"] is True and ag["backend"] == "nccl"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Range guard of the 16-bit modes (include/bsr_hip.h: BSR_ERR_RANGE, bsr_check_range)
+
+_RANGE_PROBES = ("x1", "x2", "x3", "x0", "res0", "res1", "res2", "up1", "up2", "y", "res3", "res4", "res5", "f1", "f2", "f")
+
+
+def _max_activation(gen):
+    return max(float(gen.probe(k).abs().max()) for k in _RANGE_PROBES)
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f16"])
+def test_range_guard_large_activations_and_overflow(dtype):
+    """Inputs scaled until the largest activation of the net sits at ~4e4 (fp16 max 65504): the 16-bit mode must still track the fp32
+    path (1e-3 RELATIVE to the output scale for f32x3) and report no range error.  Scaled 4x further, activations pass 65520: the
+    forward must be REPORTED — check_range() raises RangeError, and so does the next forward until the condition is acknowledged —
+    instead of silently returning inf / NaN.  The fp32 handle never reports."""
+    from blindshadowremoval_amd import Generator
+    from blindshadowremoval_amd._lib import RangeError
+    w = init_weights(1)
+    g32, g16 = Generator(dtype="f32").load_weights(w), Generator(dtype=dtype).load_weights(w)
+    torch.manual_seed(61)
+    inp, uv = torch.rand(2, 256, 256, 3).cuda(), torch.rand(2, 256, 256, 3).cuda()
+    g32(inp, uv)
+    a1 = _max_activation(g32)
+    k = 4.0e4 / a1                                     # first guess; refine once (the net is only piecewise linear)
+    g32(inp * k, uv * k)
+    k *= 4.0e4 / _max_activation(g32)
+    ref = [t.clone() for t in g32(inp * k, uv * k)]
+    amax = _max_activation(g32)
+    assert 2.0e4 < amax < 6.0e4, amax
+    out = g16(inp * k, uv * k)
+    g16.check_range()                                  # in range: no error
+    assert torch.equal(g16.probe("bmask"), g32.probe("bmask"))
+    rel_tol = 1e-3 if dtype == "f32x3" else 4e-3
+    for a, b, name in zip(out, ref, ("gs", "con_rgb", "mask22", "dif")):
+        scale = max(1.0, float(b.abs().max()))
+        err = float((a - b).abs().max()) / scale
+        print("range guard %s %s: max |act| %.3g, rel err %.2e" % (dtype, name, amax, err))
+        assert err <= rel_tol, name
+    # 4x further: overflow
+    big = [t.clone() for t in g32(inp * (4 * k), uv * (4 * k))]
+    assert _max_activation(g32) > 7.0e4 and all(bool(torch.isfinite(t).all()) for t in big)     # the fp32 path stays finite
+    g32.check_range()
+    g16(inp * (4 * k), uv * (4 * k))
+    torch.cuda.synchronize()
+    with pytest.raises(RangeError, match="fp16 range"):
+        g16(inp, uv)                                   # the completed overflowing forward is not silent: the next call refuses
+    with pytest.raises(RangeError):
+        g16.check_range()                              # ... and check_range reports and CLEARS
+    out2 = g16(inp, uv)                                # acknowledged: the handle works again
+    g16.check_range()
+    ref2 = g32(inp, uv)
+    for a, b in zip(out2, ref2):
+        assert float((a - b).abs().max()) <= (1e-3 if dtype == "f32x3" else 4e-3)
+    g32.close()
+    g16.close()
+
+
+def test_f32x3_tiny_operands_bound_the_absolute_error():
+    """Operands below 2^-14 make the lo half of the split an fp16 subnormal (igemm_h16.h): the ERROR is then absolute (<= 2^-25 per
+    operand), not relative.  Inputs of 1e-6: the f32x3 outputs stay within 2e-5 absolute of the fp32 path."""
+    from blindshadowremoval_amd import Generator
+    w = init_weights(1)
+    g32, g16 = Generator(dtype="f32").load_weights(w), Generator(dtype="f32x3").load_weights(w)
+    torch.manual_seed(62)
+    inp, uv = (torch.rand(2, 256, 256, 3) * 1e-6).cuda(), (torch.rand(2, 256, 256, 3) * 1e-6).cuda()
+    ref = [t.clone() for t in g32(inp, uv)]
+    out = g16(inp, uv)
+    g16.check_range()
+    assert torch.equal(g16.probe("bmask"), g32.probe("bmask"))
+    for a, b, name in zip(out, ref, ("gs", "con_rgb", "mask22", "dif")):
+        err = float((a - b).abs().max())
+        print("tiny operands %s abs err %.2e" % (name, err))
+        assert err <= 2e-5, name
+    g32.close()
+    g16.close()
