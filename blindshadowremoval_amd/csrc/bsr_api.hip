@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -147,7 +146,6 @@ struct bsr_handle {
   // Range guard of the 16-bit modes (igemm_h16.h): one word of pinned, device-mapped host memory; a kernel that stages an activation
   // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
   unsigned* range_flag = nullptr;
-  int dephase_pct = 0;           // igemm_conv.h dephase_start: percent of half a workgroup's matrix time (env BSR_DEPHASE, experiment)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
   std::vector<int> ev_class;
@@ -243,7 +241,6 @@ struct Launcher {
     a.pad_l = pad_before(W, KW, S);
     a.act = act;
     a.range_flag = h->range_flag;
-    a.dephase = h->dephase_pct;
     const int mh = TR ? H : a.Ho, mw = TR ? W : a.Wo;
     if (mh % 4 != 0 || mw % 32 != 0) {
       rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': feature map is not a multiple of the 4x32 tile");
@@ -379,7 +376,6 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   bsr_handle* h = new bsr_handle();
   h->device = device;
   h->dtype = dtype;
-  if (const char* e_ = getenv("BSR_DEPHASE")) h->dephase_pct = atoi(e_);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {

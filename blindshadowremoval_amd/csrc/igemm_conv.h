@@ -90,39 +90,17 @@ struct ConvArgs {
   int tiles_x, tiles_y; // M tiles per image
   int n_blocks;         // igemm_h16_kernel: > 0 = 1-D grid with the N block as the FASTEST index (the N blocks of a tile share its input through L2)
   unsigned* range_flag; // 16-bit kernels: set to 1 when a staged activation does not fit fp16 (|x| >= 65520); may be null
-  int dephase;          // > 0: shader cycles the first-round workgroups of the odd wave slot wait before starting (see dephase_start)
-  int first_round;      // workgroups of the first dispatch round (2 per CU)
 #ifdef BSR_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
 #endif
 };
-
-// Multi-round grids of identical workgroups run in LOCKSTEP: the two workgroups that share a CU (one wave each per SIMD) start
-// together, share the matrix pipe through their main loops at 128 cycles per MFMA, reach their epilogues together and are replaced
-// together — so in every round the pipe idles for a whole prologue + epilogue (PMC, round 3: SQ_VALU_MFMA_BUSY_CYCLES = 79 % of
-// the GPU-active cycles on the dominant kernel although its main loop shares the pipe perfectly).  Shifting ONE of the two
-// residents by half a workgroup's life at kernel start puts one's prologue / epilogue under the other's main loop for all later
-// rounds (a slot's next workgroup starts when the previous one ends, so the offset persists).  The shifted set = first-round
-// workgroups whose waves sit in an odd hardware wave slot (HW_REG_HW_ID.wave_id: the first resident of a SIMD gets slot 0, the
-// second slot 1); correctness does not depend on that placement — a wave that sleeps is only late.
-__device__ __forceinline__ void dephase_start(const int dephase, const int first_round) {
-  if (dephase > 0) {
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if (lin < (unsigned)first_round) {
-      const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID (4), bits [3:0] = wave_id
-      if (wave_slot & 1u) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)dephase) __builtin_amdgcn_s_sleep(16);
-      }
-    }
-  }
-}
 
 // INB = number of LDS input-tile buffers: 1 (reload synchronously at chunk boundaries), 2 (taps > 1: next chunk's
 // tile is staged one tap ahead) or 3 (1x1 convs: ring, like the weights).
 template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
 struct ConvCfg {
   static constexpr int T = KH * KW;
+  static constexpr int NT = WM * WN * 64;                        // threads per workgroup: 4 waves, or 8 (two waves per SIMD from ONE workgroup)
   static constexpr int IH = TR ? TH + 1 : (TH - 1) * S + KH;
   static constexpr int IW = TR ? TW + 1 : (TW - 1) * S + KW;
   static constexpr int LDP = CC + 4;
@@ -139,10 +117,10 @@ struct ConvCfg {
   static constexpr int W_FLOATS = BN * LDP;
   static constexpr int SMEM_BYTES = (INB * IN_FLOATS + 3 * W_FLOATS) * 4;
   static constexpr int IN_V4 = IH * IW * (CC / 4);               // float4 loads per input-tile chunk
-  static constexpr int IN_PER_THREAD = (IN_V4 + 255) / 256;
+  static constexpr int IN_PER_THREAD = (IN_V4 + NT - 1) / NT;
   static constexpr int W_V4 = W_FLOATS / 4;
-  static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static constexpr int W_PER_THREAD = (W_V4 + NT - 1) / NT;
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   static_assert(BM == TH * TW, "M tile must equal the spatial tile");
   static_assert(CC % 8 == 0, "channel chunk must be a multiple of the 8-wide K group");
   static_assert(!TR || (KH == 3 && KW == 3 && S == 1), "transposed path is ConvT(3, stride 2)");
@@ -151,9 +129,10 @@ struct ConvCfg {
 };
 
 template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
-__global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
   constexpr bool PAIR = C::PAIR;
+  constexpr int NT = C::NT;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH, G = C::G;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
@@ -162,7 +141,9 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   // Prologue and epilogue are VALU/VMEM streams that share the SIMD with a co-resident wave's MFMA stream; at
   // equal priority they get an issue slot only every few dozen cycles (measured: a 128-store epilogue took 41k
   // cycles).  They run at raised priority; the MFMA main loop runs at priority 0.
-  dephase_start(p.dephase, p.first_round);
+#ifdef BSR_STAMPS
+  const unsigned long long stA = __builtin_amdgcn_s_memtime(), rtA = __builtin_amdgcn_s_memrealtime();      // kernel entry (st0 below: after the address setup)
+#endif
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -216,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   unsigned in_okmask = 0u;
 #pragma unroll
   for (int i = 0; i < C::IN_PER_THREAD; ++i) {
-    const int idx0 = tid + i * 256;
+    const int idx0 = tid + i * NT;
     const int idx = idx0 < C::IN_V4 ? idx0 : C::IN_V4 - 1;
     const int pix = idx / (CC / 4), q = idx % (CC / 4);
     const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
@@ -228,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < C::W_PER_THREAD; ++i) {
-    const int idx0 = tid + i * 256;
+    const int idx0 = tid + i * NT;
     w_off[i] = (unsigned)((idx0 < C::W_V4 ? idx0 : C::W_V4 - 1) * 16);
   }
   auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
@@ -255,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
     char* dst = reinterpret_cast<char*>(s_w + off);
 #pragma unroll
     for (int i = 0; i < C::W_PER_THREAD; ++i) {
-      if (tid + i * 256 < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
+      if (tid + i * NT < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
     }
   };
 
@@ -440,9 +421,9 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(ConvArgs p) {
     __builtin_amdgcn_s_waitcnt(0);
     unsigned long long st3 = __builtin_amdgcn_s_memtime();
 
-    unsigned long long* d = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+    unsigned long long* d = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WM * WN) + wave) * 4;
     unsigned long long rt3 = __builtin_amdgcn_s_memrealtime();
-    d[0] = st1 - st0; d[1] = st2 - st1; d[2] = ((rt3 - rt0) << 32) | (st2b - st2); d[3] = st3 - st2;
+    d[0] = st1 - stA; d[1] = st2 - st1; d[2] = ((rt3 - rtA) << 32) | (st2b - st2); d[3] = st3 - st2; (void)st0; (void)rt0;
   }
 #endif
 }
@@ -462,15 +443,7 @@ inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream) {
   a.tiles_x = mw / TW;
   a.tiles_y = mh / TH;
   dim3 grid(a.tiles_x * a.tiles_y * batch, (a.n_store + C::BN - 1) / C::BN);
-  {   // dephase (see dephase_start): a.dephase arrives as a PERCENTAGE of half a workgroup's matrix time; only grids of >= 4 rounds
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev >= 0 ? dev : 0);
-    a.first_round = 2 * cus;
-    const long long total = (long long)grid.x * grid.y;
-    const long long mfma_per_wave = (long long)a.nchunk * C::T * C::G * 4 * MI * NI;
-    a.dephase = (a.dephase > 0 && total >= 4LL * a.first_round) ? (int)(mfma_per_wave * 64 * a.dephase / 100) : 0;
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }
 

@@ -12,9 +12,10 @@ using namespace bsr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 static int g_mode = 0;
-template <int KH, int KW, int S, bool TR, int NI, int CC, int INB>
+template <int KH, int KW, int S, bool TR, int NI, int CC, int INB, int WN = 1>
 int run(const char* name, int B, int H, int W, int Cin, int Cout) {
-  using C = ConvCfg<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>;
+  using C = ConvCfg<KH, KW, S, TR, 4, 32, 4, WN, 1, NI, CC, INB>;
+  constexpr int NW = 4 * WN;
   const int T = KH * KW, nchunk = Cin / CC, n_pad = ((Cout + C::BN - 1) / C::BN) * C::BN;
   const int Ho = TR ? 2 * H : H / S, Wo = TR ? 2 * W : W / S;
   size_t n_in = (size_t)B * H * W * Cin, n_out = (size_t)B * Ho * Wo * Cout, n_w = (size_t)nchunk * T * n_pad * (CC + 4);
@@ -31,23 +32,33 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   const int mh = TR ? H : Ho, mw = TR ? W : Wo;
   size_t nblk = (size_t)(mw / 32) * (mh / 4) * B * (n_pad / C::BN);
   unsigned long long* d_st;
-  CK(hipMalloc(&d_st, nblk * 16 * 8));
+  CK(hipMalloc(&d_st, nblk * NW * 4 * 8));
   a.stamps = d_st;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e9;
-  for (int it = 0; it < 6; ++it) {
+  const int iters = getenv("BSR_ITERS") ? atoi(getenv("BSR_ITERS")) : 6;      // many back-to-back launches = the sustained clock
+  for (int it = 0; it < iters; ++it) {
     CK(hipEventRecord(e0));
-    CK((launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, B, 0)));
+    if (getenv("BSR_SOLO")) {          // one workgroup per CU (LDS request > half the CU's): a wave's matrix rate WITHOUT a SIMD partner
+      auto kern = igemm_conv_kernel<KH, KW, S, TR, 4, 32, 4, WN, 1, NI, CC, INB>;
+      const int smem = 100 * 1024;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      ConvArgs b = a;
+      b.tiles_x = mw / 32; b.tiles_y = mh / 4;
+      hipLaunchKernelGGL(kern, dim3(b.tiles_x * b.tiles_y * B, (Cout + C::BN - 1) / C::BN), dim3(C::NT), smem, 0, b);
+      CK(hipGetLastError());
+    } else
+    CK((launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, WN, 1, NI, CC, INB>(a, B, 0)));
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it > 0) best = std::min(best, ms);
   }
-  std::vector<unsigned long long> st(nblk * 16);
-  CK(hipMemcpy(st.data(), d_st, nblk * 16 * 8, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> st(nblk * NW * 4);
+  CK(hipMemcpy(st.data(), d_st, nblk * NW * 4 * 8, hipMemcpyDeviceToHost));
   double pro = 0, loop = 0, epi = 0, epi_issue = 0;
   double rt = 0;
-  for (size_t i = 0; i < nblk * 4; ++i) { pro += st[i * 4]; loop += st[i * 4 + 1]; epi_issue += (st[i * 4 + 2] & 0xffffffffull); rt += (double)(st[i * 4 + 2] >> 32); epi += st[i * 4 + 3]; }
-  printf("   wave lifetime %.0f cycles = %.0f ticks of the 100 MHz realtime counter -> shader clock %.2f GHz\n", (pro + loop + epi) / (nblk * 4.0), rt / (nblk * 4.0), (pro + loop + epi) / rt * 0.1);
-  double nw = nblk * 4.0;
+  for (size_t i = 0; i < nblk * NW; ++i) { pro += st[i * 4]; loop += st[i * 4 + 1]; epi_issue += (st[i * 4 + 2] & 0xffffffffull); rt += (double)(st[i * 4 + 2] >> 32); epi += st[i * 4 + 3]; }
+  printf("   wave lifetime %.0f cycles = %.0f ticks of the 100 MHz realtime counter -> shader clock %.2f GHz\n", (pro + loop + epi) / (nblk * (double)NW), rt / (nblk * (double)NW), (pro + loop + epi) / rt * 0.1);
+  double nw = nblk * (double)NW;
   double flops = 2.0 * B * (TR ? H * W : Ho * Wo) * (double)T * Cin * Cout;
   double mfma_per_wave = (double)nchunk * T * (CC / 2) * NI;       // MFMAs a wave issues
   printf("%-10s %7.1f us  %6.1f TFLOP/s | blocks %zu, per wave (cycles): prologue %.0f  loop %.0f  epilogue %.0f (issue %.0f) | loop ticks per MFMA %.2f\n",
@@ -128,6 +139,16 @@ int run_gemm(const char* name, int pixels, int N, int nsplit, bool res) {
 
 int main(int argc, char** argv) {
   if (argc > 1) g_mode = atoi(argv[1]);
+  if (argc > 2 && argv[2][0] == 'u') {            // clock cross-check (round 3): the dominant instantiation at two dispatch lengths
+    if (run<3, 3, 1, true, 2, 32, 1>("up3 B=32", 32, 128, 128, 128, 64)) return 1;
+    if (run<3, 3, 1, true, 1, 32, 1, 2>("up3 8w", 32, 128, 128, 128, 64)) return 1;          // 8 waves: WN = 2, NI = 1 per wave
+    if (run<3, 3, 1, false, 2, 32, 1>("conv2", 32, 32, 32, 128, 128)) return 1;
+    if (run<3, 3, 1, false, 1, 32, 1, 2>("conv2 8w", 32, 32, 32, 128, 128)) return 1;
+    if (run<3, 3, 1, false, 2, 32, 1, 2>("conv2 8w ni2", 32, 32, 32, 128, 128)) return 1;
+    if (run<3, 3, 2, false, 2, 16, 1>("down1", 32, 256, 256, 32, 64)) return 1;
+    if (run<3, 3, 2, false, 1, 16, 1, 2>("down1 8w", 32, 256, 256, 32, 64)) return 1;
+    return 0;
+  }
   if (argc > 2 && argv[2][0] == 's') {            // the stride-2 encoder convs
     if (run<3, 3, 2, false, 2, 16, 1>("down1", 32, 256, 256, 32, 64)) return 1;
     if (run<3, 3, 2, false, 2, 32, 1>("down1/cc32", 32, 256, 256, 32, 64)) return 1;
