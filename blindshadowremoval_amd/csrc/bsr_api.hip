@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -146,6 +147,7 @@ struct bsr_handle {
   // Range guard of the 16-bit modes (igemm_h16.h): one word of pinned, device-mapped host memory; a kernel that stages an activation
   // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
   unsigned* range_flag = nullptr;
+  bool fuse_heads = true;        // env BSR_FUSE_HEADS=0: always the two-launch heads (A/B measurements, bit-identity tests)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
   std::vector<int> ev_class;
@@ -287,6 +289,41 @@ struct Launcher {
     end();
   }
 
+  void heads(const float* y, int H, int W, float* qh, const float* inputs, float* gs, float* mask22, size_t npix) {
+    if (rc != BSR_OK) return;
+    LayerW l;
+    rc = find_layer(h, "heads", 2, 7, 36, 16, &l);
+    if (rc != BSR_OK) return;
+    if (l.n_pad != 16) { rc = fail(BSR_ERR_BLOB, "layer 'heads' must be packed with n_pad 16"); return; }
+    if (H % 8 != 0 || W % 32 != 0) { rc = fail(BSR_ERR_ARG, "layer 'heads': image is not a multiple of its tile"); return; }
+    bsr::ConvN16Args a{};
+    a.in = y; a.in_cs = 64; a.H = H; a.W = W; a.w = l.w; a.bias = l.b; a.out = qh; a.out_cs = 16; a.act = 0;
+    a.pad_t = 3; a.pad_l = 0;
+    a.inputs = inputs; a.gs_out = gs; a.mask22 = mask22; a.b_mask = h->head_bias[0]; a.b_con = h->head_bias[1];
+    a.range_flag = h->range_flag;
+    const int dt = h->dtype;
+    int resident = 0;
+    check(bsr::launch_conv_n16<7, 1, false, false, 2, 0, false, true>(a, h->B, s, &resident), "heads");      // query: resident workgroup slots
+    const bool fuse = rc == BSR_OK && h->fuse_heads && bsr::conv_n16_fuse_pays(h->B, H, 8, resident);
+    begin(K_CONV7, "heads");
+    if (fuse) {
+      if (dt == BSR_DTYPE_F32) check(bsr::launch_conv_n16<7, 1, false, false, 2, 0, false, true>(a, h->B, s), "heads");
+      else if (dt == BSR_DTYPE_F16) check(bsr::launch_conv_n16<7, 1, false, false, 2, 2, true, true>(a, h->B, s), "heads");
+      else check(bsr::launch_conv_n16<7, 1, false, false, 2, 2, false, true>(a, h->B, s), "heads");
+      end();
+      return;
+    }
+    if (dt == BSR_DTYPE_F32) check(bsr::launch_conv_n16<7, 1, false, false, 2, 0>(a, h->B, s), "heads");
+    else if (dt == BSR_DTYPE_F16) check(bsr::launch_conv_n16<7, 1, false, false, 2, 2, true>(a, h->B, s), "heads");
+    else check(bsr::launch_conv_n16<7, 1, false, false, 2, 2>(a, h->B, s), "heads");
+    end();
+    begin(K_GLUE, "heads_post");
+    hipLaunchKernelGGL(bsr::heads_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, qh, inputs, h->head_bias[0], h->head_bias[1], gs,
+                       mask22, W, npix);
+    check(hipGetLastError(), "heads_post");
+    end();
+  }
+
   template <int KH, int KW, bool GS, bool TAIL, int RW>
   void conv16(int cls, const char* name, const float* in, int in_cs, int H, int W, float* out, int out_cs, int act, const float* gs,
               const float* inputs, float* con_rgb, float* dif) {
@@ -376,6 +413,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   bsr_handle* h = new bsr_handle();
   h->device = device;
   h->dtype = dtype;
+  if (const char* e_ = getenv("BSR_FUSE_HEADS")) h->fuse_heads = atoi(e_) != 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -627,12 +665,10 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   L.conv<3, 3, 1, true, 1, 24, 1>(K_CONVT, "up1", ws + p.r[2], V.cs_r, 0, V.cs_r, H8, W8, ws + p.c2, 160, 0, 96, 1, io_out);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up2", ws + p.c2, 160, 0, 160, H4, W4, ws + p.c3, 128, 0, 64, 1, io_both);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "up3", ws + p.c3, 128, 0, 128, H2, W2, ws + p.ybuf, 64, 0, 64, 1, io_both);
-  // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head)
-  L.conv16<7, 1, false, false, 2>(K_CONV7, "heads", ws + p.ybuf, 64, H, W, ws + p.qh, 16, 0, nullptr, nullptr, nullptr, nullptr);
-  glue_begin("heads_post");
-  hipLaunchKernelGGL(bsr::heads_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, ws + p.qh, inputs, h->head_bias[0],
-                     h->head_bias[1], gs, mask22, W, npix);
-  glue_end("heads_post");
+  // heads conv2 (mask) / conv3 (con): 7x7, 64 -> 1 each (model.py:246-247) as one 7x1 MFMA conv with N = (kx, head); the 7 horizontal
+  // taps + tanh / gs / mask22 (model.py:246-252) either inside the same kernel (row-strip workgroups, when the batch has enough
+  // strips to fill the chip) or by heads_post_kernel from the qh scratch tensor — bit-identical results either way
+  L.heads(ws + p.ybuf, H, W, ws + p.qh, inputs, gs, mask22, npix);
   // bmask / x_hole (model.py:256-259)
   glue_begin("bmask_xhole");
   hipLaunchKernelGGL(bsr::bmask_xhole_kernel, dim3((unsigned)ncell), dim3(64), 0, s, gs, inputs, H, W, ws + p.r[2], V.cs_r, V.c_r, ws + p.xh,

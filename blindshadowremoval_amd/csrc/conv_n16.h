@@ -1,7 +1,11 @@
 // 16-output-channel convolutions on v_mfma_f32_16x16x4_f32 — the two thin, full-resolution layers of the
 // generator, where a 32-wide MFMA tile would waste half (or more) of the matrix core:
 //   * heads  = conv2 | conv3, 7x7, 64 -> 1 each (/root/reference/model.py:204-205,246-247), run as a 7x1 conv
-//     with N = (kx, head) = 14 (-> 16); the 7 horizontal taps are summed by heads_post_kernel;
+//     with N = (kx, head) = 14 (-> 16); the 7 horizontal taps are summed, and tanh / gs / mask22 (model.py:246-252) applied, either by
+//     heads_post_kernel from a [B,H,W,16] scratch tensor or — FUSE, round 3 — by this kernel itself: a persistent workgroup then
+//     walks a whole ROW STRIP of tiles left to right, parks the tile's 14 partial planes in LDS (over the input tile it has
+//     finished with), and each output pixel adds its 7 taps in heads_post_kernel's order, the 6 pixels that straddle a tile
+//     boundary carrying their partial sums to the next tile — same bits, no 134 MB write + 171 MB re-read + second launch;
 //   * clr_conv1 = Conv(16, 3x3) over cat[gs, f] (model.py:217,267), optionally fused with clr_conv2 (1x1 16->16
 //     + BN + LeakyReLU), clr_conv3 (1x1 16->3) and dif = gray(con_rgb) - gray(inputs) (model.py:268-269,288).
 //
@@ -35,12 +39,15 @@ struct ConvN16Args {
   float* dif;           // TAIL: [B,H,W,1]
   int tiles_x, tiles_y, batch;   // filled by the launcher
   unsigned* range_flag; // H = 2: set when a staged activation does not fit fp16 (igemm_h16.h); may be null
+  float* gs_out;        // FUSE: [B,H,W,1] gs = gray(inputs) * (1 + mask) + con   (inputs = the `inputs` field)
+  float* mask22;        // FUSE: [B,H,W,3] = [relu(mask), 0, relu(-mask)]
+  float b_mask, b_con;  // FUSE: conv2 / conv3 biases
 #ifdef BSR_STAMPS
   unsigned long long* stamps;
 #endif
 };
 
-template <int KH, int KW, bool GS, bool TAIL, int RW>   // RW = tile rows per wave (MFMA work per staged byte)
+template <int KH, int KW, bool GS, bool TAIL, int RW, bool FUSE = false>   // RW = tile rows per wave (MFMA work per staged byte)
 struct ConvN16Cfg {
   static constexpr int T = KH * KW, TH = 4 * RW, TW = 32, MT = 2 * RW, CC = 32, LDP = 36, G = 2;
   static constexpr int IH = TH + KH - 1, IW = TW + KW - 1;
@@ -48,12 +55,31 @@ struct ConvN16Cfg {
   static constexpr int W_FLOATS = T * 16 * LDP;
   static constexpr int GS_FLOATS = GS ? (TH + 2) * (TW + 2) + 2 : 0;
   static constexpr int TAIL_FLOATS = TAIL ? 352 + TH * TW * 3 : 0;   // for the variant that keeps them in LDS: the fused tail's weights (337 floats) + the tile's input pixels
-  static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS + GS_FLOATS + TAIL_FLOATS) * 4;
+  static constexpr int QLD = 20;                                     // FUSE: floats per pixel of the parked partial planes (16 + 4: conflict-free 16-byte stores)
+  static constexpr int CARRY_FLOATS = FUSE ? 2 * TH * 6 * 2 : 0;     // FUSE: partial sums of the 6 boundary pixels x 2 heads, double-buffered by tile parity
+  static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS + GS_FLOATS + TAIL_FLOATS + CARRY_FLOATS) * 4;
+  static_assert(!FUSE || (KH == 7 && KW == 1 && !GS && !TAIL), "FUSE is the heads epilogue");
+  static_assert(!FUSE || TH * TW * QLD <= IN_FLOATS, "the parked planes reuse the input tile's LDS");
+  static_assert(!FUSE || TH * TW == 256, "FUSE: one output pixel per thread");
   static constexpr int IN_V4 = IH * IW * (CC / 4);
   static constexpr int IN_PER_THREAD = IH + 1;                   // one float4 per tile row + one halo-column load
   static constexpr int W_V4 = W_FLOATS / 4;
   static constexpr int W_PER_THREAD = (W_V4 + 255) / 256;
 };
+
+// FUSE: one pixel of the heads' outputs from its two 7-tap sums — the arithmetic of heads_post_kernel (glue_kernels.h), same
+// operation order, fp contraction off (gs feeds the hard 0.1 threshold of model.py:256).
+__device__ __forceinline__ void heads_emit(const ConvN16Args& p, size_t pix, float m, float cn, const float (&in3)[3]) {
+#pragma clang fp contract(off)
+  const float mask = tanhf(m + p.b_mask);
+  const float con = cn + p.b_con;
+  const float g0 = (in3[0] * 0.2989f + in3[1] * 0.5870f) + in3[2] * 0.1140f;      // tf.image.rgb_to_grayscale (model.py:250)
+  const float g = g0 * (1.f + mask) + con;
+  p.gs_out[pix] = g;
+  p.mask22[pix * 3 + 0] = fmaxf(mask, 0.f);
+  p.mask22[pix * 3 + 1] = mask * 0.f;
+  p.mask22[pix * 3 + 2] = fmaxf(-mask, 0.f);
+}
 
 // H = 0: fp32 matrix cores (v_mfma_f32_16x16x4_f32).  H = 2: split precision on v_mfma_f32_16x16x32_f16 (igemm_h16.h): the
 // LDS row of a pixel / output channel keeps its 36 words but holds [32 hi halves | 32 lo halves | pad]; activations are split
@@ -62,16 +88,18 @@ struct ConvN16Cfg {
 // k = 8q .. 8q+7 of A and B; C/D is the fp32 instruction's layout, so the gs K group and the fused 1x1 tail stay as they are.
 // IN16 (with H = 2, the f16 mode): p.in is an fp16 tensor (in_cs counts halves).  Its values ARE the hi plane — the lo plane and the
 // weight-hi x input-lo instruction disappear: 2 instead of 3 matrix instructions per tap, 8-byte loads instead of 16.
-template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0, bool IN16 = false>
+template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0, bool IN16 = false, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   static_assert(!IN16 || H == 2, "fp16 input belongs to the 16-bit kernel");
-  using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
+  using C = ConvN16Cfg<KH, KW, GS, TAIL, RW, FUSE>;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, TW = C::TW, TH = C::TH, MT = C::MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
   float* s_w = smem + C::IN_FLOATS;
   float* s_gs = s_w + C::W_FLOATS;
   float* s_tail = s_gs + C::GS_FLOATS;
+  float* s_carry = s_tail + C::TAIL_FLOATS;      // FUSE
+  float* s_q = s_in;                             // FUSE: [TH][TW][QLD], valid between the tile's MFMA loop and the next tile's staging
   // The split-precision variant needs ~290 VGPRs with the fused tail's 15 per-lane weights held across the tile loop and spilled them
   // (reloaded per tile from scratch: +45 % HBM traffic); it reads them from a 1.4-KB LDS copy at each epilogue instead.
   constexpr bool TAIL_LDS = TAIL && H == 2 && !IN16;
@@ -97,6 +125,13 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
     d.y0 = (t % p.tiles_y) * TH;
     d.img = t / p.tiles_y;
     return d;
+  };
+  // Work sequence of this workgroup.  Plain: tiles blockIdx.x, + gridDim.x, ...  FUSE: whole row strips (tiles_x consecutive tile
+  // indices, x fastest) blockIdx.x, + gridDim.x, ..., each walked left to right, because a tile hands its right-hand boundary sums
+  // to its right neighbour through LDS.
+  auto seq = [&](int k) -> int {        // k-th tile of this workgroup, or >= ntiles when there is none
+    if constexpr (FUSE) return (blockIdx.x + (k / p.tiles_x) * (int)gridDim.x) * p.tiles_x + k % p.tiles_x;
+    else return blockIdx.x + k * (int)gridDim.x;
   };
 
   // Input-tile staging with NO per-load vector arithmetic (it would run beside the co-resident workgroup's MFMA stream, where
@@ -210,7 +245,8 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   };
 
   // ---- prologue: first tile's chunk 0 ----
-  int tile = blockIdx.x;
+  int kseq = 0;
+  int tile = seq(0);
   Tile cur = decode(tile);
   f32x4 in_regs[C::IN_PER_THREAD];
   f32x4 w_regs[C::W_PER_THREAD];
@@ -251,9 +287,27 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
   for (int mt = 0; mt < MT; ++mt) x_base[mt] = ((wave * RW + mt / 2) * IW + (mt % 2) * 16 + r) * LDP + 4 * q;
   const int w_base = r * LDP + 4 * q;
 
-  for (; tile < ntiles; tile += gridDim.x) {
-    const bool has_next = tile + (int)gridDim.x < ntiles;
-    const Tile nxt = decode(has_next ? tile + (int)gridDim.x : tile);
+  for (; tile < ntiles; tile = seq(++kseq)) {
+    const int tile_n = seq(kseq + 1);
+    const bool has_next = tile_n < ntiles;
+    const Tile nxt = decode(has_next ? tile_n : tile);
+    // FUSE: the input pixels of this thread's output pixel (row tid >> 5, column x0 - 3 + (tid & 31)) for gs = gray(inputs) * (1 + mask) + con,
+    // requested now, used after the MFMA loops; at the strip's last tile threads 0..2 of a row also finish columns W-3 .. W-1
+    float fin[3] = {0.f, 0.f, 0.f}, fin_e[3] = {0.f, 0.f, 0.f};
+    if constexpr (FUSE) {
+      const int frow = tid >> 5, fj = tid & 31;
+      const int fx = cur.x0 - 3 + fj;
+      const size_t rowpix = ((size_t)cur.img * p.H + cur.y0 + frow) * p.W;
+      if (fx >= 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fin[c] = p.inputs[(rowpix + fx) * 3 + c];
+      }
+      if (cur.x0 + TW == p.W && fj < 3) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fin_e[c] = p.inputs[(rowpix + p.W - 3 + fj) * 3 + c];
+      }
+      if (cur.x0 == 0 && tid < C::TH * 12) s_carry[tid] = 0.f;      // strip start: nothing to the left (parity-0 buffer; read after two barriers)
+    }
     float tin[MT][3];
     float tin_st[3] = {0.f, 0.f, 0.f};
     if constexpr (TAIL_LDS) {   // the same pixels through LDS (3 registers instead of 12 across the MFMA loops): row-contiguous loads now, ds_write at the chunk-0 barrier
@@ -356,6 +410,65 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
           }
         }
       }
+      if constexpr (FUSE) {
+        if (ch == 1) {
+          // ---- fused heads epilogue.  q[row][col][kx*2 + head] (this tile's 7x1 partial planes) -> LDS over the input tile ----
+          __syncthreads();                                   // every wave has finished reading the input tile
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc[mt] + b4;
+            *reinterpret_cast<f32x4*>(s_q + ((wave * RW + mt / 2) * TW + (mt % 2) * 16 + r) * C::QLD + 4 * q) = v;
+          }
+          __syncthreads();
+          {
+            // thread = output pixel (row frow, image column x0 - 3 + fj): out[x] = sum_kx q[x + kx - 3][kx], kx ascending as in
+            // heads_post_kernel; columns left of this tile were summed by the previous tile (carry), columns right of it go to the next
+            const int frow = tid >> 5, fj = tid & 31;
+            const int par = (cur.x0 / TW) & 1;
+            const float* cin = s_carry + par * (TH * 12) + frow * 12;
+            float* cout = s_carry + (par ^ 1) * (TH * 12) + frow * 12;
+            float m = 0.f, cn = 0.f;
+            if (fj < 6) { m = cin[fj * 2]; cn = cin[fj * 2 + 1]; }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+              const int c = fj + kx - 6;
+              if (c >= 0) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(s_q + (frow * TW + c) * C::QLD + 2 * kx);
+                m += v[0];
+                cn += v[1];
+              }
+            }
+            const size_t rowpix = ((size_t)cur.img * p.H + cur.y0 + frow) * p.W;
+            const int fx = cur.x0 - 3 + fj;
+            if (fx >= 0) heads_emit(p, rowpix + fx, m, cn, fin);
+            if (fj < 6) {                                    // pixels x0 + 29 + fj: the taps that lie in this tile
+              float cm = 0.f, ccn = 0.f;
+#pragma unroll
+              for (int kx = 0; kx < 6; ++kx) {
+                if (kx <= 5 - fj) {
+                  const f32x2 v = *reinterpret_cast<const f32x2*>(s_q + (frow * TW + 26 + fj + kx) * C::QLD + 2 * kx);
+                  cm += v[0];
+                  ccn += v[1];
+                }
+              }
+              cout[fj * 2] = cm;
+              cout[fj * 2 + 1] = ccn;
+              if (cur.x0 + TW == p.W && fj < 3) heads_emit(p, rowpix + p.W - 3 + fj, cm, ccn, fin_e);      // right image edge: nothing follows
+            }
+          }
+          if (has_next) {
+            __syncthreads();                                 // the parked planes have been read: the next tile may overwrite them
+            store_in(in_regs);
+            store_w(w_regs);
+            __syncthreads();
+          }
+        } else {
+          __syncthreads();
+          store_in(in_regs);
+          store_w(w_regs);
+          __syncthreads();
+        }
+      } else
       if (ch == 0 || has_next) {
         __syncthreads();
         store_in(in_regs);
@@ -370,6 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
         __syncthreads();
       }
     }
+    if constexpr (FUSE) { cur = nxt; continue; }
 
 #ifdef BSR_STAMPS
     const unsigned long long se0 = __builtin_amdgcn_s_memtime();
@@ -446,10 +560,13 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
 #endif
 }
 
-template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0, bool IN16 = false>
-inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream) {
-  using C = ConvN16Cfg<KH, KW, GS, TAIL, RW>;
-  auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW, H, IN16>;
+// FUSE grids are one workgroup per row strip (at most `resident`): conv_n16_fuse_pays() tells the caller when that fills the chip.
+inline bool conv_n16_fuse_pays(int batch, int H, int TH, int resident) { return (long long)batch * (H / TH) >= resident; }
+
+template <int KH, int KW, bool GS, bool TAIL, int RW, int H = 0, bool IN16 = false, bool FUSE = false>
+inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream, int* resident_out = nullptr) {
+  using C = ConvN16Cfg<KH, KW, GS, TAIL, RW, FUSE>;
+  auto kern = conv_n16_kernel<KH, KW, GS, TAIL, RW, H, IN16, FUSE>;
   static PerDeviceOnce once;               // .value = workgroups the device holds at once (2 per CU: LDS-bound)
   const int dev = PerDeviceOnce::current();
   int resident = dev >= 0 && once.done[dev] ? once.value[dev] : 0;
@@ -465,11 +582,13 @@ inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream) 
     resident = 2 * cus;
     if (dev >= 0) { once.value[dev] = resident; once.done[dev] = true; }
   }
+  if (resident_out != nullptr) { *resident_out = resident; return hipSuccess; }      // query only
   a.tiles_x = a.W / C::TW;
   a.tiles_y = a.H / C::TH;
   a.batch = batch;
   const int ntiles = a.tiles_x * a.tiles_y * batch;
-  hipLaunchKernelGGL(kern, dim3(ntiles < resident ? ntiles : resident), dim3(256), C::SMEM_BYTES, stream, a);
+  const int nunits = FUSE ? a.tiles_y * batch : ntiles;        // FUSE: a workgroup's unit of work is a row strip
+  hipLaunchKernelGGL(kern, dim3(nunits < resident ? nunits : resident), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }
 
