@@ -1,6 +1,8 @@
-"""Worker process of the test-time loader (dataset.Dataset(workers=N)): reads pickled jobs from stdin, writes pickled dataset
-elements to stdout, both length-prefixed.  Started as `python -m blindshadowremoval_amd._row_worker`, so it never depends on the
-parent's __main__ module and never imports torch or touches a GPU (numpy / PIL / matplotlib.tri only)."""
+"""Worker process of the test-time loader (dataset.Dataset(workers=N)) and of the UCB post-processing pool
+(FSRNet.test(post_workers=N)): reads pickled jobs from stdin, writes pickled results to stdout, both length-prefixed.  Started as
+`python -m blindshadowremoval_amd._row_worker`, so it never depends on the parent's __main__ module.  Loader jobs need numpy / PIL /
+matplotlib.tri only; a ("ucb_post", ...) job imports torch for its CPU resize / SSIM — the worker never touches a GPU (the pool
+starts it with no visible device)."""
 import os
 import pickle
 import struct
@@ -28,7 +30,12 @@ def main() -> int:
             return 0
         job = pickle.loads(_read_exact(fin, struct.unpack("<Q", head)[0]))
         try:
-            payload = pickle.dumps(("ok", build_element(job)), protocol=pickle.HIGHEST_PROTOCOL)
+            if isinstance(job, tuple) and job and job[0] == "ucb_post":
+                from blindshadowremoval_amd.ucb_post import run_post_job
+                result = run_post_job(job[1])
+            else:
+                result = build_element(job)
+            payload = pickle.dumps(("ok", result), protocol=pickle.HIGHEST_PROTOCOL)
         except Exception as e:          # reported to the parent, which re-raises
             payload = pickle.dumps(("err", "%s: %s" % (type(e).__name__, e)), protocol=pickle.HIGHEST_PROTOCOL)
         fout.write(struct.pack("<Q", len(payload)))

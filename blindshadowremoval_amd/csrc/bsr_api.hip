@@ -20,6 +20,7 @@
 #include "glue_kernels.h"
 #include "igemm_conv.h"
 #include "igemm_h16.h"
+#include "prep_kernels.h"
 #include "stem7.h"
 
 namespace {
@@ -699,6 +700,21 @@ int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const f
                     float* gs, float* con_rgb, float* mask22, float* dif, void* stream) {
   if (reg == nullptr) return fail(BSR_ERR_ARG, "bsr_forward_tsm: null reg");
   return forward_impl(h, inputs, uv, reg, frame, share != 0, B, H, W, gs, con_rgb, mask22, dif, stream);
+}
+
+int bsr_prep_rows(const void* d_blob, size_t rows_off, size_t grid_off, int B, int S, float* out, float* hull_tmp, void* stream) {
+  if (d_blob == nullptr || out == nullptr || hull_tmp == nullptr) return fail(BSR_ERR_ARG, "bsr_prep_rows: null argument");
+  if (B <= 0 || S <= 0 || (S * S) % 256 != 0) return fail(BSR_ERR_ARG, "bsr_prep_rows: B must be positive and S*S a multiple of 256");
+  if (rows_off % 8 != 0 || grid_off % 8 != 0) return fail(BSR_ERR_ARG, "bsr_prep_rows: table offsets must be 8-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned char* blob = static_cast<const unsigned char*>(d_blob);
+  const dim3 grid((unsigned)(S * S / 256), (unsigned)B);
+  hipLaunchKernelGGL(bsr::prep_rows_kernel, grid, dim3(256), 0, s, blob, reinterpret_cast<const bsr::PrepRow*>(blob + rows_off),
+                     reinterpret_cast<const double*>(blob + grid_off), S, out, hull_tmp);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(bsr::prep_blur_kernel, grid, dim3(256), 0, s, hull_tmp, S, out);
+  HIP_TRY(hipGetLastError());
+  return BSR_OK;
 }
 
 int bsr_debug_attention_dtype(const float* qkv, float* y, int B, int tokens, int dtype, void* stream) {

@@ -1,0 +1,141 @@
+// Input preparation on the device: the per-sample numpy / matplotlib work of the reference's test loaders
+// (/root/reference/dataset.py:619-638 `parse_fn_test_FFHQ`, :148-170 `parse_fn_test`; helpers /root/reference/utils.py:356-433
+// `face_crop_and_resize`, :255-276 `generate_face_region`; /root/reference/warp.py:194-232 `generate_offset_map`, `generate_uv_map`)
+// for a whole batch of rows at once.  The host keeps what is tiny and irregular — PNG decode, the crop box, the three Delaunay
+// triangulations of <= 101 points (qhull via matplotlib.tri, exactly the reference's call) and their plane coefficients
+// (`Triangulation.calculate_plane_coefficients`, what LinearTriInterpolator evaluates) — and ships it as ONE blob; the 65 536-point
+// evaluations (seven interpolated channels, the hull mask and its 5x5 Gaussian, the bilinear crop-resize of image + ground truth) run
+// here in float64 with the reference's operation order, fp contraction off, and land as the packed [B,S,S,16] float32 tensor the
+// generator's callers split (channel layout: img3, gt3, uvm3, reg_in3, reg_out3, face1 — SURVEY.md Appendix D).
+//
+// Point location is brute force over the mesh's triangles (<= 200): per triangle three edge functions l_i = A_i x + B_i y + C_i
+// (normalised barycentrics, built on the host), the triangle with the largest min(l_i) wins, inside = that value >= -1e-12 (grid
+// points ON a hull edge — the offset meshes' anchors sit on the image border — count as inside, as in matplotlib's trifinder).
+// The interpolant is continuous across edges, so which of two triangles sharing an edge wins changes the result by rounding only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace bsr {
+
+constexpr int kPrepTriDoubles = 18;     // 9 edge-function doubles + 3 channels x (a, b, c) plane coefficients
+constexpr int kPrepMaxTri = 256;
+
+struct PrepRow {            // one row of the batch; offsets are bytes from the blob start
+  int64_t img_off, gt_off;  // RGB8 images [h][w][3] (gt_off == img_off when there is no separate ground truth)
+  int32_t h, w;
+  int32_t box[4];           // crop box x0, y0, x1, y1 in image pixels; may leave the image (zero extension, utils.py:414-425)
+  int64_t tri_off[4];       // meshes: 0 uv map (3 channels), 1 reg_in (2), 2 reg_out (2), 3 face hull (1); kPrepTriDoubles doubles per triangle
+  int32_t ntri[4];
+};
+
+// kernel 1: everything but the blur.  grid (S*S / 256, B); block 256.  hull: [B][S][S] raw hull mask (0 / 1) for kernel 2.
+__global__ __launch_bounds__(256) void prep_rows_kernel(const unsigned char* __restrict__ blob, const PrepRow* __restrict__ rows,
+                                                        const double* __restrict__ grid, int S, float* __restrict__ out, float* __restrict__ hull) {
+  __shared__ double s_tri[kPrepMaxTri * kPrepTriDoubles];
+  const PrepRow row = rows[blockIdx.y];
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int oy = pix / S, ox = pix % S;
+  float* o = out + ((size_t)blockIdx.y * S * S + pix) * 16;
+
+  // ---- crop + INTER_LINEAR resize of image and ground truth (dataset.resize_linear: float64, (1-w) a + w b per axis, x first) ----
+  {
+    const int n = row.box[2] - row.box[0];                        // the crop is square: side 2 * int(length)
+    const double scale = (double)n / (double)S;
+    auto axis = [&](int oidx, int& i0, int& i1, double& wgt) {
+      double src = ((double)oidx + 0.5) * scale - 0.5;
+      src = src > 0.0 ? src : 0.0;
+      int f = (int)floor(src);
+      i0 = f < n - 1 ? f : n - 1;
+      i1 = i0 + 1 < n - 1 ? i0 + 1 : n - 1;
+      wgt = src - (double)i0;
+    };
+    int y0, y1, x0, x1;
+    double wy, wx;
+    axis(oy, y0, y1, wy);
+    axis(ox, x0, x1, wx);
+    auto tap = [&](const unsigned char* im, int cy, int cx, int c) -> double {      // crop pixel (cy, cx): image pixel or 0 outside
+      const int iy = cy + row.box[1], ix = cx + row.box[0];
+      if (iy < 0 || iy >= row.h || ix < 0 || ix >= row.w) return 0.0;
+      return (double)im[((size_t)iy * row.w + ix) * 3 + c] / 255.0;
+    };
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const unsigned char* im = blob + (which ? row.gt_off : row.img_off);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double v = 0.0;
+        if (n > 0) {
+          const double top = tap(im, y0, x0, c) * (1.0 - wx) + tap(im, y0, x1, c) * wx;
+          const double bot = tap(im, y1, x0, c) * (1.0 - wx) + tap(im, y1, x1, c) * wx;
+          v = top * (1.0 - wy) + bot * wy;
+        }
+        o[which * 3 + c] = (float)v;
+      }
+    }
+  }
+
+  // ---- the four meshes ----
+  const double px = grid[ox], py = grid[oy];                      // np.meshgrid(linspace(0,1,S), linspace(0,1,S)): x varies along columns
+#pragma unroll 1
+  for (int m = 0; m < 4; ++m) {
+    const int nt = row.ntri[m] < kPrepMaxTri ? row.ntri[m] : kPrepMaxTri;
+    const double* t = reinterpret_cast<const double*>(blob + row.tri_off[m]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * kPrepTriDoubles; i += 256) s_tri[i] = t[i];
+    __syncthreads();
+    int best = -1;
+    double best_l = -1.0e300;
+    for (int k = 0; k < nt; ++k) {
+      const double* e = s_tri + k * kPrepTriDoubles;
+      const double l0 = (e[0] * px + e[1] * py) + e[2];
+      const double l1 = (e[3] * px + e[4] * py) + e[5];
+      const double l2 = (e[6] * px + e[7] * py) + e[8];
+      const double lm = fmin(l0, fmin(l1, l2));
+      if (lm > best_l) { best_l = lm; best = k; }
+    }
+    const bool inside = best >= 0 && best_l >= -1.0e-12;
+    const double* cf = s_tri + (best >= 0 ? best : 0) * kPrepTriDoubles + 9;
+    // LinearTriInterpolator: z = a x + b y + c, evaluated left to right as numpy does
+    const double z0 = (cf[0] * px + cf[1] * py) + cf[2];
+    const double z1 = (cf[3] * px + cf[4] * py) + cf[5];
+    const double z2 = (cf[6] * px + cf[7] * py) + cf[8];
+    const double nan = __builtin_nan("");
+    if (m == 0) {                       // uv map: np.nan_to_num -> 0 outside the landmark hull (warp.py:231)
+      o[6] = inside ? (float)z0 : 0.f;
+      o[7] = inside ? (float)z1 : 0.f;
+      o[8] = inside ? (float)z2 : 0.f;
+    } else if (m == 1 || m == 2) {      // offset maps: [my, mx, mx * 0], NOT nan_to_num'ed (warp.py:212-213; the anchors cover the square)
+      const double my = inside ? z0 : nan, mx = inside ? z1 : nan;
+      o[6 + 3 * m] = (float)my;
+      o[7 + 3 * m] = (float)mx;
+      o[8 + 3 * m] = (float)(mx * 0.0);
+    } else {                            // face hull: interpolated x coordinate > 0 (utils.py:272-273; nan -> 0 -> false)
+      hull[(size_t)blockIdx.y * S * S + pix] = (inside && z0 > 0.0) ? 1.f : 0.f;
+    }
+  }
+}
+
+// kernel 2: cv2.GaussianBlur(mask, (5,5), 0) = [1,4,6,4,1]/16 separable, BORDER_REFLECT_101, columns first then rows as
+// dataset.gaussian_blur5 sums them (float64) -> channel 15
+__global__ __launch_bounds__(256) void prep_blur_kernel(const float* __restrict__ hull, int S, float* __restrict__ out) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int oy = pix / S, ox = pix % S;
+  const float* hm = hull + (size_t)blockIdx.y * S * S;
+  const double k[5] = {1.0 / 16.0, 4.0 / 16.0, 6.0 / 16.0, 4.0 / 16.0, 1.0 / 16.0};
+  auto refl = [&](int i) { return i < 0 ? -i : (i >= S ? 2 * S - 2 - i : i); };
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {               // outer sum over rows of the horizontally blurred image: sum_i k[i] * tmp[y + i - 2]
+    const int yy = refl(oy + i - 2);
+    double tmp = 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) tmp = tmp + k[j] * (double)hm[(size_t)yy * S + refl(ox + j - 2)];
+    acc = acc + k[i] * tmp;
+  }
+  out[((size_t)blockIdx.y * S * S + pix) * 16 + 15] = (float)acc;
+}
+
+}  // namespace bsr

@@ -242,6 +242,9 @@ def build_element(job) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """One dataset element `(img[1,R,size,size,16], box[1,4], name[1])` from a job `(lm_path, gt_path, sibling lm paths, size)`.
     Top-level so that worker processes can run it (the rows of an element never depend on another element)."""
     lm_path, gt_path, siblings, size = job
+    if isinstance(gt_path, tuple) and gt_path[0] == "<device>":            # the host half of a device-prepared row (prep.py)
+        from .prep import host_part
+        return host_part((lm_path, gt_path[1], size))
     if gt_path == "<sfw>":
         return build_sfw_pair(lm_path, size)
     if gt_path == "<sfw_video>":
@@ -266,7 +269,7 @@ class Dataset:
     min(cpu_count, 16)."""
 
     def __init__(self, config, mode: str = "test", dset=None, ucb: bool = False, rows: int = 1, seed: int = 0,
-                 workers: int = 0, prefetch: Optional[int] = None):
+                 workers: int = 0, prefetch: Optional[int] = None, device_prep: Optional[int] = None, device_batch: int = 16):
         if mode != "test" or dset not in (None, "sfw", "sfw_video"):
             raise NotImplementedError("only the test loaders are provided (GSC: dset=None; TSM: dset='sfw' | 'sfw_video'); training loaders are out of scope")
         self.config, self.mode, self.ucb, self.rows, self.dset = config, mode, ucb, rows, dset
@@ -276,6 +279,12 @@ class Dataset:
         self.workers = int(workers)
         self.prefetch = int(prefetch) if prefetch is not None else max(2, 2 * self.workers)
         self._pool = None
+        # device_prep = GPU index: rows are prepared ON THE DEVICE (prep.py / csrc/prep_kernels.h) in groups of `device_batch`; the
+        # workers then only decode PNGs and triangulate, and `feed` yields (img CUDA tensor [1,1,S,S,16], box[1,4], name) — the
+        # same values as the host path to 1e-6 (tests/test_prep_gpu.py), never leaving HBM before the generator reads them
+        self.device_prep, self.device_batch = device_prep, int(device_batch)
+        if device_prep is not None and (rows != 1 or dset is not None):
+            raise NotImplementedError("device_prep prepares row 0 of the GSC loaders (rows=1, dset=None)")
         self.name_list: List[str] = []
         pattern = "*.npy" if dset is None else "*_label.png"               # dataset.py:55-61 | dataset_with_TSM.py:63
         for d in config.DATA_DIR_TEST:
@@ -301,7 +310,8 @@ class Dataset:
             if self.rows > 1:
                 siblings = sorted(glob.glob(os.path.join(os.path.dirname(lm_path), "*.npy")), key=natural_key)
                 sibs = [siblings[self._rng.randint(0, len(siblings) - 1)] for _ in range(self.rows - 1)]
-            yield (lm_path, self._gt_path(lm_path), sibs, size)
+            gt = self._gt_path(lm_path)
+            yield (lm_path, ("<device>", gt) if self.device_prep is not None else gt, sibs, size)
 
     def close(self) -> None:
         pool, self._pool = self._pool, None
@@ -315,6 +325,26 @@ class Dataset:
             pass
 
     def _iterate(self):
+        if self.device_prep is None:
+            yield from self._iterate_host()
+            return
+        from .prep import DevicePrep
+        dp = DevicePrep(self.device_prep, self.config.IMG_SIZE)
+        group = []
+
+        def emit():
+            out, boxes = dp.rows(group)
+            for i, part in enumerate(group):
+                yield out[i:i + 1][None], boxes[i][None], np.array([part[4]])
+        for part in self._iterate_host():
+            group.append(part)
+            if len(group) >= self.device_batch:
+                yield from emit()
+                group = []
+        if group:
+            yield from emit()
+
+    def _iterate_host(self):
         jobs = self._jobs()
         if self.workers <= 0:
             for job in jobs:
@@ -357,6 +387,9 @@ class _WorkerPool:
             env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
             env.setdefault("OMP_NUM_THREADS", "1")
             env.setdefault("OPENBLAS_NUM_THREADS", "1")
+            env.setdefault("MKL_NUM_THREADS", "1")
+            env["HIP_VISIBLE_DEVICES"] = ""                    # workers are host-only: whatever they import, they get no GPU
+            env["CUDA_VISIBLE_DEVICES"] = ""
             p = subprocess.Popen([sys.executable, "-m", "blindshadowremoval_amd._row_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
             self._local.proc = p
             with self._lock:

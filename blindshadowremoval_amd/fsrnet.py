@@ -86,13 +86,41 @@ class Logging(object):
             column.append(a[0, :, :, :3])
         return np.rint(np.concatenate(column, axis=1)).astype(np.uint8)
 
+    @staticmethod
+    def strips_from_batch(figs: Sequence[torch.Tensor]) -> np.ndarray:
+        """get_imgs for a whole batch, on whatever device the figures live: [B,S,S,C] each -> uint8 [B,S,S*len(figs),3].  The same
+        float32 arithmetic (clip, * 255, round half to even) as get_imgs, one device-to-host copy of bytes instead of one float copy
+        per figure and item."""
+        cols = []
+        for f in figs:
+            a = torch.clamp(f.detach().float(), 0.0, 1.0) * 255.0
+            cols.append(a.expand(-1, -1, -1, 3) if a.shape[3] == 1 else a[..., :3])
+        return torch.round(torch.cat(cols, dim=2)).to(torch.uint8).cpu().numpy()
+
+    def _png_path(self, fname: str) -> str:
+        parts = fname.replace('\\', '/').split('/')
+        stem = (parts[-2] + '_' if len(parts) > 1 else '') + parts[-1].split('.')[0]
+        return os.path.join(self.config.CHECKPOINT_DIR, 'test', stem + '-result.png')
+
+    def save_strip(self, strip: np.ndarray, fname: str) -> str:
+        """save_img for an already assembled uint8 strip (strips_from_batch)."""
+        out = self._png_path(fname)
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        self.saved.append(out)
+        if self._png_threads > 0:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self._png_threads, thread_name_prefix="bsr-png")
+            self._pending.append(self._pool.submit(self._write_png, strip, out))
+        else:
+            self._write_png(strip, out)
+        return out
+
     def save_img(self, fig: Sequence[torch.Tensor], fname: str) -> str:
         """Returns the PNG's path.  With png_threads > 0 the file is written ASYNCHRONOUSLY: it exists (and `saved` is accurate)
         only after flush() / close() returned."""
         strip = self.get_imgs(fig)
-        parts = fname.replace('\\', '/').split('/')
-        stem = (parts[-2] + '_' if len(parts) > 1 else '') + parts[-1].split('.')[0]
-        out = os.path.join(self.config.CHECKPOINT_DIR, 'test', stem + '-result.png')
+        out = self._png_path(fname)
         os.makedirs(os.path.dirname(out), exist_ok=True)
         self.saved.append(out)
         if self._png_threads > 0:
@@ -147,7 +175,11 @@ class FSRNet(object):
             self.gen.load_weights(weights)
         self.log = Logging(config, png_threads=4)
         self.timings: Dict[str, float] = {}      # wall-clock split of the last test / testFFHQ loop (see _loop)
-        self.post_threads = 8                    # threads that post-process the items of one UCB batch
+        self.post_threads = 8                    # threads that post-process the items of one UCB batch (post_workers == 0)
+        self.post_workers = 0                    # > 0: UCB post-processing in that many worker PROCESSES, pipelined one batch behind the GPU
+        self.post_inflight = 2                   # batches whose post-processing may be outstanding
+        self.return_figs = True                  # False: FSRNet.test returns (name, None, losses) — the figures are only written as PNG strips
+        self._post_writes_png = False            # set by test(): the post-processing workers write the PNG strips themselves
 
     # -- checkpoint -------------------------------------------------------------------------
     def _restore(self) -> int:
@@ -231,73 +263,112 @@ class FSRNet(object):
         self._restore()
         start = time.time()
 
+        post_pool = None
+        if ucb and postprocess and self.post_workers > 0:
+            from .dataset import _WorkerPool
+            post_pool = _WorkerPool(self.post_workers)
+        inflight: List[Tuple] = []          # UCB batches whose post-processing runs in the worker pool: (pending items, futures)
+
+        def finish(batch_items, post):
+            """log + save + collect one batch, in item order (post = [(losses, figs | None)] for the UCB post-processing mode)"""
+            for j, (step, name, _, box) in enumerate(batch_items):
+                t1 = time.perf_counter()
+                losses, f = post[j]
+                self.log.display(losses, 0, step, False, num_list)
+                if f is not None and not self._post_writes_png:
+                    self.log.save_img([torch.from_numpy(a) for a in f], name)
+                elif self._post_writes_png:
+                    self.log.saved.append(self.log._png_path(name))
+                tm["png_s"] += time.perf_counter() - t1
+                tm["items"] += 1
+                results.append((name, [torch.from_numpy(a) for a in f] if f is not None else None, losses))
+
+        def drain(keep: int):
+            while len(inflight) > keep:
+                t1 = time.perf_counter()
+                batch_items, futs = inflight.pop(0)
+                post = [fu.result() for fu in futs]
+                tm["post_s"] += time.perf_counter() - t1
+                finish(batch_items, post)
+
         def flush():
             if not pending:
                 return
             t0 = time.perf_counter()
-            rows = torch.cat([self._split_row0(p[2]) for p in pending], dim=0)
-            im, gt, uv, reg, face = torch.split(rows, list(SPLIT_FFHQ), dim=3)
             dev = "cuda:%d" % self.gen._device
-            rows_d = rows.to(dev)                                   # ONE host-to-device copy of the packed rows; the channel slices are cut on the GPU
-            im_d, _, uv_d, _, _ = torch.split(rows_d, list(SPLIT_FFHQ), dim=3)
-            gs, con_rgb, _, mask_pred = self.gen(im_d, uv_d, reg, chuck=4 if ucb else 1, training=False)
+            rows = torch.cat([self._split_row0(p[2]) for p in pending], dim=0)
+            rows_d = rows.to(dev)                                   # ONE host-to-device copy of the packed rows (none when the loader prepared them on the device)
+            im_d, gt_d, uv_d, _, face_d = torch.split(rows_d, list(SPLIT_FFHQ), dim=3)
+            gs, con_rgb, _, mask_pred = self.gen(im_d, uv_d, None, chuck=4 if ucb else 1, training=False)
+            if self.gen.dtype != "f32":
+                self.gen.check_range()                              # 16-bit modes: an out-of-range activation is an error here, never a silent inf
+            items = list(pending)
+            pending.clear()
             if ucb and postprocess:
-                con_h, mask_h = con_rgb.cpu().numpy(), mask_pred.cpu().numpy()
-            torch.cuda.synchronize(self.gen._device)
+                # train_test_GSC.py:424-748 on the host, one independent item per call.  What the host reads comes over in ONE copy.
+                host = torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3).cpu().numpy()         # [B,S,S,10]
+                torch.cuda.synchronize(self.gen._device)
+                tm["forward_s"] += time.perf_counter() - t0
+                tm["forwards"] += 1
+                tm.setdefault("first_batch_done_s", time.time() - start)
+                t1 = time.perf_counter()
+
+                def job(j):
+                    step, name, _, box = items[j]
+                    return {"im": host[j, ..., 0:3], "gt": host[j, ..., 3:6], "con": host[j, ..., 6:9], "mp": host[j, ..., 9:10],
+                            "box": np.asarray(box, np.float32).reshape(-1)[:4], "masks": mask_files[step],
+                            "png": self.log._png_path(name) if self._post_writes_png else None, "return_figs": self.return_figs}
+                if post_pool is not None:
+                    # worker PROCESSES (the post-processing is ~60 ms of small numpy / torch-CPU calls per item, GIL-bound in threads);
+                    # this batch is post-processed while the next one is prepared and run: results are collected one batch later
+                    inflight.append((items, [post_pool.submit(("ucb_post", job(j))) for j in range(len(items))]))
+                    tm["post_s"] += time.perf_counter() - t1
+                    drain(keep=self.post_inflight)
+                    return
+                from .ucb_post import run_post_job
+                if len(items) > 1 and self.post_threads > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=min(self.post_threads, len(items))) as ex:
+                        post = list(ex.map(lambda j: run_post_job(job(j)), range(len(items))))
+                else:
+                    post = [run_post_job(job(j)) for j in range(len(items))]
+                tm["post_s"] += time.perf_counter() - t1
+                finish(items, post)
+                return
+            # FFHQ / raw-UCB: the figures stay on the device; the PNG strips of the whole batch are assembled there and come
+            # over as bytes in one copy (Logging.strips_from_batch = get_imgs per item, same arithmetic)
+            if ucb:
+                figs_b = [im_d, gs, con_rgb, mask_pred, gt_d, face_d]
+                shown_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]
+            else:
+                figs_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]            # train_test_GSC.py:872-873,889
+                shown_b = figs_b
+            strips = self.log.strips_from_batch(shown_b)
             tm["forward_s"] += time.perf_counter() - t0
             tm["forwards"] += 1
-            post = [None] * len(pending)
-            if ucb and postprocess:
-                # train_test_GSC.py:424-748 on the host, one independent item per call: the items of a batch are post-processed by
-                # a few threads (numpy / torch release the GIL in the heavy parts), logged and saved in order afterwards
-                from .ucb_post import ucb_postprocess
-                t1 = time.perf_counter()
-
-                def one(j):
-                    step, _, _, box = pending[j]
-                    with np.errstate(invalid="ignore", divide="ignore"):
-                        return ucb_postprocess(im[j].numpy(), gt[j].numpy(), con_h[j], mask_h[j], np.asarray(box).reshape(-1)[:4],
-                                               self._read_masks(mask_files[step]))
-                if len(pending) > 1 and self.post_threads > 1:
-                    from concurrent.futures import ThreadPoolExecutor
-                    with ThreadPoolExecutor(max_workers=min(self.post_threads, len(pending))) as ex:
-                        post = list(ex.map(one, range(len(pending))))
-                else:
-                    post = [one(j) for j in range(len(pending))]
-                tm["post_s"] += time.perf_counter() - t1
-            for j, (step, name, _, box) in enumerate(pending):
-                sl = slice(j, j + 1)
-                losses: Dict[str, float] = {}
-                t1 = time.perf_counter()
-                if ucb and postprocess:
-                    losses, f = post[j]
-                    figs = [torch.from_numpy(a) for a in f]
-                    shown = figs
-                elif ucb:
-                    figs = [im[sl].to(dev), gs[sl], con_rgb[sl], mask_pred[sl], gt[sl].to(dev), face[sl].to(dev)]
-                    shown = [figs[0], torch.clamp(figs[2], 0, 1), figs[3] * figs[5] * 2]
-                else:
-                    figs = [im[sl].to(dev), torch.clamp(con_rgb[sl], 0, 1), mask_pred[sl] * face[sl].to(dev) * 2]
-                    shown = figs
-                t2 = time.perf_counter()
-                self.log.display(losses, 0, step, False, num_list)
-                self.log.save_img(shown, name)
-                t3 = time.perf_counter()
-                tm["post_s"] += t2 - t1
-                tm["png_s"] += t3 - t2
+            tm.setdefault("first_batch_done_s", time.time() - start)
+            t1 = time.perf_counter()
+            for j, (step, name, _, box) in enumerate(items):
+                self.log.display({}, 0, step, False, num_list)
+                self.log.save_strip(strips[j], name)
                 tm["items"] += 1
-                results.append((name, figs) if not (ucb and postprocess) else (name, figs, losses))
-            pending.clear()
+                results.append((name, [f[j:j + 1] for f in figs_b]))
+            tm["png_s"] += time.perf_counter() - t1
 
-        for step, img_name in enumerate(names):
-            t0 = time.perf_counter()
-            element = next(dataset.feed)
-            tm["prep_wait_s"] += time.perf_counter() - t0
-            img = element[0]
-            pending.append((step, _name(img_name), img, element[1] if len(element) > 1 else None))
-            if len(pending) >= batch:
-                flush()
-        flush()
+        try:
+            for step, img_name in enumerate(names):
+                t0 = time.perf_counter()
+                element = next(dataset.feed)
+                tm["prep_wait_s"] += time.perf_counter() - t0
+                img = element[0]
+                pending.append((step, _name(img_name), img, element[1] if len(element) > 1 else None))
+                if len(pending) >= batch:
+                    flush()
+            flush()
+            drain(keep=0)
+        finally:
+            if post_pool is not None:
+                post_pool.shutdown()
         t0 = time.perf_counter()
         self.log.flush()
         tm["png_s"] += time.perf_counter() - t0
@@ -319,6 +390,7 @@ class FSRNet(object):
         """train_test_GSC.py:360-408 + test_step :411-748.  Returns [(name, figs, {'ssim','psnr'})] with the reference's seven
         figures per item; ``postprocess=False`` returns the raw generator outputs [(name, [img, gs, con_rgb, dif, gt, face])].
         ``mask_files``: optional explicit per-item list (as ``_ucb_masks()`` returns it) instead of the folder listing."""
+        self._post_writes_png = bool(postprocess and self.post_workers > 0 and not self.return_figs)
         return self._loop(dataset_val, batch, ucb=True, postprocess=postprocess, mask_files=mask_files)
 
 

@@ -33,13 +33,23 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
     res = {"loop": "FSRNet.test (UCB, batch %d, host post-processing + SSIM/PSNR)" % batch if ucb else "FSRNet.testFFHQ (batch %d)" % batch,
            "dtype": dtype}
     try:
-        for label, nw in (("serial_loader", 0), ("pooled_loader", workers)):
-            ds = Dataset(cfg, "test", ucb=ucb, workers=nw)
+        ncpu = os.cpu_count() or 1
+        modes = [("serial_loader", dict(workers=0), {}), ("pooled_loader", dict(workers=workers), {}),
+                 # round 3: rows prepared ON THE DEVICE (prep.py: the workers only decode PNGs and triangulate), PNG strips assembled
+                 # on the device, UCB post-processing in worker processes one batch behind the GPU
+                 ("device_prep", dict(workers=min(32, max(4, ncpu // 4)), device_prep=fsr.gen._device, device_batch=batch),
+                  dict(post_workers=min(32, max(4, ncpu // 4)), png_threads=min(16, max(4, ncpu // 8))))]
+        for label, ds_kw, fsr_kw in modes:
+            ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
+            fsr.post_workers = fsr_kw.get("post_workers", 0)
+            fsr.return_figs = not fsr_kw                                 # the device_prep mode measures the loop as a user who wants the PNGs + metrics runs it
+            fsr.log._png_threads = fsr_kw.get("png_threads", 4)
             base = list(ds.name_list)
-            reps = (items + len(base) - 1) // len(base)
-            ds.name_list = (base * reps)[:items]
+            n_items = items * (10 if fsr_kw else 1)                      # the fast mode needs a longer list for a steady-state rate
+            reps = (n_items + len(base) - 1) // len(base)
+            ds.name_list = (base * reps)[:n_items]
             # item i of the repeated list is evaluated against mask i of the equally repeated mask list (FSRNet.test indexes strictly)
-            masks = (fsr._ucb_masks()[:len(base)] * reps)[:items] if ucb else None
+            masks = (fsr._ucb_masks()[:len(base)] * reps)[:n_items] if ucb else None
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
                 out = fsr.test(ds, batch=batch, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=batch)
@@ -47,6 +57,11 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
             tm = dict(fsr.timings)
             res[label] = {"workers": ds.workers, "items": len(out), "images_per_sec": round(len(out) / dt, 2), "seconds": round(dt, 3),
                           "split_s": {k: round(v, 3) for k, v in tm.items() if k.endswith("_s")}, "forwards": tm.get("forwards")}
+            if fsr_kw:
+                t_first = tm.get("first_batch_done_s", 0.0)
+                res[label].update(post_workers=fsr.post_workers, png_threads=fsr.log._png_threads,
+                                  steady_images_per_sec=round((len(out) - batch) / max(dt - t_first, 1e-9), 2),
+                                  note="images_per_sec includes starting the worker processes; steady_images_per_sec = items after the first batch / time after it")
             ds.close()
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)

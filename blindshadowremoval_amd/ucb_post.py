@@ -10,6 +10,7 @@ The numbers (0.018, 0.02, 0.252 ...) are the reference's; line references are gi
 tests/golden/ucb_post_9156.npz, produced by executing the reference's own `test_step` source
 (tools/make_ucb_post_fixture.py).
 """
+import os
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -136,3 +137,27 @@ def ucb_postprocess(img0: np.ndarray, gt0: np.ndarray, con_rgb0: np.ndarray, mas
     losses = {"ssim": float(_ssim(g, o).sum()), "psnr": float(_psnr(g, o).sum())}          # :724-725
     figs = [tmp, out, mp * 2, gt_sc, detected3, full_pred, nose * tmp]                     # :744
     return losses, [np.asarray(f, np.float32).reshape(1, full, full, 3) for f in figs]
+
+
+def read_masks(paths: Dict[str, str]) -> Dict[str, np.ndarray]:
+    """The seven mask images of one item: cv2.imread(...)/255.0, three equal channels (train_test_GSC.py:386-393)."""
+    from PIL import Image
+    out = {}
+    for k, path in paths.items():
+        a = np.asarray(Image.open(path).convert("L"), np.float64) / 255.0
+        out[k] = np.repeat(a[:, :, None], 3, axis=2)
+    return out
+
+
+def run_post_job(job: dict):
+    """One item of FSRNet.test's post-processing in a worker process (fsrnet.FSRNet(post_workers=N)): reads the item's masks,
+    runs ucb_postprocess, optionally writes the PNG strip of the seven figures itself.  -> (losses, figs | None)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        losses, figs = ucb_postprocess(job["im"], job["gt"], job["con"], job["mp"], job["box"], read_masks(job["masks"]))
+    if job.get("png"):
+        from PIL import Image
+        cols = [np.clip(f[0], 0.0, 1.0) * np.float32(255) for f in figs]
+        strip = np.rint(np.concatenate(cols, axis=1)).astype(np.uint8)           # = fsrnet.Logging.get_imgs
+        os.makedirs(os.path.dirname(job["png"]), exist_ok=True)
+        Image.fromarray(strip).save(job["png"], compress_level=1)
+    return losses, (figs if job.get("return_figs", True) else None)

@@ -104,6 +104,15 @@ int bsr_get_timing(bsr_handle* h, float ms_per_class[BSR_NUM_CLASSES], int launc
 int bsr_timing_launches(bsr_handle* h);
 int bsr_timing_entry(bsr_handle* h, int i, char* name, size_t name_cap, float* ms, int* cls);
 
+/* Input preparation for a batch of rows on the device: the per-sample work of the reference's test loaders
+ * (/root/reference/dataset.py:619-638, 148-170; utils.py:356-433 face_crop_and_resize, :255-276 generate_face_region;
+ * warp.py:194-232 generate_offset_map / generate_uv_map) after PNG decoding and Delaunay triangulation, which stay on the host.
+ * d_blob: ONE device buffer holding, at 8-byte aligned offsets, B row records (csrc/prep_kernels.h PrepRow: image / ground-truth
+ * RGB8 offsets and size, crop box, four triangle tables), `S` float64 grid coordinates (numpy.linspace(0, 1, S)) and the data
+ * they point to — blindshadowremoval_amd/prep.py builds it.  out: [B,S,S,16] float32 = img3 | gt3 | uvm3 | reg_in3 | reg_out3 |
+ * face1 (the packed layout FSRNet.test_step / test_step_FFHQ split, train_test_GSC.py:419,870); hull_tmp: [B,S,S] float32 scratch. */
+int bsr_prep_rows(const void* d_blob, size_t rows_off, size_t grid_off, int B, int S, float* out, float* hull_tmp, void* stream);
+
 /* Test hook: the fused NonLocalBlock attention kernel alone (/root/reference/model.py:51-53).
  * qkv [B,tokens,384] (theta | phi | g, 128 channels each) -> y [B,tokens,128]; tokens % 128 == 0. */
 int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream);

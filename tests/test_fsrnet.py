@@ -223,3 +223,59 @@ def test_logging_flush_waits_for_all_writers_and_reraises(tmp_path):
         log.flush()
     assert os.path.isfile(p1) and os.path.isfile(p3)   # the good ones were still waited for
     log.close()
+
+
+@pytest.mark.gpu
+def test_device_prepared_loader_feeds_the_loops(golden_dir, tmp_path):
+    """Dataset(device_prep=gpu): rows are prepared on the device (prep.py / csrc/prep_kernels.h) and reach the generator without a
+    host round trip; FSRNet.testFFHQ on them gives the figures of the host-prepared path (inputs equal to 1e-6)."""
+    from blindshadowremoval_amd import dataset as D
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    w = init_weights(1)
+    outs = []
+    for k, kw in enumerate((dict(workers=2), dict(workers=2, device_prep=0, device_batch=8))):
+        cfg.CHECKPOINT_DIR = str(tmp_path / ("run%d" % k))
+        ds = D.Dataset(cfg, "test", ucb=True, **kw)
+        fsr = FSRNet(cfg, weights=w)
+        res = fsr.testFFHQ(ds, batch=16)
+        ds.close()
+        assert len(res) == 20 and all(os.path.isfile(f) for f in fsr.log.saved) and len(fsr.log.saved) == 20
+        outs.append(res)
+        fsr.gen.close()
+    for (n0, f0), (n1, f1) in zip(*outs):
+        assert n0 == n1
+        assert f1[0].is_cuda
+        assert float((f0[0].cpu() - f1[0].cpu()).abs().max()) <= 1e-6          # the prepared image itself
+        for a, b in zip(f0[1:], f1[1:]):
+            assert float((a.cpu() - b.cpu()).abs().max()) <= 1e-3               # generator outputs on inputs that differ by <= 1e-6
+
+
+@pytest.mark.gpu
+def test_ucb_post_processing_in_worker_processes_equals_the_in_process_form(golden_dir, tmp_path):
+    """FSRNet.test(post_workers=N): the reference's per-item post-processing runs in worker processes one batch behind the GPU;
+    same code, same inputs => identical metrics and identical PNG strips."""
+    from blindshadowremoval_amd import dataset as D
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    w = init_weights(1)
+    runs = []
+    for k, (pw, figs) in enumerate(((0, True), (3, True), (3, False))):
+        cfg.CHECKPOINT_DIR = str(tmp_path / ("run%d" % k))
+        ds = D.Dataset(cfg, "test", ucb=True, workers=2)
+        fsr = FSRNet(cfg, weights=w)
+        fsr.post_workers, fsr.return_figs = pw, figs
+        res = fsr.test(ds, batch=8)
+        ds.close()
+        assert len(res) == 20 and len(fsr.log.saved) == 20
+        runs.append((res, [open(f, "rb").read() for f in fsr.log.saved]))
+        fsr.gen.close()
+    base_res, base_png = runs[0]
+    for res, png in runs[1:]:
+        assert [r[0] for r in res] == [r[0] for r in base_res]
+        assert [r[2] for r in res] == [r[2] for r in base_res]                  # SSIM / PSNR, item by item
+        assert png == base_png                                                  # the strips, byte for byte
+    assert all(r[1] is None for r in runs[2][0]) and all(len(r[1]) == 7 for r in runs[1][0])
