@@ -30,7 +30,27 @@ def main() -> int:
             return 0
         job = pickle.loads(_read_exact(fin, struct.unpack("<Q", head)[0]))
         try:
-            if isinstance(job, tuple) and job and job[0] == "ucb_post":
+            if isinstance(job, tuple) and job and job[0] == "warm":                  # import what the jobs of this pool will need, before the clock runs
+                import time
+                if job[1] == "post":
+                    import blindshadowremoval_amd.ucb_post  # noqa: F401
+                else:
+                    import matplotlib.tri  # noqa: F401
+                    import PIL.Image  # noqa: F401
+                time.sleep(0.2)                                                      # keeps this worker busy so that the pool starts the others too
+                result = True
+            elif isinstance(job, tuple) and job and job[0] == "png":                 # ("png", path, uint8 strip | (shm file, shape, index)): Logging(png_workers=N)
+                import numpy as np
+                from PIL import Image
+                strip = job[2]
+                if isinstance(strip, tuple):                                         # one strip of a batch the parent parked in shared memory
+                    shm, shape, idx = strip
+                    n = int(np.prod(shape[1:]))
+                    strip = np.fromfile(shm, np.uint8, count=n, offset=idx * n).reshape(shape[1:])
+                os.makedirs(os.path.dirname(job[1]), exist_ok=True)
+                Image.fromarray(strip).save(job[1], compress_level=1)
+                result = True
+            elif isinstance(job, tuple) and job and job[0] == "ucb_post":
                 from blindshadowremoval_amd.ucb_post import run_post_job
                 result = run_post_job(job[1])
             else:

