@@ -238,6 +238,7 @@ def test_device_prepared_loader_feeds_the_loops(golden_dir, tmp_path):
     for k, kw in enumerate((dict(workers=2), dict(workers=2, device_prep=0, device_batch=8))):
         cfg.CHECKPOINT_DIR = str(tmp_path / ("run%d" % k))
         ds = D.Dataset(cfg, "test", ucb=True, **kw)
+        ds.name_list = ds.name_list[:20]
         fsr = FSRNet(cfg, weights=w)
         res = fsr.testFFHQ(ds, batch=16)
         ds.close()
@@ -266,6 +267,7 @@ def test_ucb_post_processing_in_worker_processes_equals_the_in_process_form(gold
     for k, (pw, figs) in enumerate(((0, True), (3, True), (3, False))):
         cfg.CHECKPOINT_DIR = str(tmp_path / ("run%d" % k))
         ds = D.Dataset(cfg, "test", ucb=True, workers=2)
+        ds.name_list = ds.name_list[:20]
         fsr = FSRNet(cfg, weights=w)
         fsr.post_workers, fsr.return_figs = pw, figs
         res = fsr.test(ds, batch=8)
