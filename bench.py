@@ -244,10 +244,14 @@ class _StubGenerator:
     """Stand-in for the HIP generator so the rank logic (launcher, sharding, double-buffered all-gather, JSON contract)
     runs on a CPU box over gloo.  NOT a fallback of the product path: bench lines produced with it carry "stub": true."""
 
-    def __call__(self, inputs, uv, out=None):
+    def __call__(self, inputs, uv, out=None, packed_out=None):
         import torch
         g0 = inputs.mean(dim=3, keepdim=True)
         res = (g0, inputs * 0.5 + uv * 0.5, torch.cat([g0, g0 * 0, -g0], 3), g0 - uv[..., :1])
+        if packed_out is not None:
+            packed_out[..., :3].copy_(res[1])
+            packed_out[..., 3:].copy_(res[3])
+            return res[0], packed_out[..., :3], res[2], packed_out[..., 3:]
         if out is not None:
             for o, r in zip(out, res):
                 o.copy_(r)
@@ -467,9 +471,11 @@ def run_rank(args):
     pending = [None, None]
     last = [None, None]                     # the output tuple of the last forward in each slot
 
-    def forward(slot):
+    def forward(slot, pack=False):
         if tsm:
             return gen(inp, uv, reg, 2, True)           # frame = 2 (image + mirror pairs, train_with_TSM.py:676)
+        if pack:                                        # con_rgb | dif written by the tail kernel straight into the all-gather payload (bsr_forward_packed)
+            return gen(inp, uv, out=outs[slot], packed_out=packed[slot])
         return gen(inp, uv, out=outs[slot])
 
     def step(i, gather=True):
@@ -477,10 +483,12 @@ def run_rank(args):
         if pending[slot] is not None:           # buffers of step i-2 are free once its gather completed
             pending[slot].wait()
             pending[slot] = None
-        o = forward(slot)
+        gathering = distributed and gather and not args.no_gather
+        o = forward(slot, pack=gathering)
         last[slot] = o
-        if distributed and gather and not args.no_gather:
-            torch.cat((o[1], o[3]), dim=3, out=packed[slot])
+        if gathering:
+            if tsm:
+                torch.cat((o[1], o[3]), dim=3, out=packed[slot])
             pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
 
     def drain():

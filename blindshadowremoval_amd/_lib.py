@@ -16,7 +16,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows")
+           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed")
 
 
 def load() -> ctypes.CDLL:
@@ -39,6 +39,8 @@ def load() -> ctypes.CDLL:
     lib.bsr_create.restype = c_i
     lib.bsr_forward.argtypes = [c_v, c_v, c_v, c_i, c_i, c_i, c_v, c_v, c_v, c_v, c_v]
     lib.bsr_forward.restype = c_i
+    lib.bsr_forward_packed.argtypes = [c_v, c_v, c_v, c_i, c_i, c_i, c_v, c_v, c_v, c_v]
+    lib.bsr_forward_packed.restype = c_i
     lib.bsr_forward_tsm.argtypes = [c_v, c_v, c_v, c_v, c_i, c_i, c_i, c_i, c_i, c_v, c_v, c_v, c_v, c_v]
     lib.bsr_forward_tsm.restype = c_i
     lib.bsr_workspace_bytes.argtypes = [c_i, c_i, c_i]

@@ -327,7 +327,7 @@ struct Launcher {
 
   template <int KH, int KW, bool GS, bool TAIL, int RW>
   void conv16(int cls, const char* name, const float* in, int in_cs, int H, int W, float* out, int out_cs, int act, const float* gs,
-              const float* inputs, float* con_rgb, float* dif) {
+              const float* inputs, float* con_rgb, float* dif, float* packed = nullptr) {
     if (rc != BSR_OK) return;
     LayerW l;
     rc = find_layer(h, name, 2, KH * KW, 36, 16, &l);
@@ -336,7 +336,7 @@ struct Launcher {
     bsr::ConvN16Args a{};
     a.in = in; a.in_cs = in_cs; a.H = H; a.W = W; a.w = l.w; a.bias = l.b; a.out = out; a.out_cs = out_cs; a.act = act;
     a.pad_t = (KH - 1) / 2; a.pad_l = (KW - 1) / 2;
-    a.gs = gs; a.w_gs = h->clr_gs_w; a.tail_w = h->tail_w; a.inputs = inputs; a.con_rgb = con_rgb; a.dif = dif;
+    a.gs = gs; a.w_gs = h->clr_gs_w; a.tail_w = h->tail_w; a.inputs = inputs; a.con_rgb = con_rgb; a.dif = dif; a.packed = packed;
     a.range_flag = h->range_flag;
     if (H % (4 * RW) != 0 || W % 32 != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': image is not a multiple of its tile"); return; }
     begin(cls, name);
@@ -551,8 +551,8 @@ size_t bsr_handle_workspace_bytes(const bsr_handle* h, int B, int H, int W) {
 }
 
 static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, const float* reg, int frame, int share, int B, int H, int W,
-                        float* gs, float* con_rgb, float* mask22, float* dif, void* stream) {
-  if (h == nullptr || inputs == nullptr || uv == nullptr || gs == nullptr || con_rgb == nullptr || mask22 == nullptr || dif == nullptr)
+                        float* gs, float* con_rgb, float* mask22, float* dif, void* stream, float* packed = nullptr) {
+  if (h == nullptr || inputs == nullptr || uv == nullptr || gs == nullptr || mask22 == nullptr || (packed == nullptr && (con_rgb == nullptr || dif == nullptr)))
     return fail(BSR_ERR_ARG, "bsr_forward: null argument");
   if (B <= 0) return fail(BSR_ERR_ARG, "bsr_forward: B must be positive");
   const Variant& V = h->var;
@@ -686,7 +686,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   L.conv<3, 3, 1, true, 1, 32, 1>(K_CONVT, "clr_up2", ws + p.f1, 128, 0, 128, H4, W4, ws + p.f2, 96, 0, 96, 1, io_both);
   L.conv<3, 3, 1, true, 2, 32, 1>(K_CONVT_NI2, "clr_up3", ws + p.f2, 96, 0, 96, H2, W2, ws + p.cf, CS_CF, 0, 64, 1, io_both);
   // clr_conv1 (3x3 over cat[gs, f]) + clr_conv2 + clr_conv3 + dif, one kernel (model.py:267-269,288)
-  L.conv16<3, 3, true, true, 2>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, H, W, nullptr, 0, 1, gs, inputs, con_rgb, dif);
+  L.conv16<3, 3, true, true, 2>(K_CONV3, "clr_conv1", ws + p.cf, CS_CF, H, W, nullptr, 0, 1, gs, inputs, con_rgb, dif, packed);
   if (L.rc == BSR_OK) h->ran = true;
   return L.rc;
 }
@@ -694,6 +694,12 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
 int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W, float* gs, float* con_rgb, float* mask22,
                 float* dif, void* stream) {
   return forward_impl(h, inputs, uv, nullptr, 1, 0, B, H, W, gs, con_rgb, mask22, dif, stream);
+}
+
+int bsr_forward_packed(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W, float* gs, float* con_rgb_dif, float* mask22,
+                       void* stream) {
+  if (con_rgb_dif == nullptr) return fail(BSR_ERR_ARG, "bsr_forward_packed: null con_rgb_dif");
+  return forward_impl(h, inputs, uv, nullptr, 1, 0, B, H, W, gs, nullptr, mask22, nullptr, stream, con_rgb_dif);
 }
 
 int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const float* reg, int B, int H, int W, int frame, int share,

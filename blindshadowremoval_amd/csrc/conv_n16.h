@@ -37,6 +37,8 @@ struct ConvN16Args {
   const float* inputs;  // TAIL: [B,H,W,3]
   float* con_rgb;       // TAIL: [B,H,W,3]
   float* dif;           // TAIL: [B,H,W,1]
+  float* packed;        // TAIL: when not null, con_rgb | dif are written as ONE [B,H,W,4] tensor (16-byte store per pixel) instead — the
+                        //       payload of the multi-GPU output all-gather (bench.py / dist.py); con_rgb / dif are then not written
   int tiles_x, tiles_y, batch;   // filled by the launcher
   unsigned* range_flag; // H = 2: set when a staged activation does not fit fp16 (igemm_h16.h); may be null
   float* gs_out;        // FUSE: [B,H,W,1] gs = gray(inputs) * (1 + mask) + con   (inputs = the `inputs` field)
@@ -536,12 +538,16 @@ __global__ __launch_bounds__(256, 2) void conv_n16_kernel(ConvN16Args p) {
         if (q == 0) {   // rows 0..2 = R,G,B of pixel r
 #pragma clang fp contract(off)
           const float cr = a3[0] + tb3[0], cg = a3[1] + tb3[1], cb = a3[2] + tb3[2];
-          p.con_rgb[pix * 3 + 0] = cr;
-          p.con_rgb[pix * 3 + 1] = cg;
-          p.con_rgb[pix * 3 + 2] = cb;
           const float g1 = (cr * 0.2989f + cg * 0.5870f) + cb * 0.1140f;
           const float g0 = (tin[mt][0] * 0.2989f + tin[mt][1] * 0.5870f) + tin[mt][2] * 0.1140f;
-          p.dif[pix] = g1 - g0;
+          if (p.packed != nullptr) {
+            *reinterpret_cast<f32x4*>(p.packed + pix * 4) = f32x4{cr, cg, cb, g1 - g0};
+          } else {
+            p.con_rgb[pix * 3 + 0] = cr;
+            p.con_rgb[pix * 3 + 1] = cg;
+            p.con_rgb[pix * 3 + 2] = cb;
+            p.dif[pix] = g1 - g0;
+          }
         }
       }
     }

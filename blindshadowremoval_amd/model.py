@@ -107,7 +107,9 @@ class Generator:
         return tuple(out)
 
     def __call__(self, inputs, uv, reg=None, chuck: int = 1, training: bool = False,
-                 out: Optional[Tuple[torch.Tensor, ...]] = None):
+                 out: Optional[Tuple[torch.Tensor, ...]] = None, packed_out: Optional[torch.Tensor] = None):
+        """``packed_out``: optional [B,H,W,4] float32 CUDA tensor; con_rgb | dif are then written straight into it (bsr_forward_packed:
+        the multi-GPU all-gather payload) and the returned con_rgb / dif are views of it."""
         if training:
             raise NotImplementedError("only the inference path (training=False) is implemented "
                                       "(/root/reference/train_test_GSC.py:404,856)")
@@ -130,8 +132,16 @@ class Generator:
             else:
                 gs, con_rgb, mask22, dif = self._check_out(out, B, H, W, dev)
             stream = torch.cuda.current_stream().cuda_stream
-            rc = self._lib.bsr_forward(self._handle, inputs.data_ptr(), uv.data_ptr(), B, H, W, gs.data_ptr(), con_rgb.data_ptr(),
-                                       mask22.data_ptr(), dif.data_ptr(), stream)
+            if packed_out is not None:
+                if (not isinstance(packed_out, torch.Tensor) or tuple(packed_out.shape) != (B, H, W, 4) or packed_out.dtype != torch.float32
+                        or packed_out.device.type != "cuda" or packed_out.device.index != dev or not packed_out.is_contiguous()):
+                    raise ValueError("packed_out must be a contiguous float32 [B,H,W,4] tensor on cuda:%d" % dev)
+                rc = self._lib.bsr_forward_packed(self._handle, inputs.data_ptr(), uv.data_ptr(), B, H, W, gs.data_ptr(), packed_out.data_ptr(),
+                                                  mask22.data_ptr(), stream)
+                con_rgb, dif = packed_out[..., :3], packed_out[..., 3:]
+            else:
+                rc = self._lib.bsr_forward(self._handle, inputs.data_ptr(), uv.data_ptr(), B, H, W, gs.data_ptr(), con_rgb.data_ptr(),
+                                           mask22.data_ptr(), dif.data_ptr(), stream)
         _lib.check(rc, "bsr_forward")
         self._shape = (B, H, W)
         return gs, con_rgb, mask22, dif

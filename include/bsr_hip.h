@@ -61,6 +61,12 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
 int bsr_forward(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W,
                 float* gs, float* con_rgb, float* mask22, float* dif, void* stream);
 
+/* bsr_forward with the two outputs the reference's callers consume (train_test_GSC.py:871-873: deshadow_img_c, mask_pred) written as
+ * ONE tensor con_rgb_dif [B,H,W,4] = con_rgb(3) | dif(1): the payload of the multi-GPU output all-gather (one 16-byte store per pixel,
+ * no separate packing pass).  Values are bit-identical to bsr_forward's con_rgb / dif. */
+int bsr_forward_packed(bsr_handle* h, const float* inputs, const float* uv, int B, int H, int W,
+                       float* gs, float* con_rgb_dif, float* mask22, void* stream);
+
 /* TSM variant (BASELINE config 5): replaces Generator.call(inputs, uv, reg, frame, share, chuck, training=False) of
  * /root/reference/model_with_TSM.py:261-325 (call site /root/reference/train_with_TSM.py:676).  The handle must have been
  * created from TSM weights (res_stack/0/conv1 with 291 input channels).  reg: [B,H,W,6] = reg_in(3) | reg_out(3) offset

@@ -669,3 +669,20 @@ def test_fused_heads_epilogue_is_bit_identical_to_the_two_launch_form(dtype, mon
             assert torch.equal(x, y), (dtype, B, H, W, name)
     fused.close()
     plain.close()
+
+
+def test_packed_output_is_bit_identical(gen_w):
+    """bsr_forward_packed: con_rgb | dif written as one [B,H,W,4] tensor by the tail kernel (the all-gather payload of bench.py /
+    dist.py) — the same bits as the two separate outputs."""
+    gen, _ = gen_w
+    torch.manual_seed(81)
+    inp, uv = torch.rand(5, 256, 256, 3).cuda(), torch.rand(5, 256, 256, 3).cuda()
+    a = [t.clone() for t in gen(inp, uv)]
+    packed = torch.full((5, 256, 256, 4), float("nan"), device="cuda")
+    b = gen(inp, uv, packed_out=packed)
+    assert b[1].data_ptr() == packed.data_ptr()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(packed, torch.cat((a[1], a[3]), dim=3))
+    with pytest.raises(ValueError):
+        gen(inp, uv, packed_out=packed[:4])
