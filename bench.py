@@ -334,6 +334,9 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
           "frac": dom["hbm_frac"] if hbm_bound else dom["frac"], "traffic": None, "mfma_view": mfma_view, "hbm_view": hbm_view,
           "kernel": dom_name + " — the largest kernel instantiation, %.0f %% of the forward's device time" % (100 * dom["ms"] / t_all),
           "launches_per_forward": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+          "duration_source": ("HIP events recorded around every launch on the forward's stream (bsr_set_timing), mean of %d extra forwards after the timed "
+                              "region; the rocprofv3 --kernel-trace average of the same kernel is in profiles/ (3-4 %% longer: profiler overhead); event-timed "
+                              "launches carry ~1-2 us of event overhead each, so all_kernels_ms slightly exceeds ms_per_step" % n_rep),
           "algorithmic_gflop_per_launch": round(dom["gflop"] / dom["launches"], 2),
           "path_3x3": {"achieved": round(path, 2), "peak": round(peak33, 1), "frac": round(path / peak33, 4), "unit": "TFLOP/s", "launches": len(LAYERS_3X3), "ms": round(t33, 4),
                        "algorithmic_gflop": round(GFLOP_3X3_PER_IMAGE * B, 2)},
@@ -356,7 +359,7 @@ def attach_traffic(rf, dom_name, B, dtype):
     from blindshadowremoval_amd.build import source_sha16
     sha = source_sha16()
     sfx = "" if dtype == "f32" else "_" + dtype
-    for tag in ("r2", "r1"):
+    for tag in ("r3", "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx))
         if not os.path.isfile(tpath):
             continue
@@ -379,6 +382,41 @@ def attach_traffic(rf, dom_name, B, dtype):
         return
 
 
+def attach_mfma(rf, dom_name, B, dtype):
+    """Matrix-pipe utilisation and the clock the chip held, for the dominant kernel, from the committed counter passes
+    (tools/pmc_mfma.py: separate rocprofv3 --pmc runs of SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE ...; profiles/r3_pmc_mfma*.json) —
+    under the same rule as `traffic`: only while the kernel sources hash to what the passes ran on.  north_star asks for "MFMA
+    utilisation against chip peak": `mfma_busy` = busy cycles / GPU-active cycles (utilisation at the clock actually held),
+    `clock_ghz` = GRBM_GUI_ACTIVE / 8 XCDs / duration; frac (of the NOMINAL 2.4 GHz peak) ~= mfma_busy x clock_ghz / 2.4 x
+    (algorithmic / issued FLOP)."""
+    from blindshadowremoval_amd.build import source_sha16
+    sha = source_sha16()
+    sfx = "" if dtype == "f32" else "_" + dtype
+    mpath = os.path.join(ROOT, "profiles", "r3_pmc_mfma%s.json" % sfx)
+    rf["mfma_busy"] = rf["clock_ghz"] = None
+    if not os.path.isfile(mpath):
+        rf["mfma_note"] = "no profiles/r3_pmc_mfma%s.json" % sfx
+        return
+    with open(mpath) as fm:
+        m = json.load(fm)
+    key = [k for g, k in GROUP_KERNEL_KEY if g in dom_name]
+    rows = [v for k, v in (m.get("per_kernel") or {}).items() if key and key[0] in k]
+    if B != m.get("batch") or m.get("kernel_src_sha16") != sha:
+        rf["mfma_note"] = ("profiles/r3_pmc_mfma%s.json was measured on kernel sources %s / batch %s, this build is %s / batch %d: not reported"
+                           % (sfx, m.get("kernel_src_sha16"), m.get("batch"), sha, B))
+    elif not rows or "mfma_busy" not in rows[0]:
+        rf["mfma_note"] = "profiles/r3_pmc_mfma%s.json has no matrix-pipe counters for the dominant kernel of this run" % sfx
+    else:
+        us = sum(r["us_per_forward"] for r in rows)
+        rf["mfma_busy"] = round(sum(r["mfma_busy"] * r["us_per_forward"] for r in rows) / us, 4)
+        rf["clock_ghz"] = round(sum(r["clock_ghz"] * r["us_per_forward"] for r in rows) / us, 3)
+        rf["mfma_busy_of_nominal_clock"] = round(sum(r["mfma_busy_nominal"] * r["us_per_forward"] for r in rows) / us, 4)
+        rf["mfma_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) and GRBM_GUI_ACTIVE / 8 / duration of the same kernel "
+                           "(profiles/r3_pmc_mfma%s.csv, separate rocprofv3 --pmc passes on kernel sources %s = this build; profiled dispatches are "
+                           "serialised and clock 2-5 %% differently from the un-profiled run; the in-kernel s_memtime / s_memrealtime clock of the "
+                           "same kernel is in profiles/r3_clock_stamps.txt)" % (sfx, sha))
+
+
 def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_parity):
     """The same workload on the split-precision path, reported BESIDE the f32 line (never as `value`): per-GPU images/s of this
     rank, its own roofline object, and (N = 1) its parity against the oracle under the fp32 tolerances."""
@@ -395,6 +433,7 @@ def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_p
     dt = time.perf_counter() - t0
     rf, dom = roofline_from_events(gen, lambda: gen(inp, uv, out=out), B, "f32x3")
     attach_traffic(rf, dom, B, "f32x3")
+    attach_mfma(rf, dom, B, "f32x3")
     res = {"dtype": "f32x3", "value": round(B * args.steps / dt, 2), "unit": "images/sec (this GPU, no collective)", "ms_per_step": round(dt / args.steps * 1e3, 4),
            "steps": args.steps, "roofline": rf,
            "note": "3x3 / stride-2 / transposed 3x3 layers on v_mfma_f32_32x32x16_f16 with operands split into hi + lo fp16 planes at LDS staging "
@@ -593,6 +632,7 @@ def run_rank(args):
             else:
                 rf, dom_name = roofline_from_events(gen, lambda: forward(0), B, args.dtype)
                 attach_traffic(rf, dom_name, B, args.dtype)
+                attach_mfma(rf, dom_name, B, args.dtype)
                 result["roofline"] = rf
             if not args.no_cpu_baseline and world == 1 and not tsm:
                 result["cpu_baseline"] = cpu_baseline(weights, gen=gen, device=dev)
