@@ -166,6 +166,8 @@ int main(int argc, char** argv) {
   if (argc > 2 && argv[2][0] == 'g') {            // only the resident-activation GEMMs
     if (run_gemm("c3q", 32768, 672, 2, false)) return 1;
     if (run_gemm("c3q+res", 32768, 672, 2, true)) return 1;
+    if (run_gemm("c3q+res/3", 32768, 672, 3, true)) return 1;
+    if (run_gemm("w/3", 32768, 288, 3, true)) return 1;
     if (run_gemm("c3q/split1", 32768, 672, 1, false)) return 1;
     if (run_gemm("w", 32768, 288, 2, true)) return 1;
     if (run_gemm("w/nores", 32768, 288, 2, false)) return 1;
