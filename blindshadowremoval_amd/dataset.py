@@ -390,9 +390,10 @@ class Dataset:
 
 
 class _SelectPool:
-    """N worker processes driven from the CALLING thread with non-blocking pipes and select() — no helper threads at all.  The
-    thread-per-worker pool below costs nothing at 40 elements per second; at a few hundred, two dozen threads waking up to read
-    and unpickle results keep taking the GIL from the loop's own thread (measured on the GPU box: host halves alone 3 900 /s, the
+    """N worker PROCESSES (`python -m blindshadowremoval_amd._row_worker`: plain subprocesses over pipes — nothing is forked from a process
+    that may hold a GPU context, and the workers do not re-import the parent's __main__), driven from the CALLING thread with
+    non-blocking pipes and select() — no helper threads at all.  Round 2's thread-per-worker pool cost nothing at 40 elements per
+    second; at a few hundred, two dozen threads waking up to read and unpickle results keep taking the GIL from the loop's own thread (measured on the GPU box: host halves alone 3 900 /s, the
     device half alone 2 300 /s, both together through the threaded pool 430 /s).  `imap(jobs, depth)` yields results in job order
     with at most `depth` jobs outstanding."""
 
@@ -488,7 +489,8 @@ class _SelectPool:
 
     def imap(self, jobs, depth: int):
         jobs = iter(jobs)
-        nxt, sent, exhausted = 0, 0, False
+        nxt = sent = self._seq          # tickets are pool-wide sequence numbers: this iteration's run from here
+        exhausted = False
         per_worker = max(1, (depth + len(self.procs) - 1) // len(self.procs))
         while True:
             while not exhausted and sent - nxt < depth:
@@ -531,76 +533,3 @@ class _SelectPool:
             except Exception:
                 p.kill()                # the exact child we started
         self.procs = []
-
-
-class _WorkerPool:
-    """N worker PROCESSES (`python -m blindshadowremoval_amd._row_worker`), each driven by one thread of a ThreadPoolExecutor
-    over a pair of pipes.  Plain subprocesses instead of multiprocessing: nothing is forked from a process that may hold a GPU
-    context, and the workers do not re-import the parent's __main__."""
-
-    def __init__(self, n: int):
-        import threading
-        from concurrent.futures import ThreadPoolExecutor
-        self._local = threading.local()
-        self._procs = []
-        self._lock = threading.Lock()
-        self._ex = ThreadPoolExecutor(max_workers=n, thread_name_prefix="bsr-row")
-
-    def _proc(self):
-        p = getattr(self._local, "proc", None)
-        if p is None:
-            import subprocess
-            import sys
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            env = dict(os.environ)
-            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-            env.setdefault("OMP_NUM_THREADS", "1")
-            env.setdefault("OPENBLAS_NUM_THREADS", "1")
-            env.setdefault("MKL_NUM_THREADS", "1")
-            env["HIP_VISIBLE_DEVICES"] = ""                    # workers are host-only: whatever they import, they get no GPU
-            env["CUDA_VISIBLE_DEVICES"] = ""
-            p = subprocess.Popen([sys.executable, "-m", "blindshadowremoval_amd._row_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
-            self._local.proc = p
-            with self._lock:
-                self._procs.append(p)
-        return p
-
-    def _run(self, job):
-        import pickle
-        import struct
-        p = self._proc()
-        payload = pickle.dumps(job, protocol=pickle.HIGHEST_PROTOCOL)
-        p.stdin.write(struct.pack("<Q", len(payload)) + payload)
-        p.stdin.flush()
-        head = p.stdout.read(8)
-        if len(head) != 8:
-            raise RuntimeError("loader worker exited (code %s)" % p.poll())
-        n = struct.unpack("<Q", head)[0]
-        buf = bytearray()
-        while len(buf) < n:
-            chunk = p.stdout.read(n - len(buf))
-            if not chunk:
-                raise RuntimeError("loader worker closed its pipe mid-result")
-            buf += chunk
-        status, value = pickle.loads(bytes(buf))
-        if status != "ok":
-            raise RuntimeError("loader worker failed: %s" % value)
-        return value
-
-    def submit(self, job):
-        return self._ex.submit(self._run, job)
-
-    def shutdown(self) -> None:
-        self._ex.shutdown(wait=True, cancel_futures=True)
-        with self._lock:
-            procs, self._procs = self._procs, []
-        for p in procs:
-            try:
-                p.stdin.close()
-            except Exception:
-                pass
-        for p in procs:
-            try:
-                p.wait(timeout=5)
-            except Exception:
-                p.kill()                # the exact child we started
