@@ -57,7 +57,14 @@ def ucb_postprocess(img0: np.ndarray, gt0: np.ndarray, con_rgb0: np.ndarray, mas
     rs = lambda a: resize_bilinear(a, size)
     gt_sc = _pad(rs(gt0), size, full)                                                      # :437,454
     pred = rs(con_rgb0)                                                                    # :438
-    m = {k: _pad(np.round(rs(v)), size, full).astype(np.float32) for k, v in masks.items()}   # :439-471 (round-half-even, as tf.round)
+    # :439-471: the seven masks, resized and rounded (round-half-even, as tf.round).  They come from cv2.imread of grey PNGs — three
+    # IDENTICAL channels — so one channel of each is resized (all seven in one call) and repeated; any other input takes the plain path
+    keys = list(masks)
+    if all(v.shape[2] == 3 and np.array_equal(v[..., 0], v[..., 1]) and np.array_equal(v[..., 0], v[..., 2]) for v in masks.values()):
+        mr = np.round(rs(np.stack([masks[k][:, :, 0] for k in keys], axis=2).astype(np.float32)))
+        m = {k: _pad(np.repeat(mr[..., i:i + 1], 3, axis=2), size, full).astype(np.float32) for i, k in enumerate(keys)}
+    else:
+        m = {k: _pad(np.round(rs(v)), size, full).astype(np.float32) for k, v in masks.items()}
     face_hair, face, mouth, nose, brow = m["face_hair"], m["face"], m["mouth"], m["nose"], m["eyebrow"]
     tmp = _pad(rs(img0), size, full)                                                       # :456-458
     mp = _pad(rs(mask_pred0), size, full) * face_hair                                      # :473-477, now 3 channels
