@@ -59,8 +59,8 @@ Other round-3 artefacts (this block is written by `tools/r3_readme.py` from the 
   FFHQ (`FSRNet.testFFHQ`, batch 16): serial loader %.1f, 16 loader processes %.1f, **device-side preparation %.0f images/s** (1 000 items: rows
   prepared by `bsr_prep_rows` from host triangulations, PNG strips assembled on the device, PNG worker processes; 850-1 240 over the
   round's boxes and worker counts).  UCB (`FSRNet.test`, the 100 distinct items repeated to 1 000, seven masks each, SSIM / PSNR): %.1f -> %.1f ->
-  **%.0f images/s** (150-230 over the round): the reference's per-item post-processing costs ~57 ms of one CPU, so %d CPUs cap this loop near
-  250 images/s whatever the GPU does.  Round 2: 39.9 / 19.4 images/s.
+  **%.0f images/s** (150-230 over the round): the reference's per-item post-processing costs ~42 ms of one CPU (57 before its SSIM / mask-resize
+  diet), so %d CPUs cap this loop near 350 images/s whatever the GPU does.  Round 2: 39.9 / 19.4 images/s.
 <!-- END r3 NOTES -->''' % (
     dom["clock_ghz"], 100 * dom["mfma_busy"], 100 * dom["mfma_busy_nominal"], b["roofline"]["frac"], 100 * row("nonlocal_attention")["mfma_busy"],
     100 * row("<3, 3, 1, false")["mfma_busy"], 100 * row("gemm_nloop")["mfma_busy"], 100 * mf["forward"]["mfma_busy_time_weighted"],
