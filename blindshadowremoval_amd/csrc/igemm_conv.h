@@ -28,6 +28,7 @@
 #define BSR_PAIR_S2 1
 #endif
 
+
 namespace bsr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -92,6 +93,7 @@ struct ConvArgs {
   unsigned* range_flag; // 16-bit kernels: set to 1 when a staged activation does not fit fp16 (|x| >= 65520); may be null
 #ifdef BSR_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
+  unsigned long long* stamps2;  // diagnostic build only: per-step timeline of 64 mid-kernel workgroups (1024 .. 1087): [block][wave][step][3] = step start, matrix work done, barrier passed
 #endif
 };
 
@@ -294,6 +296,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int s = ch * T + t;
+#ifdef BSR_STAMPS
+      const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
       const bool has1 = s + 1 < nsteps, has2 = s + 2 < nsteps;
       constexpr bool kRing1x1 = (T == 1 && INB == 3);
       // input tiles stream from HBM (weights are L2 hits): issue their loads up to three taps before they are needed
@@ -348,7 +353,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
       }
 
       // (3) one barrier per step publishes what was staged and frees the slot read in this step
+#ifdef BSR_STAMPS
+      const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+#ifdef BSR_STAMPS
+      if (p.stamps2 != nullptr && lane == 0 && blockIdx.y == 0 && blockIdx.x >= 1024 && blockIdx.x < 1088) {
+        unsigned long long* d2 = p.stamps2 + (((size_t)(blockIdx.x - 1024) * (WM * WN) + wave) * nsteps + s) * 3;
+        d2[0] = ts0; d2[1] = ts1; d2[2] = __builtin_amdgcn_s_memtime();
+      }
+#endif
       if (INB == 1 && t == T - 1 && more) {          // single input buffer: swap it between chunks (2 barriers)
         if constexpr (PAIR) {
           if (ch & 1) store_in(0, in_regs); else store_in(0, in_regs2);

@@ -34,6 +34,9 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   unsigned long long* d_st;
   CK(hipMalloc(&d_st, nblk * NW * 4 * 8));
   a.stamps = d_st;
+  const int nsteps_h = nchunk * T;
+  unsigned long long* d_st2; CK(hipMalloc(&d_st2, (size_t)64 * NW * nsteps_h * 3 * 8)); CK(hipMemset(d_st2, 0, (size_t)64 * NW * nsteps_h * 3 * 8));
+  a.stamps2 = getenv("BSR_TIMELINE") ? d_st2 : nullptr;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e9;
   const int iters = getenv("BSR_ITERS") ? atoi(getenv("BSR_ITERS")) : 6;      // many back-to-back launches = the sustained clock
@@ -63,7 +66,23 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   double mfma_per_wave = (double)nchunk * T * (CC / 2) * NI;       // MFMAs a wave issues
   printf("%-10s %7.1f us  %6.1f TFLOP/s | blocks %zu, per wave (cycles): prologue %.0f  loop %.0f  epilogue %.0f (issue %.0f) | loop ticks per MFMA %.2f\n",
          name, best * 1e3, flops / best / 1e9, nblk, pro / nw, loop / nw, epi / nw, epi_issue / nw, loop / nw / mfma_per_wave);
-  hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_st);
+  if (getenv("BSR_TIMELINE") && nblk >= 1088) {      // per-step timeline of 64 mid-kernel workgroups: matrix phase and barrier wait per step
+    std::vector<unsigned long long> t2((size_t)64 * NW * nsteps_h * 3);
+    CK(hipMemcpy(t2.data(), d_st2, t2.size() * 8, hipMemcpyDeviceToHost));
+    double work = 0, wait = 0, gap = 0; size_t n = 0, ng = 0;
+    std::vector<double> works;
+    for (size_t bw = 0; bw < (size_t)64 * NW; ++bw)
+      for (int st = 0; st < nsteps_h; ++st) {
+        const unsigned long long* e = &t2[(bw * nsteps_h + st) * 3];
+        if (e[2] == 0) continue;
+        work += (double)(e[1] - e[0]); wait += (double)(e[2] - e[1]); works.push_back((double)(e[1] - e[0])); ++n;
+        if (st + 1 < nsteps_h) { const unsigned long long* f = e + 3; if (f[2] != 0) { gap += (double)(f[0] - e[2]); ++ng; } }
+      }
+    std::sort(works.begin(), works.end());
+    printf("   timeline (%zu steps): matrix phase %.0f cycles avg (p10 %.0f, p50 %.0f, p90 %.0f; %d MFMAs -> %.1f per MFMA), barrier wait %.0f, between steps %.0f\n", n, work / n,
+           works[n / 10], works[n / 2], works[n * 9 / 10], (CC / 2) * NI, work / n / ((CC / 2) * NI), wait / n, gap / (ng ? ng : 1));
+  }
+  hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_st); hipFree(d_st2);
   return 0;
 }
 
