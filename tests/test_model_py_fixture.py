@@ -8,6 +8,7 @@ KAT-checked primitives in float64 (parity stays "unpinned" for SURVEY A.1-A.7). 
 stand-in, so an agreement to ~1e-5 means two independent restatements driven by two different control flows (ours, the
 reference's) coincide."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -90,3 +91,38 @@ def test_hip_tsm_reproduces_reference_model_with_tsm_py():
     for o, n in zip(out, NAMES):
         assert float(np.abs(o - z[n]).max()) < 1e-3, n
     gen.close()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="imports the reference's model.py (build container only)")
+@pytest.mark.parametrize("variant", ["gsc", "tsm"])
+def test_tf_backend_driver_dry_run_over_mock_tensorflow(variant, monkeypatch):
+    """`tools/make_model_fixture.py --backend tf` cannot run here (no TensorFlow), but its DRIVER can: over a mock `tensorflow` module
+    that has Keras' variable mechanics (variables created on the first call, `model.variables`, `.assign`) and the stand-in's
+    arithmetic, the tf code path — build by one forward, assignment through the checkpoint attribute paths incl. `res_stack/<i>/...`,
+    the every-variable-assigned check, the keyword call of the reference's call sites, the d32 spy on `tf.image.resize` — must
+    reproduce the committed stand-in fixture exactly.  This is a test of the tool's logic, not a pin of TensorFlow's arithmetic."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_model_fixture", os.path.join(root, "tools", "make_model_fixture.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    monkeypatch.setenv("BSR_MOCK_TF", "1")
+    z = _load("model_py_%s_64.npz" % variant)
+    w = init_weights(int(z["weights_seed"]), variant=variant)
+    inp, uv = z["inputs"].astype(np.float32), z["uv"].astype(np.float32)
+    if variant == "gsc":
+        args = (inp, uv, None, 1, False)
+        outs, probes, backend = tool.run_reference_tf("model.py", w, args)
+    else:
+        args = (inp, uv, z["reg"].astype(np.float32), int(z["frame"]), True, 1, False)
+        outs, probes, backend = tool.run_reference_tf("model_with_TSM.py", w, args)
+    assert backend == "tf-mock"
+    assert getattr(sys.modules.get("tensorflow"), "__version__", "") != "mock"          # the mock does not outlive the call
+    for o, n in zip(outs, NAMES):
+        assert np.array_equal(o.astype(np.float32), z[n]), n
+    assert np.array_equal(probes["d32"].astype(np.float32), z["d32"])
+    # a checkpoint name that does not exist in the model, or a model variable that no name covers, must fail loudly
+    bad = dict(w)
+    bad.pop("conv1/conv/bias")
+    with pytest.raises(RuntimeError, match="variables"):
+        tool.run_reference_tf("model.py" if variant == "gsc" else "model_with_TSM.py", bad, args)

@@ -302,9 +302,115 @@ def run_reference(module_file, weights, call_args, call_kwargs=None):
     return [np.asarray(o) for o in outs]
 
 
+# ------------------------------------------------------------------------------------------------ mock TensorFlow (dry run of the tf backend)
+class Variable:
+    """What the tf backend touches of a tf.Variable: shape, assign(), ref(), numpy(); array-like for the stand-in arithmetic."""
+
+    def __init__(self, shape):
+        self.value = np.zeros(shape, np.float64)
+
+    @property
+    def shape(self):
+        return self.value.shape
+
+    def assign(self, v):
+        v = np.asarray(v)
+        assert v.shape == self.value.shape, (v.shape, self.value.shape)
+        self.value = v.astype(np.float64)
+
+    def ref(self):
+        return id(self)
+
+    def numpy(self):
+        return self.value
+
+    def __array__(self, dtype=None, copy=None):
+        return self.value if dtype is None else self.value.astype(dtype)
+
+
+def make_mock_tf_module():
+    """The stand-in of make_tf_module() with Keras' VARIABLE mechanics added — layers create their variables on the first call,
+    `model.variables` walks the attribute tree (lists included), `tf.constant`, `tf.__version__` — so that run_reference_tf's driver
+    logic (build by one forward, assignment through the checkpoint attribute paths, the every-variable-assigned check, the keyword
+    call, the d32 spy on tf.image.resize) can be exercised WITHOUT TensorFlow (tests/test_model_py_fixture.py, BSR_MOCK_TF=1).  Same
+    arithmetic as the stand-in, so the outputs must equal the committed stand-in fixtures bit for bit."""
+    mods = make_tf_module()
+    tf, layers = mods["tensorflow"], mods["tensorflow.keras.layers"]
+
+    def _walk(obj, seen, out):
+        if id(obj) in seen:
+            return
+        seen.add(id(obj))
+        if isinstance(obj, Variable):
+            out.append(obj)
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                _walk(o, seen, out)
+        elif isinstance(obj, Layer):
+            for v in vars(obj).values():
+                _walk(v, seen, out)
+
+    class MockLayer(Layer):
+        @property
+        def variables(self):
+            out = []
+            _walk(self, set(), out)
+            return out
+
+    class MConv2D(MockLayer, Conv2D):
+        def call(self, x):
+            if self.kernel is None:
+                self.kernel, self.bias = Variable(self.ksize + (x.shape[-1], self.filters)), Variable((self.filters,))
+            return t(P.conv2d_same(np.asarray(x), np.asarray(self.kernel), np.asarray(self.bias), self.strides[0]))
+
+    class MConv2DTranspose(MockLayer, Conv2DTranspose):
+        def call(self, x):
+            if self.kernel is None:
+                self.kernel, self.bias = Variable((3, 3, self.filters, x.shape[-1])), Variable((self.filters,))
+            return t(P.conv2d_transpose_same(np.asarray(x), np.asarray(self.kernel), np.asarray(self.bias)))
+
+    class MBatchNormalization(MockLayer, BatchNormalization):
+        def call(self, x, training=None):
+            if self.gamma is None:
+                c = (x.shape[-1],)
+                self.gamma, self.beta, self.moving_mean, self.moving_variance = Variable(c), Variable(c), Variable(c), Variable(c)
+                self.gamma.assign(np.ones(c))
+                self.moving_variance.assign(np.ones(c))
+            assert training is False
+            return t(P.batchnorm(np.asarray(x), *(np.asarray(v) for v in (self.gamma, self.beta, self.moving_mean, self.moving_variance))))
+
+    class MLeakyReLU(MockLayer, LeakyReLU):
+        pass
+
+    for name, cls in (("Layer", MockLayer), ("Conv2D", MConv2D), ("Conv2DTranspose", MConv2DTranspose), ("BatchNormalization", MBatchNormalization),
+                      ("LeakyReLU", MLeakyReLU)):
+        setattr(layers, name, cls)
+    tf.keras.Model = MockLayer
+    tf.constant = lambda a, dtype=None: t(np.asarray(a, np.float64))
+    tf.__version__ = "mock"
+    return mods
+
+
 # ------------------------------------------------------------------------------------------------ real-TensorFlow backend
 def run_reference_tf(module_file, weights, call_args):
-    """The reference's module UNMODIFIED over real TensorFlow.  Returns ([gs, con_rgb, mask22, dif], {"d32": ...}, "tf-<version>")."""
+    """The reference's module UNMODIFIED over real TensorFlow.  Returns ([gs, con_rgb, mask22, dif], {"d32": ...}, "tf-<version>").
+    BSR_MOCK_TF=1 runs the same driver over make_mock_tf_module() (a dry run of THIS function's logic, not a pin)."""
+    mock = os.environ.get("BSR_MOCK_TF") == "1"
+    if mock:
+        saved = {k: sys.modules.get(k) for k in ("tensorflow", "tensorflow.keras", "tensorflow.keras.layers", "tensorflow_addons", "cv2")}
+        sys.modules.update(make_mock_tf_module())
+    try:
+        return _run_reference_tf(module_file, weights, call_args)
+    finally:
+        if mock:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+
+
+def _run_reference_tf(module_file, weights, call_args):
     try:
         import tensorflow as tf
     except ImportError as e:                                            # the build container: no TensorFlow
@@ -367,7 +473,7 @@ def run_reference_tf(module_file, weights, call_args):
             outs = gen(*args, **kwargs)
     finally:
         tf.image.resize = orig
-    return [np.asarray(o.numpy(), np.float64) for o in outs], probes, "tf-" + tf.__version__
+    return [np.asarray(o.numpy(), np.float64) for o in outs], {k: np.asarray(v) for k, v in probes.items()}, "tf-" + tf.__version__
 
 
 BACKEND = "standin"
