@@ -268,3 +268,27 @@ def test_ucb_full_set_100_items(tmp_path, golden_dir):
     assert worst["mask_px"] <= 3 * 8 and worst["ssim"] < 1e-3 and worst["psnr"] < 1e-3
     fsr.close()
     host.close()
+
+
+def test_select_pool_png_jobs_through_shared_memory(tmp_path):
+    """The worker pool the loops use (dataset._SelectPool): a batch of PNG strips parked in ONE shared-memory file, one job per strip,
+    results collected by ticket — no helper threads, no megabytes through the pipes."""
+    from PIL import Image
+    from blindshadowremoval_amd.fsrnet import _shm_file
+    rng = np.random.default_rng(3)
+    strips = (rng.random((5, 32, 96, 3)) * 255).astype(np.uint8)
+    shm = _shm_file("bsr_test_")
+    try:
+        strips.tofile(shm)
+        pool = D._SelectPool(2)
+        pool.warm("rows")
+        tickets = [pool.submit(("png", os.path.join(str(tmp_path), "s%d.png" % j), (shm, strips.shape, j))) for j in range(5)]
+        assert [pool.result(t) for t in reversed(tickets)] == [True] * 5          # any collection order
+        bad = pool.submit(("png", os.path.join(str(tmp_path), "x.png"), (shm + ".missing", strips.shape, 0)))
+        with pytest.raises(RuntimeError, match="worker failed"):
+            pool.result(bad)
+        pool.shutdown()
+    finally:
+        os.unlink(shm)
+    for j in range(5):
+        assert np.array_equal(np.asarray(Image.open(os.path.join(str(tmp_path), "s%d.png" % j))), strips[j])

@@ -686,3 +686,13 @@ def test_packed_output_is_bit_identical(gen_w):
     assert torch.equal(packed, torch.cat((a[1], a[3]), dim=3))
     with pytest.raises(ValueError):
         gen(inp, uv, packed_out=packed[:4])
+
+
+def test_smallest_accepted_image(gen_w):
+    """H = 32 is the smallest height the C ABI accepts with W = 256 (128 attention tokens, one 4x32 tile row at 1/8 resolution)."""
+    from parity_util import run_and_compare
+    gen, w = gen_w
+    torch.manual_seed(91)
+    inp, uv = torch.rand(3, 32, 256, 3), torch.rand(3, 32, 256, 3)
+    out, ref, errs, nflip = run_and_compare(gen, w, inp, uv, want_probes=("x0", "res2", "res5"))
+    assert out[0].shape == (3, 32, 256, 1)

@@ -96,3 +96,39 @@ def test_device_rows_match_the_reference_fixture_and_the_host_path(golden_dir):
     for i, ref in enumerate(host_rows):
         err = np.abs(out[i] - ref).max(axis=(0, 1))
         assert np.isfinite(out[i]).all() and err.max() <= 1e-6, (i, err)
+
+
+def _border_case(tmp_path):
+    """A synthetic image whose landmarks hug the top-left corner: the crop box leaves the image on two sides (zero extension,
+    utils.py:414-425)."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    img = (rng.random((200, 240, 3)) * 255).astype(np.uint8)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_02165.npz"))
+    lm0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_imgs", "02165", "02165.npy")).astype(np.float32)
+    lm = (lm0 - lm0.min(0)) * 0.55 + np.float32(4.0)            # face squeezed into the corner: box starts at negative coordinates
+    base = os.path.join(str(tmp_path), "corner")
+    Image.fromarray(img).save(base + ".png")
+    np.save(base + ".npy", lm)
+    return base
+
+
+def test_zero_extended_crop_matches_the_host_path(tmp_path):
+    base = _border_case(tmp_path)
+    part = prep.host_part((base + ".npy", None, 256))
+    assert part[2][0] < 0 and part[2][1] < 0                      # the box really leaves the image
+    row_host, box_host = D.build_row(base + ".png", base + ".npy", None, 256)
+    assert np.array_equal(part[2].astype(np.float32), box_host)
+    err = np.abs(emulate(part, 256) - row_host).max(axis=(0, 1))
+    assert err.max() <= 1e-6, err
+
+
+@pytest.mark.gpu
+def test_device_zero_extended_crop(tmp_path):
+    import torch
+    base = _border_case(tmp_path)
+    row_host, _ = D.build_row(base + ".png", base + ".npy", None, 256)
+    out, _ = prep.DevicePrep(0, 256).rows([prep.host_part((base + ".npy", None, 256))])
+    torch.cuda.synchronize()
+    err = np.abs(out[0].cpu().numpy() - row_host).max(axis=(0, 1))
+    assert err.max() <= 1e-6, err
