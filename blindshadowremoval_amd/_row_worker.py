@@ -41,14 +41,13 @@ def main() -> int:
                 result = True
             elif isinstance(job, tuple) and job and job[0] == "png":                 # ("png", path, uint8 strip | (shm file, shape, index)): Logging(png_workers=N)
                 import numpy as np
-                from PIL import Image
+                from blindshadowremoval_amd.pngio import write_png
                 strip = job[2]
                 if isinstance(strip, tuple):                                         # one strip of a batch the parent parked in shared memory
                     shm, shape, idx = strip
                     n = int(np.prod(shape[1:]))
                     strip = np.fromfile(shm, np.uint8, count=n, offset=idx * n).reshape(shape[1:])
-                os.makedirs(os.path.dirname(job[1]), exist_ok=True)
-                Image.fromarray(strip).save(job[1], compress_level=1)
+                write_png(job[1], strip)
                 result = True
             elif isinstance(job, tuple) and job and job[0] == "ucb_post":
                 from blindshadowremoval_amd.ucb_post import run_post_job

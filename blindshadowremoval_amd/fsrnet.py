@@ -194,8 +194,8 @@ class Logging(object):
 
     @staticmethod
     def _write_png(strip: np.ndarray, out: str) -> None:
-        from PIL import Image
-        Image.fromarray(strip).save(out, compress_level=1)        # cv2.imwrite's default PNG compression is 1 (fastest); pixels are identical
+        from .pngio import write_png
+        write_png(out, strip)                                     # cv2.imwrite's defaults (Sub filter, RLE strategy, level 1); pixels are identical
 
     def flush(self) -> None:
         """Wait for every queued PNG (re-raises a writer's exception)."""

@@ -39,16 +39,18 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
         modes = [("serial_loader", dict(workers=0), {}), ("pooled_loader", dict(workers=workers), {}),
                  # round 3: rows prepared ON THE DEVICE (prep.py: the workers only decode PNGs and triangulate), PNG strips assembled
                  # on the device, UCB post-processing in worker processes one batch behind the GPU
-                 # worker counts from sweeps on the GPU box (16-CPU quota): loader ~1 per usable CPU, PNG 3/4 of that; UCB: loader 3/4, post 2x
-                 ("device_prep", dict(workers=max(2, ncpu * 3 // 4) if ucb else max(2, ncpu), device_prep=fsr.gen._device, device_batch=batch),
-                  dict(post_workers=max(2, 2 * ncpu), png_workers=max(2, ncpu * 3 // 4)))]
+                 # worker counts from sweeps on the GPU box (16-CPU quota): loader ~1 per usable CPU, PNG 3/4 of that; UCB: loader 1/2,
+                 # post 5/4 (the post-processing alone peaks at ONE process per usable CPU — scratch/post_scaling.py), three batches in flight
+                 ("device_prep", dict(workers=max(2, ncpu // 2) if ucb else max(2, ncpu), device_prep=fsr.gen._device, device_batch=batch),
+                  dict(post_workers=max(2, ncpu * 5 // 4), png_workers=max(2, ncpu * 3 // 4), post_inflight=3))]
         for label, ds_kw, fsr_kw in modes:
             ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
             fsr.post_workers = fsr_kw.get("post_workers", 0)
+            fsr.post_inflight = fsr_kw.get("post_inflight", fsr.post_inflight)
             fsr.return_figs = not fsr_kw                                 # the device_prep mode measures the loop as a user who wants the PNGs + metrics runs it
             fsr.log.png_workers = fsr_kw.get("png_workers", 0)
             base = list(ds.name_list)
-            n_items = items * (10 if fsr_kw else 1)                      # the fast mode needs a longer list for a steady-state rate
+            n_items = items * ((10 if ucb else 20) if fsr_kw else 1)     # the fast mode needs a longer list for a steady-state rate (~2-4 s of loop)
             reps = (n_items + len(base) - 1) // len(base)
             ds.name_list = (base * reps)[:n_items]
             # item i of the repeated list is evaluated against mask i of the equally repeated mask list (FSRNet.test indexes strictly)

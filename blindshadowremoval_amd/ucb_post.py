@@ -48,7 +48,7 @@ def _bbox(mask2d: np.ndarray) -> Tuple[int, int, int, int]:
 
 def ucb_postprocess(img0: np.ndarray, gt0: np.ndarray, con_rgb0: np.ndarray, mask_pred0: np.ndarray, box: np.ndarray,
                     masks: Dict[str, np.ndarray]) -> Tuple[Dict[str, float], List[np.ndarray]]:
-    """img0 / gt0 / con_rgb0: [S,S,3]; mask_pred0: [S,S,1] (the generator's `dif`); box: [4]; masks: the seven [S,S,3]
+    """img0 / gt0 / con_rgb0: [S,S,3]; mask_pred0: [S,S,1] (the generator's `dif`); box: [4]; masks: the seven [S,S,3] (or, from read_masks(grey=True), [S,S,1])
     {0,1} maps of MASK_DIRS.  Returns ({'ssim','psnr'}, figs) with figs as in train_test_GSC.py:744: input, composite,
     2 x gated magnitude, ground truth, detected shadow mask, full prediction, nose image — each [1,S,S,3] float32."""
     full = img0.shape[0]
@@ -60,7 +60,8 @@ def ucb_postprocess(img0: np.ndarray, gt0: np.ndarray, con_rgb0: np.ndarray, mas
     # :439-471: the seven masks, resized and rounded (round-half-even, as tf.round).  They come from cv2.imread of grey PNGs — three
     # IDENTICAL channels — so one channel of each is resized (all seven in one call) and repeated; any other input takes the plain path
     keys = list(masks)
-    if all(v.shape[2] == 3 and np.array_equal(v[..., 0], v[..., 1]) and np.array_equal(v[..., 0], v[..., 2]) for v in masks.values()):
+    grey = all(v.shape[2] == 1 for v in masks.values())                                    # read_masks(grey=True): one channel, known to stand for three equal ones
+    if grey or all(v.shape[2] == 3 and np.array_equal(v[..., 0], v[..., 1]) and np.array_equal(v[..., 0], v[..., 2]) for v in masks.values()):
         mr = np.round(rs(np.stack([masks[k][:, :, 0] for k in keys], axis=2).astype(np.float32)))
         m = {k: _pad(np.repeat(mr[..., i:i + 1], 3, axis=2), size, full).astype(np.float32) for i, k in enumerate(keys)}
     else:
@@ -146,13 +147,14 @@ def ucb_postprocess(img0: np.ndarray, gt0: np.ndarray, con_rgb0: np.ndarray, mas
     return losses, [np.asarray(f, np.float32).reshape(1, full, full, 3) for f in figs]
 
 
-def read_masks(paths: Dict[str, str]) -> Dict[str, np.ndarray]:
-    """The seven mask images of one item: cv2.imread(...)/255.0, three equal channels (train_test_GSC.py:386-393)."""
+def read_masks(paths: Dict[str, str], grey: bool = False) -> Dict[str, np.ndarray]:
+    """The seven mask images of one item: cv2.imread(...)/255.0, three equal channels (train_test_GSC.py:386-393).  grey=True keeps
+    ONE channel ([S,S,1]), which ucb_postprocess expands itself after the resize — same values, a third of the copies."""
     from PIL import Image
     out = {}
     for k, path in paths.items():
         a = np.asarray(Image.open(path).convert("L"), np.float64) / 255.0
-        out[k] = np.repeat(a[:, :, None], 3, axis=2)
+        out[k] = a[:, :, None] if grey else np.repeat(a[:, :, None], 3, axis=2)
     return out
 
 
@@ -165,11 +167,10 @@ def run_post_job(job: dict):
         a = np.fromfile(job["shm"], np.float32, count=n, offset=idx * n * 4).reshape(shape[1:])
         job = dict(job, im=a[..., 0:3], gt=a[..., 3:6], con=a[..., 6:9], mp=a[..., 9:10])
     with np.errstate(invalid="ignore", divide="ignore"):
-        losses, figs = ucb_postprocess(job["im"], job["gt"], job["con"], job["mp"], job["box"], read_masks(job["masks"]))
+        losses, figs = ucb_postprocess(job["im"], job["gt"], job["con"], job["mp"], job["box"], read_masks(job["masks"], grey=True))
     if job.get("png"):
-        from PIL import Image
+        from .pngio import write_png
         cols = [np.clip(f[0], 0.0, 1.0) * np.float32(255) for f in figs]
         strip = np.rint(np.concatenate(cols, axis=1)).astype(np.uint8)           # = fsrnet.Logging.get_imgs
-        os.makedirs(os.path.dirname(job["png"]), exist_ok=True)
-        Image.fromarray(strip).save(job["png"], compress_level=1)
+        write_png(job["png"], strip)
     return losses, (figs if job.get("return_figs", True) else None)

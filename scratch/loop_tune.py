@@ -27,10 +27,19 @@ ds.warm()
 fsr.log.warm()
 if ucb:
     fsr.warm_pools()
+prof = None
+if os.environ.get("BSR_PROFILE"):
+    import cProfile
+    prof = cProfile.Profile()
+    prof.enable()
 t0 = time.perf_counter()
 with contextlib.redirect_stdout(io.StringIO()):
     out = fsr.test(ds, batch=16, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=16)
 dt = time.perf_counter() - t0
+if prof is not None:
+    import pstats
+    prof.disable()
+    pstats.Stats(prof).sort_stats("tottime").print_stats(28)
 tm = fsr.timings
 print(kind, "workers", workers, "png", png_threads, "post", post_workers, "inflight", inflight, "switch_us", switch_us, "->", round(len(out) / dt, 1), "img/s; steady",
       round((len(out) - 16) / (dt - tm["first_batch_done_s"]), 1), {k: round(v, 2) for k, v in tm.items() if k.endswith("_s")})

@@ -40,3 +40,15 @@ def test_resize_is_tf_half_pixel_bilinear():
     np.testing.assert_allclose(y[:, :, 0], [[2.5, 4.5], [10.5, 12.5]])
     z = resize_bilinear(x, 8)                        # up-sampling clamps at the border
     assert z.shape == (8, 8, 1) and z[0, 0, 0] == 0.0 and z[-1, -1, 0] == 15.0
+
+
+def test_single_channel_masks_give_the_same_result():
+    """run_post_job reads the masks as ONE channel (read_masks(grey=True)); ucb_postprocess must not care."""
+    key, row, box, masks, con, dif = next(iter(cases()))
+    grey = {k: v[:, :, 0:1] for k, v in masks.items()}
+    with np.errstate(invalid="ignore", divide="ignore"):
+        l3, f3 = ucb_postprocess(row[..., 0:3], row[..., 3:6], con, dif, box, masks)
+        l1, f1 = ucb_postprocess(row[..., 0:3], row[..., 3:6], con, dif, box, grey)
+    assert l1 == l3
+    for a, b in zip(f1, f3):
+        np.testing.assert_array_equal(a, b)

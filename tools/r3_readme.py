@@ -56,11 +56,15 @@ Other round-3 artefacts (this block is written by `tools/r3_readme.py` from the 
 * `r3_bench_tsm512.json` / `_f32x3` — BASELINE configs[4] per-rank shape (8 frames of 512x512, TSM generator, frame = 2): %.0f frames/s at f32, %.0f at f32x3.
 * `r3_loop_ffhq.json` / `r3_loop_ucb.json` — `python bench.py --loop ffhq|ucb`: the reference's test loops END TO END (input preparation ->
   forward -> post-processing -> PNG strips) on the GPU box, whose container is limited to **%d CPUs by its cgroup quota** (it shows 256).
-  FFHQ (`FSRNet.testFFHQ`, batch 16): serial loader %.1f, 16 loader processes %.1f, **device-side preparation %.0f images/s** (1 000 items: rows
-  prepared by `bsr_prep_rows` from host triangulations, PNG strips assembled on the device, PNG worker processes; 850-1 240 over the
-  round's boxes and worker counts).  UCB (`FSRNet.test`, the 100 distinct items repeated to 1 000, seven masks each, SSIM / PSNR): %.1f -> %.1f ->
-  **%.0f images/s** (150-230 over the round): the reference's per-item post-processing costs ~42 ms of one CPU (57 before its SSIM / mask-resize
-  diet), so %d CPUs cap this loop near 350 images/s whatever the GPU does.  Round 2: 39.9 / 19.4 images/s.
+  FFHQ (`FSRNet.testFFHQ`, batch 16): serial loader %.1f, 16 loader processes %.1f, **device-side preparation %.0f images/s** (2 000 items: rows
+  prepared by `bsr_prep_rows` from host triangulations, PNG strips assembled on the device, PNG worker processes; 940-1 380 over the
+  round's boxes).  UCB (`FSRNet.test`, the 100 distinct items repeated to 1 000, seven masks each, SSIM / PSNR): %.1f -> %.1f ->
+  **%.0f images/s** (265-300 over the boxes).  Both loops are bound by the CPU quota, and the largest CPU item of both was PIL's PNG encoder
+  (15-50 ms per strip): `pngio.py` writes the strips the way cv2.imwrite does by default (Sub filter as one numpy subtraction, zlib level 1
+  with the run-length strategy) — same file size, 2-3x faster; UCB 241 -> 275-300 on one box (A/B through `BSR_PNG_WRITER=pil`), FFHQ 926 before (another
+  box) -> 1 140-1 380.  The reference's per-item UCB post-processing now costs 27 ms of one CPU (36 with PIL's encoder, 57 before the SSIM /
+  mask-resize diet) and scales to 438 items/s at one process per usable CPU with nothing else running (`scratch/post_scaling.py`), so %d CPUs
+  shared with the loader cap this loop near 300 images/s whatever the GPU does.  Round 2: 39.9 / 19.4 images/s.
 <!-- END r3 NOTES -->''' % (
     dom["clock_ghz"], 100 * dom["mfma_busy"], 100 * dom["mfma_busy_nominal"], b["roofline"]["frac"], 100 * row("nonlocal_attention")["mfma_busy"],
     100 * row("<3, 3, 1, false")["mfma_busy"], 100 * row("gemm_nloop")["mfma_busy"], 100 * mf["forward"]["mfma_busy_time_weighted"],
