@@ -18,6 +18,7 @@ with a stand-in generator (tests/test_bench_cpu.py): it checks the launcher, sha
 bookkeeping and the JSON contract, and is labelled `"stub": true` — never a measurement.
 """
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -417,25 +418,37 @@ def attach_mfma(rf, dom_name, B, dtype):
                            "same kernel is in profiles/r3_clock_stamps.txt)" % (sfx, sha))
 
 
-def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_parity):
+def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_parity, lanes=None):
     """The same workload on the split-precision path, reported BESIDE the f32 line (never as `value`): per-GPU images/s of this
     rank, its own roofline object, and (N = 1) its parity against the oracle under the fp32 tolerances."""
     import torch
     from blindshadowremoval_amd import Generator
     gen = Generator(device=device, dtype="f32x3").load_weights(weights)
-    for _ in range(args.warmup):
-        gen(inp, uv, out=out)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gen(inp, uv, out=out)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def region(gens_, lanes_, outs_):
+        for i in range(args.warmup + args.steps):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            k = i % len(gens_)
+            with (torch.cuda.stream(lanes_[k]) if lanes_[k] is not None else contextlib.nullcontext()):
+                gens_[k](inp, uv, out=outs_[k])
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    dt_serial = region([gen], [None], [out])
+    dt = dt_serial
+    two = lanes is not None and len(lanes) > 1 and lanes[0] is not None
+    if two:                                             # as the f32 line: two forwards in flight on two handles / streams
+        gen_b = Generator(device=device, dtype="f32x3").load_weights(weights)
+        out_b = tuple(torch.empty_like(t) for t in out)
+        dt = region([gen, gen_b], list(lanes[:2]), [out, out_b])
+        gen_b.close()
     rf, dom = roofline_from_events(gen, lambda: gen(inp, uv, out=out), B, "f32x3")
     attach_traffic(rf, dom, B, "f32x3")
     attach_mfma(rf, dom, B, "f32x3")
     res = {"dtype": "f32x3", "value": round(B * args.steps / dt, 2), "unit": "images/sec (this GPU, no collective)", "ms_per_step": round(dt / args.steps * 1e3, 4),
-           "steps": args.steps, "roofline": rf,
+           "steps": args.steps, "forwards_in_flight": 2 if two else 1,
+           "single_stream": {"value": round(B * args.steps / dt_serial, 2), "ms_per_step": round(dt_serial / args.steps * 1e3, 4)}, "roofline": rf,
            "note": "3x3 / stride-2 / transposed 3x3 layers on v_mfma_f32_32x32x16_f16 with operands split into hi + lo fp16 planes at LDS staging "
                    "(three instructions per K group, fp32 accumulate); every other kernel is the fp32 one; activations stay fp32 in HBM"}
     if with_parity:
@@ -481,6 +494,8 @@ def run_rank(args):
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+
+    def init_group():
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -500,6 +515,16 @@ def run_rank(args):
         from blindshadowremoval_amd import Generator, GeneratorTSM, init_weights
         weights = init_weights(1, variant="tsm" if tsm else "gsc")
         gen = (GeneratorTSM if tsm else Generator)(device=local_rank, dtype=args.dtype).load_weights(weights)
+    # Steps are independent forwards: with --streams 2 step i runs on handle / stream i & 1 (its own workspace, the same weights), two
+    # in flight.  Each launch of the 1/8-resolution trunk is ONE round of workgroups; alone on the chip its tail and the next launch's
+    # ramp idle most CUs, a second forward's kernels fill them (scratch/two_stream.py: +4 % at f32, +8 % at f32x3).
+    nlanes = args.streams if on_gpu else 1
+    gens = [gen]
+    lanes, lanes_verified = [None], True
+    if nlanes > 1:
+        gens += [(GeneratorTSM if tsm else Generator)(device=local_rank, dtype=args.dtype).load_weights(weights) for _ in range(nlanes - 1)]
+        from blindshadowremoval_amd.lanes import concurrent_streams
+        lanes, lanes_verified = concurrent_streams(local_rank, nlanes)       # streams SEEN to overlap (distinct hardware queues), not merely distinct objects
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     inp = torch.rand(B, HW, HW, 3, generator=g).to(dev)       # synthetic, resident in HBM before timing
     uv = torch.rand(B, HW, HW, 3, generator=g).to(dev)
@@ -509,26 +534,45 @@ def run_rank(args):
     gathered = [torch.empty((world * B, HW, HW, 4), device=dev) for _ in range(2)] if distributed else None
     pending = [None, None]
     last = [None, None]                     # the output tuple of the last forward in each slot
+    pre_rf = None
+    if distributed:
+        # The per-launch events of the roofline object are taken on rank 0 BEFORE the process group exists: with RCCL initialised the
+        # same event-bracketed forwards run ~10 % longer (profiles/r3_bench_dist1.json of the earlier rounds: 5.64 vs 5.14 ms of kernel
+        # time, frac 0.716 vs 0.793) although the timed region itself is unchanged — an artefact of event recording, not of the kernels.
+        if rank == 0 and on_gpu and not tsm:
+            for _ in range(12):                     # the chip is cold here (in the single-process run the events follow the timed regions)
+                gen(inp, uv, out=outs[0])
+            torch.cuda.synchronize()
+            pre_rf = roofline_from_events(gen, lambda: gen(inp, uv, out=outs[0]), B, args.dtype)
+        init_group()
 
-    def forward(slot, pack=False):
-        if tsm:
-            return gen(inp, uv, reg, 2, True)           # frame = 2 (image + mirror pairs, train_with_TSM.py:676)
-        if pack:                                        # con_rgb | dif written by the tail kernel straight into the all-gather payload (bsr_forward_packed)
-            return gen(inp, uv, out=outs[slot], packed_out=packed[slot])
-        return gen(inp, uv, out=outs[slot])
+    def on_lane(k):
+        return torch.cuda.stream(lanes[k]) if lanes[k] is not None else contextlib.nullcontext()
 
-    def step(i, gather=True):
-        slot = i & 1
-        if pending[slot] is not None:           # buffers of step i-2 are free once its gather completed
-            pending[slot].wait()
-            pending[slot] = None
-        gathering = distributed and gather and not args.no_gather
-        o = forward(slot, pack=gathering)
-        last[slot] = o
-        if gathering:
+    def forward(slot, pack=False, lane=None):
+        k = (slot % nlanes) if lane is None else lane
+        g_ = gens[k]
+        with on_lane(k):
             if tsm:
-                torch.cat((o[1], o[3]), dim=3, out=packed[slot])
-            pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
+                return g_(inp, uv, reg, 2, True)        # frame = 2 (image + mirror pairs, train_with_TSM.py:676)
+            if pack:                                    # con_rgb | dif written by the tail kernel straight into the all-gather payload (bsr_forward_packed)
+                return g_(inp, uv, out=outs[slot], packed_out=packed[slot])
+            return g_(inp, uv, out=outs[slot])
+
+    def step(i, gather=True, lane=None):
+        slot = i & 1
+        k = (slot % nlanes) if lane is None else lane
+        with on_lane(k):                            # the gather of step i is ordered after ITS forward's stream; step i+1 runs beside both
+            if pending[slot] is not None:           # buffers of step i-2 are free once its gather completed
+                pending[slot].wait()
+                pending[slot] = None
+            gathering = distributed and gather and not args.no_gather
+            o = forward(slot, pack=gathering, lane=k)
+            last[slot] = o
+            if gathering:
+                if tsm:
+                    torch.cat((o[1], o[3]), dim=3, out=packed[slot])
+                pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
 
     def drain():
         for s in (0, 1):
@@ -563,14 +607,19 @@ def run_rank(args):
     elapsed, own = timed(args.steps, step)                  # THE timed region: exactly K steps
     reps = [elapsed] + [timed(args.steps, step)[0] for _ in range(max(0, args.repeats - 1))]
     extra = {}
+    if nlanes > 1:                                      # the same K steps strictly one after the other on one handle / one stream
+        t_serial, _ = timed(args.steps, lambda i: step(i, lane=0))
+        extra["single_stream"] = {"value": round(world * B * args.steps / t_serial, 2), "ms_per_step": round(t_serial / args.steps * 1e3, 4),
+                                  "note": "the same K steps on ONE handle and ONE stream (no two forwards in flight)"}
     if distributed and not args.no_gather:
         t_nog, _ = timed(args.steps, lambda i: step(i, gather=False))
 
         def gather_only(i):
             slot = i & 1
-            if pending[slot] is not None:
-                pending[slot].wait()
-            pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
+            with on_lane(slot % nlanes):
+                if pending[slot] is not None:
+                    pending[slot].wait()
+                pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
         t_g, _ = timed(args.steps, gather_only)
         owns = [None] * world
         dist.all_gather_object(owns, own)
@@ -587,11 +636,11 @@ def run_rank(args):
             ok = ok and float(gathered[0][r_ * B:(r_ + 1) * B].double().sum().item()) == s_
         oks = [None] * world
         dist.all_gather_object(oks, ok)
-        extra = {"allgather": {"bytes_per_rank": packed[0].numel() * 4, "backend": args.backend, "verified": all(oks),
+        extra.update({"allgather": {"bytes_per_rank": packed[0].numel() * 4, "backend": args.backend, "verified": all(oks),
                                "ms_alone": round(t_g / args.steps * 1e3, 4),
                                "ms_per_step_without_gather": round(t_nog / args.steps * 1e3, 4),
                                "ms_exposed_per_step": round((elapsed - t_nog) / args.steps * 1e3, 4)},
-                 "per_rank_images_per_sec": [round(B * args.steps / o, 2) for o in owns]}
+                 "per_rank_images_per_sec": [round(B * args.steps / o, 2) for o in owns]})
 
     result = None
     if rank == 0:
@@ -599,7 +648,7 @@ def run_rank(args):
         value = world * B * args.steps / elapsed
         rs = sorted(r / args.steps * 1e3 for r in reps)
         cfg = {"workload": None, "images_per_gpu_per_step": B, "global_batch": world * B, "height": HW, "width": HW,
-               "parallelism": "dp%d" % world,
+               "parallelism": "dp%d" % world, "forwards_in_flight": nlanes, "streams_seen_to_overlap": lanes_verified,
                "collective": ("all_gather(con_rgb|dif) per step, async, double-buffered" if distributed and not args.no_gather else "none")}
         if tsm:
             cfg["workload"] = ("BASELINE configs[4] per-rank shape: TSM generator (model_with_TSM.py), %d frames of 512x512 per GPU per step, "
@@ -613,6 +662,9 @@ def run_rank(args):
         else:
             cfg["workload"] = ("BASELINE configs[3]: batch=32 synthetic 256x256x3 per GPU, fp16 MFMA (fp32 accumulate/storage) on the "
                                "3x3-conv path, fp32 elsewhere; NOT the headline configuration")
+        if nlanes > 1:
+            cfg["workload"] += "; steps alternate between two handles on two HIP streams (two forwards in flight, `single_stream` = one at a time)"
+        single = extra.pop("single_stream", None)
         cfg.update(extra)
         result = {
             "metric": "images/sec at 256x256 batch inference (GSC generator forward)" if not tsm else "images/sec at 512x512 (TSM generator forward)",
@@ -622,6 +674,8 @@ def run_rank(args):
             "repeats": {"n": len(rs), "ms_per_step_min": round(rs[0], 4), "ms_per_step_median": round(rs[len(rs) // 2], 4),
                         "ms_per_step_all": [round(r, 4) for r in rs], "note": "`value` is the FIRST timed region of exactly K steps; the others repeat it"},
         }
+        if single is not None:
+            result["single_stream"] = single
         if args.stub:
             result["stub"] = True
             result["roofline"] = None
@@ -630,7 +684,7 @@ def run_rank(args):
             if tsm:
                 result["roofline"] = None
             else:
-                rf, dom_name = roofline_from_events(gen, lambda: forward(0), B, args.dtype)
+                rf, dom_name = pre_rf if pre_rf is not None else roofline_from_events(gen, lambda: forward(0), B, args.dtype)
                 attach_traffic(rf, dom_name, B, args.dtype)
                 attach_mfma(rf, dom_name, B, args.dtype)
                 result["roofline"] = rf
@@ -640,7 +694,7 @@ def run_rank(args):
                 result["cpu_baseline"] = None
             if args.dtype == "f32" and not tsm and not args.no_secondary:
                 result["f32x3"] = secondary_f32x3(weights, local_rank, inp, uv, outs[0], B, args, world, timed if not distributed else None,
-                                                  with_parity=(world == 1 and not args.no_cpu_baseline))
+                                                  with_parity=(world == 1 and not args.no_cpu_baseline), lanes=lanes)
             if args.loop and world == 1:
                 from blindshadowremoval_amd.loop_bench import loop_bench
                 result["loop"] = loop_bench(args.loop, os.path.join(ROOT, "tests", "golden"), gen)
@@ -675,6 +729,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the f32x3 side measurement the default f32 run appends")
     ap.add_argument("--workload", choices=("gsc256", "tsm512"), default="gsc256",
                     help="gsc256 = BASELINE configs[1]/[3]; tsm512 = the per-rank shape of configs[4] (TSM generator, 512x512 frames)")
+    ap.add_argument("--streams", type=int, choices=(1, 2), default=2,
+                    help="forwards in flight per GPU: 2 = consecutive steps alternate between two handles on two HIP streams, so one step's kernels "
+                         "fill the tails and ramps of the other's one-round launches (the serial figure is reported beside it as `single_stream`)")
     ap.add_argument("--no-gather", action="store_true", help="skip the output all-gather (N>1)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo only with --stub (CPU test of the rank logic)")
     ap.add_argument("--stub", action="store_true", help="CPU stand-in generator: tests the launcher / sharding / JSON contract, measures nothing")

@@ -31,6 +31,7 @@ def test_gpus2_launches_two_ranks_over_gloo():
     assert len(j["config"]["per_rank_images_per_sec"]) == 2
     assert abs(j["value"] - 4 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-3      # whole-job aggregate over both ranks
     assert j["repeats"]["n"] == 2 and j["repeats"]["ms_per_step_min"] > 0
+    assert j["config"]["forwards_in_flight"] == 1 and "single_stream" not in j      # the CPU stand-in has no streams: --streams 2 only applies on a GPU
 
 
 def test_gpus_without_devices_fails_loudly():

@@ -701,3 +701,29 @@ def test_smallest_accepted_image(gen_w):
     inp, uv = torch.rand(3, 32, 256, 3), torch.rand(3, 32, 256, 3)
     out, ref, errs, nflip = run_and_compare(gen, w, inp, uv, want_probes=("x0", "res2", "res5"))
     assert out[0].shape == (3, 32, 256, 1)
+
+
+@pytest.mark.gpu
+def test_two_handles_on_two_streams_give_the_serial_result():
+    """bench.py --streams 2 (and any serving loop) keeps two forwards in flight on two handles / two HIP streams: the kernels of one
+    run beside the other's.  Every output must be bit-identical to the same forward running alone."""
+    from blindshadowremoval_amd import Generator
+    w = init_weights(1)
+    torch.manual_seed(5)
+    xs = [torch.rand(8, 256, 256, 3).cuda() for _ in range(4)]
+    us = [torch.rand(8, 256, 256, 3).cuda() for _ in range(4)]
+    gens = [Generator(device=0).load_weights(w) for _ in range(2)]
+    serial = [[t.clone() for t in gens[0](x, u)] for x, u in zip(xs, us)]
+    torch.cuda.synchronize()
+    lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        outs = []
+        for i, (x, u) in enumerate(zip(xs, us)):
+            with torch.cuda.stream(lanes[i & 1]):
+                outs.append(gens[i & 1](x, u))
+        torch.cuda.synchronize()
+        for o, r in zip(outs, serial):
+            for a, b in zip(o, r):
+                assert torch.equal(a, b)
+    for g in gens:
+        g.close()
