@@ -10,26 +10,26 @@ b, bx, bh = J("r3_bench_n1.json"), J("r3_bench_n1_f32x3.json"), J("r3_bench_n1_f
 rf = b["roofline"]
 cb = b["cpu_baseline"]
 block = '''<!-- BEGIN r3 DESIGN TABLE -->
-| dtype | images/s | ms / forward | dominant kernel against its roofs | max abs error vs oracle |
+| dtype | images/s: two forwards in flight (one at a time) | ms / step | dominant kernel against its roofs | max abs error vs oracle |
 |---|---|---|---|---|
-| **f32** — fp32 matrix cores, the measured path (`value`) | **%.0f** (6 300-6 390 over the round's boxes) | %.3f | transposed 3x3 `igemm_conv_kernel`: %.1f TFLOP/s = **%.1f %%** of 157.3 (`bound: mfma`); PMC: matrix pipe busy %.1f %% of the GPU-active cycles at %.2f GHz; 3x3-conv path %.1f %%; HBM traffic %.0f MB per launch (587 MB algorithmic) | %.1e, %d mask flips |
-| f32x3 — split precision on the fp16 matrix cores (§4b) | %.0f (11.9-12.5 k over the round) | %.3f | transposed 3x3 `igemm_h16_kernel`: %.1f %% of its 833 TFLOP/s matrix roof, %.1f %% of 8 TB/s algorithmic (`bound: hbm`) | %.1e, %d mask flips |
-| f16 — fp16 operands + fp16 activation pack (configs[3]) | %.0f (15.9-16.2 k) | %.3f | bottleneck GEMMs: %.1f %% of 8 TB/s algorithmic (`bound: hbm`) | 1.4e-03 (tested at 2e-3) |
+| **f32** — fp32 matrix cores, the measured path (`value`) | **%.0f** (%.0f; over the round's boxes 6 440-6 650 and 6 270-6 390) | %.3f | transposed 3x3 `igemm_conv_kernel`: %.1f TFLOP/s = **%.1f %%** of 157.3 (`bound: mfma`); PMC: matrix pipe busy %.1f %% of the GPU-active cycles at %.2f GHz; 3x3-conv path %.1f %%; HBM traffic %.0f MB per launch (587 MB algorithmic) | %.1e, %d mask flips |
+| f32x3 — split precision on the fp16 matrix cores (§4b) | %.0f (%.0f; 11.8-12.5 k one at a time over the round) | %.3f | transposed 3x3 `igemm_h16_kernel`: %.1f %% of its 833 TFLOP/s matrix roof, %.1f %% of 8 TB/s algorithmic (`bound: hbm`) | %.1e, %d mask flips |
+| f16 — fp16 operands + fp16 activation pack (configs[3]) | %.0f (%.0f; 15.9-16.7 k one at a time) | %.3f | bottleneck GEMMs: %.1f %% of 8 TB/s algorithmic (`bound: hbm`) | 1.4e-03 (tested at 2e-3) |
 
 CPU oracle on the GPU box's host (`cpu_baseline`, `kind: "port"`): %.1f images/s at %d threads — the container may use %d CPUs (cgroup
 quota; %d logical CPUs visible), and the sweep is built around that figure (1 thread, half, all, twice the usable CPUs).
 <!-- END r3 DESIGN TABLE -->''' % (
-    b["value"], b["ms_per_step"], rf["mfma_view"]["achieved_TFLOPs"], 100 * rf["frac"], 100 * rf["mfma_busy"], rf["clock_ghz"], 100 * rf["path_3x3"]["frac"],
+    b["value"], b["single_stream"]["value"], b["ms_per_step"], rf["mfma_view"]["achieved_TFLOPs"], 100 * rf["frac"], 100 * rf["mfma_busy"], rf["clock_ghz"], 100 * rf["path_3x3"]["frac"],
     rf["traffic"] / 1e6, cb["parity"]["max_abs_err"], cb["parity"]["bmask_flips"],
-    bx["value"], bx["ms_per_step"], 100 * bx["roofline"]["mfma_view"]["frac"], 100 * bx["roofline"]["hbm_view"]["frac"], b["f32x3"]["parity"]["max_abs_err"],
-    b["f32x3"]["parity"]["bmask_flips"], bh["value"], bh["ms_per_step"], 100 * bh["roofline"]["hbm_view"]["frac"],
+    bx["value"], bx["single_stream"]["value"], bx["ms_per_step"], 100 * bx["roofline"]["mfma_view"]["frac"], 100 * bx["roofline"]["hbm_view"]["frac"], b["f32x3"]["parity"]["max_abs_err"],
+    b["f32x3"]["parity"]["bmask_flips"], bh["value"], bh["single_stream"]["value"], bh["ms_per_step"], 100 * bh["roofline"]["hbm_view"]["frac"],
     cb["value"], cb["cores"], cb["usable_cpus"], cb["logical_cpus"])
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 if "<!-- BEGIN r3 DESIGN TABLE -->" in s:
     s = re.sub(r"<!-- BEGIN r3 DESIGN TABLE -->.*?<!-- END r3 DESIGN TABLE -->", lambda m: block, s, flags=re.S)
 else:
-    a = s.index("| dtype | images/s | ms / forward | dominant kernel against its roofs | max abs error vs oracle |\n|---|---|---|---|---|\n| **f32** — fp32 matrix cores, the measured path (`value`) | **6")
+    a = s.index("| dtype | images/s")
     e = s.index("**The round's finding about the fp32 path")
     s = s[:a] + block + "\n\n" + s[e:]
 open(p, "w").write(s)

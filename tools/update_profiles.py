@@ -35,12 +35,14 @@ for _, r in d.sort_values("us/fwd", ascending=False).iterrows():
 rows.append("| **sum** | %g | | **%.0f** |" % (d["launches/fwd"].sum(), d["us/fwd"].sum()))
 rf = b["roofline"]
 cb = b.get("cpu_baseline") or {}
-head = ("* `%s_bench_n1%s.json` — `python bench.py%s` (N = 1, %d steps, %d warm-up): **%.0f images/s**, %.3f ms per %d-image forward "
+head = ("* `%s_bench_n1%s.json` — `python bench.py%s` (N = 1, %d steps, %d warm-up): **%.0f images/s**%s, %.3f ms per %d-image step "
         "(repeats: min %.3f / median %.3f ms); dominant kernel `%s`: **%.1f TFLOP/s = %.1f %% of its %.0f TFLOP/s matrix peak** "
         "(avg launch %.4f ms — compare the rocprofv3 average below; algorithmic HBM rate %.0f GB/s = %.1f %% of 8 TB/s; nearer roof: %s), whole 3x3-conv path %.1f TFLOP/s (%.1f %%), "
         "all kernels %.1f TFLOP/s; CPU oracle %s images/s on %s host threads.\n"
-        "* `%s_kernel_stats%s.csv` — `rocprofv3 --kernel-trace --stats -- python3 bench.py%s --no-cpu-baseline --no-secondary --repeats 1` (%d forwards). Per forward:\n\n"
-        % (tag, sfx, "" if dtype == "f32" else " --dtype " + dtype, b["steps"], b["warmup"], b["value"], b["ms_per_step"], b["config"]["images_per_gpu_per_step"],
+        "* `%s_kernel_stats%s.csv` — `rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 1%s --no-cpu-baseline --no-secondary --repeats 1` (%d forwards, one at a time: with two in flight a traced duration would include the time a kernel shares the chip). Per forward:\n\n"
+        % (tag, sfx, "" if dtype == "f32" else " --dtype " + dtype, b["steps"], b["warmup"], b["value"],
+           (" with two forwards in flight (`single_stream`, one at a time: %.0f)" % b["single_stream"]["value"]) if b.get("single_stream") else "",
+           b["ms_per_step"], b["config"]["images_per_gpu_per_step"],
            b["repeats"]["ms_per_step_min"], b["repeats"]["ms_per_step_median"], rf["kernel"].split(" — ")[0], rf["mfma_view"]["achieved_TFLOPs"],
            100 * rf["mfma_view"]["frac"], rf["mfma_view"]["peak_TFLOPs"],
            rf["avg_launch_ms"], rf["hbm_view"]["alg_GBps"], 100 * rf["hbm_view"]["frac"], rf["bound"], rf["path_3x3"]["achieved"], 100 * rf["path_3x3"]["frac"], rf["all_kernels_tflops"],
