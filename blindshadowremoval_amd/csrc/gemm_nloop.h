@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
   // Epilogue addressing through raw buffer resources (igemm_conv.h): per element one 32-bit SGPR offset from this wave's
   // pixel-0 row and one constant per-lane VGPR offset.
   const bool has_res = p.res1 != nullptr;
+  const float act_alpha = p.act ? kLeakyAlpha : 1.f;
   const size_t tile_pix = pix0 + (size_t)__builtin_amdgcn_readfirstlane(wave) * 32;      // this wave's 32 consecutive pixels
   const unsigned lane_out = ((unsigned)(4 * h) * (unsigned)p.out_cs + (unsigned)r) * 4u;
   const unsigned lane_out2 = ((unsigned)(4 * h) * (unsigned)p.out2_cs + (unsigned)r) * 4u;
@@ -155,9 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
     f32x16 acc[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const float b = s_bias[min(tg - t0 + ni, ntiles - 1) * 32 + r];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[ni][i] = b;
+      acc[ni] = bias_tile(h, s_bias[min(tg - t0 + ni, ntiles - 1) * 32 + r]);      // one matrix instruction per tile (igemm_conv.h), not 16 moves at priority 0
     }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -215,32 +214,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
       const bool second = p.out2 != nullptr && nt >= p.n_split;
       const bool n_ok = second ? n < p.n_store : (p.out2 != nullptr ? n < p.n_store1 : n < p.n_store);
       f32x16 v = acc[ni];
+      // Addressing as in igemm_conv_kernel's epilogue: the four pixel rows of a register quad are four per-lane offsets, the quad's
+      // base one SGPR that moves by eight pixels — one scalar add per four loads / stores instead of three per element.
       if (has_res && nt < p.res1_c) {                        // ONE residual (res1, channels [0, res1_c)); uniform per tile
+        const unsigned rcs4 = (unsigned)p.res1_cs * 4u;
         const unsigned l1 = n < p.res1_c ? lane_res + (unsigned)r * 4u : kLaneOff;      // out-of-range lanes read 0
+        const unsigned lj[4] = {l1, l1 + rcs4, l1 + 2u * rcs4, l1 + 3u * rcs4};          // (0x80000000 + a few KB is still outside the buffer)
         float r1[16];
+        unsigned so = (unsigned)nt * 4u;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int k = (i & 3) + 8 * (i >> 2);
-          r1[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_res, l1, ((unsigned)k * (unsigned)p.res1_cs + (unsigned)nt) * 4u, 0));
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r1[4 * q + j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_res, lj[j], so, 0));
+          so += 8u * rcs4;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] += r1[i];
       }
-      if (p.act) {
+      leaky_relu_tile(v, act_alpha);
+      const unsigned vb = n_ok ? (second ? lane_out2 : lane_out) : kLaneOff;
+      const unsigned cs4 = (second ? (unsigned)p.out2_cs : (unsigned)p.out_cs) * 4u;
+      const unsigned vj[4] = {vb, vb + cs4, vb + 2u * cs4, vb + 3u * cs4};
+      unsigned so = (second ? (unsigned)(nt - p.n_split) : (unsigned)nt) * 4u;
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          const f32x2 y = leaky_relu2(f32x2{v[i], v[i + 1]});
-          v[i] = y[0];
-          v[i + 1] = y[1];
-        }
-      }
-      const unsigned voff = n_ok ? (second ? lane_out2 : lane_out) : kLaneOff;
-      const unsigned cs = second ? (unsigned)p.out2_cs : (unsigned)p.out_cs;
-      const unsigned c0 = second ? (unsigned)(nt - p.n_split) : (unsigned)nt;
+      for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int k = (i & 3) + 8 * (i >> 2);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), second ? rsrc_out2 : rsrc_out, voff, ((unsigned)k * cs + c0) * 4u, 0);
+        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[4 * q + j]), second ? rsrc_out2 : rsrc_out, vj[j], so, 0);
+        so += 8u * cs4;
       }
     }
     __builtin_amdgcn_s_setprio(0);

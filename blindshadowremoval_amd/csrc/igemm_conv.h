@@ -46,6 +46,30 @@ __device__ __forceinline__ f32x2 leaky_relu2(f32x2 x) {
   return f32x2{__builtin_amdgcn_fmed3f(x[0], t[0], 3.4028234664e38f), __builtin_amdgcn_fmed3f(x[1], t[1], 3.4028234664e38f)};
 }
 __device__ __forceinline__ float leaky_relu(float x) { return __builtin_amdgcn_fmed3f(x, x * kLeakyAlpha, 3.4028234664e38f); }
+// A whole accumulator tile: the eight packed multiplies first, then the sixteen medians (a median right behind the multiply it reads
+// costs a wait state — an s_nop, i.e. one more issue slot — each time).  alpha = 1 turns the activation off without a branch
+// (median of {x, x, FLT_MAX} = x).
+__device__ __forceinline__ void leaky_relu_tile(f32x16& v, float alpha) {
+  f32x2 t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = f32x2{v[2 * i], v[2 * i + 1]} * alpha;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[2 * i] = __builtin_amdgcn_fmed3f(v[2 * i], t[i][0], 3.4028234664e38f);
+    v[2 * i + 1] = __builtin_amdgcn_fmed3f(v[2 * i + 1], t[i][1], 3.4028234664e38f);
+  }
+}
+// A 32x32 accumulator tile whose rows all hold the bias of its 32 output channels (register i of lane l = bias[l & 31]), produced by
+// ONE matrix instruction instead of 16 v_mov_b32: A = [1 | 0] (the k = 0 column all ones: lanes 0-31 supply 1, lanes 32-63 supply 0),
+// B row 0 = bias, row 1 = 0, C = 0 -> acc[m][n] = 1 * bias[n] + 0 * 0 + 0 = bias[n] exactly.  Beside a co-resident wave's MFMA stream
+// a VALU instruction waits for a matrix instruction to drain every time; the 128 moves of a transposed-conv tile were 2-3 k cycles of
+// every workgroup's prologue (and of every channel group of gemm_nloop, there at priority 0), eight matrix instructions are ~0.5 k.
+__device__ __forceinline__ f32x16 bias_tile(int h, float bias_col) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float one = h ? 0.f : 1.f;
+  asm volatile("" : "+v"(one));        // an empty statement, only to keep the compiler from computing ONE tile and copying it (v_mov) to the others
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(one, h ? 0.f : bias_col, zero, 0, 0, 0);
+}
 // Epilogue addressing through a raw buffer resource: buffer_store_dword v_data, v_lane_off, s[rsrc], s_uniform_off offen.
 // The wave-uniform part of an element's address is a 32-bit SGPR byte offset from a per-workgroup base, the per-lane part one
 // constant VGPR: no vector address arithmetic at all per element, and a lane whose offset has bit 31 set falls outside
@@ -93,6 +117,7 @@ struct ConvArgs {
   unsigned* range_flag; // 16-bit kernels: set to 1 when a staged activation does not fit fp16 (|x| >= 65520); may be null
 #ifdef BSR_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
+  unsigned long long* stamps3;  // diagnostic build only: where the prologue's cycles go, [block][wave][6] = entry, addresses set up, loads issued, loads landed + LDS written, barrier passed, accumulators + first fragments ready
   unsigned long long* stamps2;  // diagnostic build only: per-step timeline of 64 mid-kernel workgroups (1024 .. 1087): [block][wave][step][3] = step start, matrix work done, barrier passed
 #endif
 };
@@ -119,7 +144,16 @@ struct ConvCfg {
   static constexpr int W_FLOATS = BN * LDP;
   static constexpr int SMEM_BYTES = (INB * IN_FLOATS + 3 * W_FLOATS) * 4;
   static constexpr int IN_V4 = IH * IW * (CC / 4);               // float4 loads per input-tile chunk
-  static constexpr int IN_PER_THREAD = (IN_V4 + NT - 1) / NT;
+  // Row-wise staging (channel chunks of 4 / 8 float4: Q divides the workgroup): load r of a thread is tile ROW r at the thread's own
+  // column and float4 — its global offset is one per-thread VGPR per row, computed once per tile, with 0x80000000 (outside the buffer
+  // resource: the hardware returns 0) for everything that is TF SAME zero padding.  No per-element divisions in the prologue, no
+  // clamping, and no zeroing selects when the tile is written to LDS.  The RC columns the NT / Q-wide pass does not reach are ONE more
+  // load of a few threads.  (24-channel chunks keep the flat indexing: 6 float4 per pixel do not divide 256 threads.)
+  static constexpr int Q = CC / 4;
+  static constexpr bool ROWWISE = (NT % Q == 0) && (NT / Q <= IW) && (IH * (IW - NT / Q) * Q <= NT);
+  static constexpr int CP = ROWWISE ? NT / Q : 1;
+  static constexpr int RC = ROWWISE ? IW - CP : 0;
+  static constexpr int IN_PER_THREAD = ROWWISE ? IH + (RC > 0 ? 1 : 0) : (IN_V4 + NT - 1) / NT;
   static constexpr int W_V4 = W_FLOATS / 4;
   static constexpr int W_PER_THREAD = (W_V4 + NT - 1) / NT;
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
@@ -180,23 +214,38 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
     const int n = n0 + (wn * NI + ni) * 32 + r;
     bias_n[ni] = p.bias[n < p.n_pad ? n : 0];
   }
-  f32x16 acc[NPH][MI][NI];
-#pragma unroll
-  for (int ph = 0; ph < NPH; ++ph)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[ph][mi][ni][i] = bias_n[ni];     // bias folded into the accumulator start value
-
   // Staging addresses are "wave-uniform base + per-thread constant": the per-thread byte offsets (global source,
   // LDS destination) and the zero-padding mask are computed ONCE here; per chunk / per tap only the scalar base
   // moves, so the loads inside the MFMA loop cost no VALU address arithmetic.  Loads are unconditional (clamped
   // address); out-of-image pixels (TF SAME zero padding) are zeroed at LDS-store time.
-  unsigned in_goff[C::IN_PER_THREAD], w_off[C::W_PER_THREAD];
-  int in_loff[C::IN_PER_THREAD];
+  constexpr bool ROWWISE = C::ROWWISE;
+  unsigned in_goff[C::IN_PER_THREAD], w_off[C::W_PER_THREAD];      // ROWWISE: buffer offsets from the image start, 0x80000000 = zero padding
+  int in_loff[ROWWISE ? 2 : C::IN_PER_THREAD];                     // ROWWISE: [0] = this thread's LDS float offset in row 0, [1] = its remainder element (-1: none)
   unsigned in_okmask = 0u;
+  if constexpr (ROWWISE) {
+    constexpr int Q = C::Q, CP = C::CP, RC = C::RC, IH = C::IH;
+    const int scol = tid / Q, sq = tid % Q;
+    const int ix = ix0 + scol;
+    const bool colok = ix >= 0 && ix < p.W;
+    const unsigned colpart = (unsigned)((ix * p.in_cs + sq * 4) * 4);
+    const unsigned rowstride = (unsigned)(p.W * p.in_cs * 4);
+#pragma unroll
+    for (int rr = 0; rr < IH; ++rr) {
+      const int iy = iy0 + rr;                                    // wave-uniform
+      in_goff[rr] = (iy >= 0 && iy < p.H && colok) ? colpart + (unsigned)iy * rowstride : kLaneOff;
+    }
+    in_loff[0] = scol * LDP + sq * 4;
+    in_loff[1] = -1;
+    if constexpr (RC > 0) {
+      const bool act = tid < IH * RC * Q;
+      const int e = act ? tid : 0;
+      const int rq = e % Q, rc = (e / Q) % RC, rrow = e / (Q * RC);
+      const int iy = iy0 + rrow, ixr = ix0 + CP + rc;
+      const bool ok = act && iy >= 0 && iy < p.H && ixr >= 0 && ixr < p.W;
+      in_goff[IH] = ok ? (unsigned)(((iy * p.W + ixr) * p.in_cs + rq * 4) * 4) : kLaneOff;
+      in_loff[1] = act ? (rrow * IW + CP + rc) * LDP + rq * 4 : -1;
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < C::IN_PER_THREAD; ++i) {
     const int idx0 = tid + i * NT;
@@ -209,17 +258,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
     in_loff[i] = idx0 < C::IN_V4 ? pix * LDP + q * 4 : -1;
     in_okmask |= (ok ? 1u : 0u) << i;
   }
+  }
+  const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(in_img);       // ROWWISE: this image (first channel of the layer's input) as a raw buffer
 #pragma unroll
   for (int i = 0; i < C::W_PER_THREAD; ++i) {
     const int idx0 = tid + i * NT;
     w_off[i] = (unsigned)((idx0 < C::W_V4 ? idx0 : C::W_V4 - 1) * 16);
   }
   auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
-    const char* base = reinterpret_cast<const char*>(in_img + ch * CC);
+    if constexpr (ROWWISE) {
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      const unsigned soff = (unsigned)(ch * CC * 4);              // the chunk's first channel: wave-uniform SGPR offset
 #pragma unroll
-    for (int i = 0; i < C::IN_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + in_goff[i]);
+      for (int i = 0; i < C::IN_PER_THREAD; ++i)
+        regs[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(in_rsrc, in_goff[i], soff, 0));
+    } else {
+      const char* base = reinterpret_cast<const char*>(in_img + ch * CC);
+#pragma unroll
+      for (int i = 0; i < C::IN_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + in_goff[i]);
+    }
   };
   auto store_in = [&](int off, const f32x4 (&regs)[C::IN_PER_THREAD]) {
+    if constexpr (ROWWISE) {
+#pragma unroll
+      for (int rr = 0; rr < C::IH; ++rr) *reinterpret_cast<f32x4*>(s_in + off + in_loff[0] + rr * IW * LDP) = regs[rr];      // padding arrived as zeros
+      if constexpr (C::RC > 0) {
+        if (in_loff[1] >= 0) *reinterpret_cast<f32x4*>(s_in + off + in_loff[1]) = regs[C::IH];
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < C::IN_PER_THREAD; ++i) {
       if (in_loff[i] >= 0) {
@@ -227,6 +293,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
         if (!((in_okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(s_in + off + in_loff[i]) = v;
       }
+    }
     }
   };
   auto fetch_w = [&](int step, f32x4 (&regs)[C::W_PER_THREAD]) {
@@ -244,6 +311,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
 
 #ifdef BSR_STAMPS
   unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0;
+  unsigned long long stP[3] = {0, 0, 0};
   unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   f32x4 in_regs[C::IN_PER_THREAD];
@@ -255,21 +323,47 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
   int w_cur = 0, w_n1 = C::W_FLOATS, w_n2 = 2 * C::W_FLOATS;
   int in_cur = 0, in_n1 = (INB > 1) ? C::IN_FLOATS : 0, in_n2 = (INB > 2) ? 2 * C::IN_FLOATS : 0;
 
-  // prologue: steps 0 and 1 staged synchronously
-  fetch_in(0, in_regs);
-  if constexpr (PAIR) { if (p.nchunk > 1) fetch_in(1, in_regs2); }
-  fetch_w(0, w_regs);
-  store_in(0, in_regs);
-  store_w(0, w_regs);
-  if (nsteps > 1) {
-    fetch_w(1, w_regs);
-    store_w(w_n1, w_regs);
-    if (T == 1 && INB == 3) {
-      fetch_in(1, in_regs);
-      store_in(in_n1, in_regs);
+  // prologue: steps 0 and 1 staged synchronously.  The prologue is a chain of memory round trips, not of instructions (replacing its 128
+  // accumulator moves by 8 matrix instructions changed nothing): ALL its global loads — input tile, both weight steps, the bias above —
+  // are issued before the first one is waited for, so it costs one round trip instead of three.
+  {
+    f32x4 w_regs1[C::W_PER_THREAD];
+    f32x4 in_regs1[(T == 1 && INB == 3) ? C::IN_PER_THREAD : 1];
+    fetch_in(0, in_regs);
+    if constexpr (PAIR) { if (p.nchunk > 1) fetch_in(1, in_regs2); }
+    fetch_w(0, w_regs);
+    if (nsteps > 1) {
+      fetch_w(1, w_regs1);
+      if constexpr (T == 1 && INB == 3) fetch_in(1, in_regs1);
+    }
+#ifdef BSR_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    stP[0] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    store_in(0, in_regs);
+    store_w(0, w_regs);
+    if (nsteps > 1) {
+      store_w(w_n1, w_regs1);
+      if constexpr (T == 1 && INB == 3) store_in(in_n1, in_regs1);
     }
   }
+#ifdef BSR_STAMPS
+  __builtin_amdgcn_sched_barrier(0);
+  stP[1] = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+#ifdef BSR_STAMPS
+  stP[2] = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  f32x16 acc[NPH][MI][NI];
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[ph][mi][ni] = bias_tile(h, bias_n[ni]);     // bias folded into the accumulator start value
 
   f32x4 af[2][MI], bf[2][NI];
   auto read_frags = [&](int slot, int a_off, int b_off) {
@@ -396,9 +490,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
   static_assert(TW == 32, "epilogue assumes one tile row per 32-pixel MFMA tile");
   constexpr int SX = TR ? 2 : 1;
   const size_t blk_pix = (size_t)img * p.Ho * p.Wo + (size_t)(SX * y0) * p.Wo + SX * x0;
-  // per-lane constant part (bytes): register 0 of this lane is pixel column SX*4*h, channel r of its tile
-  const unsigned lane_out = ((unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r) * 4u;
+  // An epilogue instruction — scalar ones included — costs this wave ~15 cycles beside its SIMD partner's matrix stream, so the
+  // count matters, not the kind: the four pixel columns a register quad covers are four per-lane VGPR offsets (computed once per
+  // N tile), and only the quad's base moves in an SGPR: one scalar add per FOUR stores (it was three per store).
+  const unsigned cs4 = (unsigned)p.out_cs * 4u;                 // bytes per output pixel
+  // register 0 of this lane is pixel column SX*4*h, channel r of its tile; register j of a quad is SX pixels further each
+  const unsigned lane_out = (unsigned)(SX * 4 * h) * cs4 + (unsigned)r * 4u;
+  unsigned voff[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const bool n_ok = n0 + (wn * NI + ni) * 32 + r < p.n_store;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voff[ni][j] = n_ok ? lane_out + (unsigned)(SX * j) * cs4 : kLaneOff;
+  }
   const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.out + blk_pix * p.out_cs + p.out_coff);      // this workgroup's output origin
+  const float act_alpha = p.act ? kLeakyAlpha : 1.f;
+  const unsigned quad_step = (unsigned)(SX * 8) * cs4;          // registers 4q .. 4q+3 start 8 pixel columns (x SX) after the previous quad
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
@@ -406,27 +513,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int nt = n0 + (wn * NI + ni) * 32;           // first channel of this 32-wide tile (uniform)
-        const unsigned voff = nt + r < p.n_store ? lane_out : kLaneOff;
         const int ty = wm * MI + mi;
-        // wave-uniform element offset of this tile's register-0 row, relative to the workgroup origin
-        const unsigned tile_off = (unsigned)((SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0)) * (unsigned)p.out_cs + (unsigned)nt;
+        // wave-uniform byte offset of this tile's register-0 row, relative to the workgroup origin
+        unsigned soff = ((unsigned)((SX * ty + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0)) * (unsigned)p.out_cs + (unsigned)nt) * 4u;
         f32x16 v = acc[ph][mi][ni];
-        if (p.act) {
+        leaky_relu_tile(v, act_alpha);
 #pragma unroll
-          for (int i = 0; i < 16; i += 2) {
-            const f32x2 y = leaky_relu2(f32x2{v[i], v[i + 1]});
-            v[i] = y[0];
-            v[i + 1] = y[1];
-          }
-        }
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int k = SX * ((i & 3) + 8 * (i >> 2));
-          const unsigned soff = (tile_off + (unsigned)k * (unsigned)p.out_cs) * 4u;      // uniform
+          for (int j = 0; j < 4; ++j) {
 #if defined(BSR_EPI_SKIP)
-          if (v[i] == 12345.678f)
+            if (v[4 * q + j] == 12345.678f)
 #endif
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, voff, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[4 * q + j]), orsrc, voff[ni][j], soff, 0);
+          }
+          soff += quad_step;
         }
       }
 #ifdef BSR_STAMPS
@@ -437,6 +538,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
 
     unsigned long long* d = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WM * WN) + wave) * 4;
     unsigned long long rt3 = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps3 != nullptr) {
+      unsigned long long* d3 = p.stamps3 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WM * WN) + wave) * 6;
+      d3[0] = stA; d3[1] = st0; d3[2] = stP[0]; d3[3] = stP[1]; d3[4] = stP[2]; d3[5] = st1;
+    }
     d[0] = st1 - stA; d[1] = st2 - st1; d[2] = ((rt3 - rtA) << 32) | (st2b - st2); d[3] = st3 - st2; (void)st0; (void)rt0;
   }
 #endif

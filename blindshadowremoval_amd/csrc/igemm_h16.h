@@ -209,9 +209,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[ph][mi][ni][i] = bias_n[ni];
+      for (int ni = 0; ni < NI; ++ni) acc[ph][mi][ni] = bias_tile(h, bias_n[ni]);      // fp32 matrix instruction (igemm_conv.h): the bias keeps its 24 bits
 
   // staging addresses: wave-uniform base + per-thread constant, computed once (see igemm_conv.h)
   unsigned in_goff[C::IN_PER_THREAD], w_off[C::W_PER_THREAD];

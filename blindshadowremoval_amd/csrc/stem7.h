@@ -76,9 +76,7 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
   const float bias = p.bias[r];
   f32x16 acc[RW];
 #pragma unroll
-  for (int mi = 0; mi < RW; ++mi)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[mi][i] = bias;
+  for (int mi = 0; mi < RW; ++mi) acc[mi] = bias_tile(h, bias);      // one matrix instruction per tile (igemm_conv.h)
   __syncthreads();
   __builtin_amdgcn_s_setprio(0);
 

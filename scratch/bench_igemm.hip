@@ -37,6 +37,7 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   const int nsteps_h = nchunk * T;
   unsigned long long* d_st2; CK(hipMalloc(&d_st2, (size_t)64 * NW * nsteps_h * 3 * 8)); CK(hipMemset(d_st2, 0, (size_t)64 * NW * nsteps_h * 3 * 8));
   a.stamps2 = getenv("BSR_TIMELINE") ? d_st2 : nullptr;
+  unsigned long long* d_st3; CK(hipMalloc(&d_st3, nblk * NW * 6 * 8)); a.stamps3 = d_st3;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e9;
   const int iters = getenv("BSR_ITERS") ? atoi(getenv("BSR_ITERS")) : 6;      // many back-to-back launches = the sustained clock
@@ -66,6 +67,15 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
   double mfma_per_wave = (double)nchunk * T * (CC / 2) * NI;       // MFMAs a wave issues
   printf("%-10s %7.1f us  %6.1f TFLOP/s | blocks %zu, per wave (cycles): prologue %.0f  loop %.0f  epilogue %.0f (issue %.0f) | loop ticks per MFMA %.2f\n",
          name, best * 1e3, flops / best / 1e9, nblk, pro / nw, loop / nw, epi / nw, epi_issue / nw, loop / nw / mfma_per_wave);
+  {   // where the prologue goes (cycles per wave)
+    std::vector<unsigned long long> s3(nblk * NW * 6);
+    CK(hipMemcpy(s3.data(), d_st3, s3.size() * 8, hipMemcpyDeviceToHost));
+    double dd[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < nblk * NW; ++i) for (int k = 0; k < 5; ++k) dd[k] += (double)(s3[i * 6 + k + 1] - s3[i * 6 + k]);
+    printf("   prologue split: address set-up %.0f | loads issued %.0f | loads landed + LDS written %.0f | barrier %.0f | accumulators + first fragments %.0f\n",
+           dd[0] / nw, dd[1] / nw, dd[2] / nw, dd[3] / nw, dd[4] / nw);
+    hipFree(d_st3);
+  }
   if (getenv("BSR_TIMELINE") && nblk >= 1088) {      // per-step timeline of 64 mid-kernel workgroups: matrix phase and barrier wait per step
     std::vector<unsigned long long> t2((size_t)64 * NW * nsteps_h * 3);
     CK(hipMemcpy(t2.data(), d_st2, t2.size() * 8, hipMemcpyDeviceToHost));
