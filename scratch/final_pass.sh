@@ -29,7 +29,7 @@ done
 [ -n "$BSR_SKIP_PMC" ] && exit 0
 BSR_ITERS=1500 ./scratch/bench_igemm 0 u > gpurun_out/r3_clock_stamps.txt 2>&1
 BSR_ITERS=300 BSR_SOLO=1 ./scratch/bench_igemm 0 u > gpurun_out/r3_clock_stamps_solo.txt 2>&1
-BSR_ITERS=100 BSR_TIMELINE=1 ./scratch/bench_igemm 0 u 2>&1 | head -3 > gpurun_out/r3_timeline.txt
-BSR_ITERS=100 BSR_TIMELINE=1 BSR_SOLO=1 ./scratch/bench_igemm 0 u 2>&1 | head -3 >> gpurun_out/r3_timeline.txt
+BSR_ITERS=100 BSR_TIMELINE=1 ./scratch/bench_igemm 0 u 2>&1 | head -4 > gpurun_out/r3_timeline.txt
+BSR_ITERS=100 BSR_TIMELINE=1 BSR_SOLO=1 ./scratch/bench_igemm 0 u 2>&1 | head -4 >> gpurun_out/r3_timeline.txt
 ./scratch/coexec_probe > gpurun_out/r3_coexec.txt 2>&1
 ls gpurun_out | grep r3_ | wc -l
