@@ -66,19 +66,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < C::W_PER_THREAD; ++i) {
     const int idx0 = tid + i * 256;
-    w_off[i] = (unsigned)((idx0 < C::W_V4 ? idx0 : C::W_V4 - 1) * 16);
+    w_off[i] = (unsigned)((idx0 % C::W_V4) * 16);                  // surplus threads of the last pass copy an element twice (same data): no guard at the LDS write
   }
+  // raw buffer over the packed weights, the step's image as the wave-uniform SGPR offset (igemm_conv.h: no 64-bit address arithmetic,
+  // no exec-mask branches inside the matrix loop)
+  const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w);
   auto fetch_w = [&](int s, f32x4 (&regs)[C::W_PER_THREAD]) {      // step s = (group, chunk)
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     const int ng = s / NCH, ch = s % NCH;
-    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)ch * p.n_pad + (size_t)group_tile0(ng) * 32) * LDP);
+    const unsigned soff = (unsigned)((ch * p.n_pad + group_tile0(ng) * 32) * LDP * 4);
 #pragma unroll
-    for (int i = 0; i < C::W_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + w_off[i]);
+    for (int i = 0; i < C::W_PER_THREAD; ++i)
+      regs[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off[i], soff, 0));
   };
   auto store_w = [&](int off, const f32x4 (&regs)[C::W_PER_THREAD]) {
     char* dst = reinterpret_cast<char*>(s_w + off);
 #pragma unroll
-    for (int i = 0; i < C::W_PER_THREAD; ++i)
-      if (tid + i * 256 < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
+    for (int i = 0; i < C::W_PER_THREAD; ++i) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
   };
 
   // ---- prologue: everything is issued before anything is waited for: weight steps 0 and 1, the bias slice, and this

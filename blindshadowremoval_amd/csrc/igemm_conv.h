@@ -263,7 +263,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
 #pragma unroll
   for (int i = 0; i < C::W_PER_THREAD; ++i) {
     const int idx0 = tid + i * NT;
-    w_off[i] = (unsigned)((idx0 < C::W_V4 ? idx0 : C::W_V4 - 1) * 16);
+    w_off[i] = (unsigned)((idx0 % C::W_V4) * 16);                  // threads past the end of the image re-copy an element another thread copies too
   }
   auto fetch_in = [&](int ch, f32x4 (&regs)[C::IN_PER_THREAD]) {
     if constexpr (ROWWISE) {
@@ -296,17 +296,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
     }
     }
   };
+  // Weights: a raw buffer over this N block's images, the step as the wave-uniform SGPR offset, the thread's part one constant VGPR
+  // offset — no 64-bit address arithmetic per load, and NO exec-mask guard at the LDS write (the surplus threads of the last pass copy
+  // an element twice, with the same data): inside the matrix loop every instruction of this wave, scalar ones included, delays its next MFMA.
+  const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w + (size_t)n0 * LDP);
+  const unsigned w_step_bytes = (unsigned)(p.n_pad * LDP * 4);
   auto fetch_w = [&](int step, f32x4 (&regs)[C::W_PER_THREAD]) {
-    const char* base = reinterpret_cast<const char*>(p.w + ((size_t)step * p.n_pad + n0) * LDP);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const unsigned soff = (unsigned)step * w_step_bytes;
 #pragma unroll
-    for (int i = 0; i < C::W_PER_THREAD; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + w_off[i]);
+    for (int i = 0; i < C::W_PER_THREAD; ++i)
+      regs[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off[i], soff, 0));
   };
   auto store_w = [&](int off, const f32x4 (&regs)[C::W_PER_THREAD]) {
     char* dst = reinterpret_cast<char*>(s_w + off);
 #pragma unroll
-    for (int i = 0; i < C::W_PER_THREAD; ++i) {
-      if (tid + i * NT < C::W_V4) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
-    }
+    for (int i = 0; i < C::W_PER_THREAD; ++i) *reinterpret_cast<f32x4*>(dst + w_off[i]) = regs[i];
   };
 
 #ifdef BSR_STAMPS
