@@ -12,7 +12,7 @@ cb = b["cpu_baseline"]
 block = '''<!-- BEGIN r3 DESIGN TABLE -->
 | dtype | images/s: two forwards in flight (one at a time) | ms / step | dominant kernel against its roofs | max abs error vs oracle |
 |---|---|---|---|---|
-| **f32** — fp32 matrix cores, the measured path (`value`) | **%.0f** (%.0f; over the round's boxes 6 440-6 650 and 6 270-6 390) | %.3f | transposed 3x3 `igemm_conv_kernel`: %.1f TFLOP/s = **%.1f %%** of 157.3 (`bound: mfma`); PMC: matrix pipe busy %.1f %% of the GPU-active cycles at %.2f GHz; 3x3-conv path %.1f %%; HBM traffic %.0f MB per launch (587 MB algorithmic) | %.1e, %d mask flips |
+| **f32** — fp32 matrix cores, the measured path (`value`) | **%.0f** (%.0f; before the round's last kernel passes 6 440-6 650 and 6 270-6 390) | %.3f | transposed 3x3 `igemm_conv_kernel`: %.1f TFLOP/s = **%.1f %%** of 157.3 (`bound: mfma`); PMC: matrix pipe busy %.1f %% of the GPU-active cycles at %.2f GHz; 3x3-conv path %.1f %%; HBM traffic %.0f MB per launch (587 MB algorithmic) | %.1e, %d mask flips |
 | f32x3 — split precision on the fp16 matrix cores (§4b) | %.0f (%.0f; 11.8-12.5 k one at a time over the round) | %.3f | transposed 3x3 `igemm_h16_kernel`: %.1f %% of its 833 TFLOP/s matrix roof, %.1f %% of 8 TB/s algorithmic (`bound: hbm`) | %.1e, %d mask flips |
 | f16 — fp16 operands + fp16 activation pack (configs[3]) | %.0f (%.0f; 15.9-16.7 k one at a time) | %.3f | bottleneck GEMMs: %.1f %% of 8 TB/s algorithmic (`bound: hbm`) | 1.4e-03 (tested at 2e-3) |
 

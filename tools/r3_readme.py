@@ -37,14 +37,14 @@ Other round-3 artefacts (this block is written by `tools/r3_readme.py` from the 
   B = 32, 1 500 back-to-back launches, stamps from kernel entry):
   `%s` /
   `%s`.
-  Per wave (final kernels): ~10.9 k cycles before the main loop (address set-up 3.7 k, issuing the loads 1.5 k, landed + in LDS 3.0 k, barrier
-  0.6 k, accumulator start + first fragments 2.1 k — the `prologue split` line), ~153 k in it (133 cycles per MFMA: a SIMD's two waves share the
-  pipe; 2 x 64 = 128 would be a pipe that never idles while both loop), ~4.8 k of epilogue; 8 rounds x 168.9 k cycles = 567 us of the
-  599-us kernel, the rest is workgroup turn-over and the last round's tail.  Matrix-busy inside a wave pair's lifetime: 2 x 73.7 k / 168.9 k
-  = 87 %%; over the whole kernel 82 %%.  With ONE workgroup per CU (`_solo`): `%s` —
-  a lone wave cannot feed the pipe back to back either (65.8 cycles per MFMA with all staging compiled out).  Before the round's last pass
-  (row-wise staging, one-round-trip prologue, quad-addressed epilogue — DESIGN.md §7) the same stamps read 14.5 k / 140.6 k (122 per MFMA) /
-  14.6 k at 600 us: prologue and epilogue shrank by 13 k cycles, the partner wave's loop grew by 10 k.
+  Per wave (final kernels): ~11.7 k cycles before the main loop (address set-up 4.6 k, issuing the loads 0.9 k, landed + in LDS 2.6 k, barrier
+  0.7 k, accumulator start + first fragments 2.9 k — the `prologue split` line), ~144 k in it (125 cycles per MFMA: a SIMD's two waves share the
+  pipe; 2 x 64 = 128 would be a pipe that never idles while both loop), ~6.0 k of epilogue; 8 rounds x 161.7 k cycles = 553 us of the
+  579-us kernel, the rest is workgroup turn-over and the last round's tail.  Matrix-busy inside a wave pair's lifetime: 2 x 73.7 k / 161.7 k
+  = 91 %%; over the whole kernel 85 %%.  With ONE workgroup per CU (`_solo`): `%s` —
+  a lone wave cannot feed the pipe back to back either (65.8 cycles per MFMA with all staging compiled out).  Before the round's last passes
+  (row-wise staging, one-round-trip prologue, quad-addressed epilogue, buffer-addressed unguarded weight staging — DESIGN.md §7) the same
+  stamps read 14.5 k / 140.6 k (122 per MFMA) / 14.6 k at 600 us.
   What was built on these numbers and measured (all dropped): persistent workgroups with an atomic tile counter (no turn-over,
   but 40-75 spilled SGPRs around the tile loop: 616 vs 600 us), half-period dephasing of the odd wave slot (no change: the residents are not
   in lockstep), 8-wave workgroups with 64 accumulators per wave (4 waves per SIMD: 623 vs 600 us), `v_mfma_f32_16x16x4_f32` instead of
