@@ -19,6 +19,7 @@
 // per ~25 cycles, but a tile's ~65 VALU instructions still fit inside the partner's 8 192-cycle MFMA phase).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "igemm_conv.h"
 
 namespace bsr {
@@ -75,14 +76,24 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float*
   // to tile 2p + (i >> 1)
   constexpr int V4_PER_TILE = kAttKT * kAttD / 4;       // 1024
   f32x4 kreg[4], vreg[4];
+  // K / V rows through a raw buffer over this image's qkv: the thread's part of an address is one of TWO constant VGPR offsets
+  // (float4 i and i + 2 of a thread are the same (key, channel) of the pair's two tiles), the tile is the SGPR offset, phi / g are the
+  // instruction's immediate offsets — no 64-bit multiply-add per row inside the key loop (VALU instructions there stand between this
+  // wave's MFMAs and take fp32 lanes from its partner's)
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t kv_rsrc = make_rsrc(base);
+  unsigned kv_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = (tid + i * 512) & (V4_PER_TILE - 1);
+    kv_voff[i] = (unsigned)(((idx / (kAttD / 4)) * (3 * kAttD) + (idx % (kAttD / 4)) * 4) * 4);
+  }
   auto fetch = [&](int pr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int idx = (tid + i * 512) & (V4_PER_TILE - 1), tile = 2 * pr + ((tid + i * 512) >> 10);
-      const int key = idx / (kAttD / 4), c4 = idx % (kAttD / 4);
-      const float* row = base + (size_t)(tile * kAttKT + key) * (3 * kAttD);
-      kreg[i] = *reinterpret_cast<const f32x4*>(row + kAttD + c4 * 4);
-      vreg[i] = *reinterpret_cast<const f32x4*>(row + 2 * kAttD + c4 * 4);
+      const unsigned soff = (unsigned)((2 * pr + (i >> 1)) * kAttKT * (3 * kAttD) * 4);      // (tid + i * 512) >> 10 == i >> 1 for tid < 512
+      kreg[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_voff[i & 1] + (unsigned)(kAttD * 4), soff, 0));
+      vreg[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_voff[i & 1] + (unsigned)(2 * kAttD * 4), soff, 0));
     }
   };
   auto publish = [&](int pbuf) {
@@ -102,8 +113,10 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float*
   publish(0);
   __syncthreads();
 
-  for (int pr = 0; pr < npair; ++pr) {
-    const int pbuf = pr & 1;
+  // two pairs per trip: the staging buffer of a pair (pr & 1) is then a compile-time constant and every LDS address of the loop a
+  // constant offset from one per-thread register (tokens % 128 == 0, so the pair count is even)
+  auto pair_step = [&](int pr, auto pbuf_const) {
+    constexpr int pbuf = decltype(pbuf_const)::value;
     if (pr + 1 < npair) fetch(pr + 1);
     const float* sk = smem + (2 * pbuf + grp) * kAttStageFloats;      // this wave's tile of the pair
     const float* sv = sk + kAttKT * kAttLdK;
@@ -137,13 +150,16 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float*
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] *= scale;
     }
-    float psum = 0.f;
+    f32x2 ps2 = {0.f, 0.f};                                  // packed subtraction and row sum: 16 instead of 32 VALU instructions
+    const f32x2 m2 = {m_run, m_run};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      s[i] = __builtin_amdgcn_exp2f(s[i] - m_run);
-      psum += s[i];
+    for (int i = 0; i < 16; i += 2) {
+      const f32x2 d = f32x2{s[i], s[i + 1]} - m2;
+      s[i] = __builtin_amdgcn_exp2f(d[0]);
+      s[i + 1] = __builtin_amdgcn_exp2f(d[1]);
+      ps2 += f32x2{s[i], s[i + 1]};
     }
-    l_run += psum;
+    l_run += ps2[0] + ps2[1];
 
     // O^T += g^T . P^T : register i of s holds key (i&3) + 8*(i>>2) + 4h
 #pragma unroll
@@ -158,6 +174,10 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float*
       publish(pbuf ^ 1);
       __syncthreads();
     }
+  };
+  for (int pr = 0; pr < npair; pr += 2) {
+    pair_step(pr, std::integral_constant<int, 0>{});
+    pair_step(pr + 1, std::integral_constant<int, 1>{});
   }
 
   // merge the two key streams: waves 4-7 hand (m, l, O^T) to waves 0-3 through LDS ([wq][66 values][64 lanes])
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float*
 }
 
 inline hipError_t launch_nonlocal_attention(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
-  if (tokens % (2 * kAttKT) != 0) return hipErrorInvalidValue;
+  if (tokens % (4 * kAttKT) != 0) return hipErrorInvalidValue;      // 128 queries per workgroup; the key loop takes two 64-key pairs per trip
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {
