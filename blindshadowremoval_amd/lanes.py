@@ -37,6 +37,8 @@ def concurrent_streams(device: int = 0, n: int = 2, candidates: int = 8) -> Tupl
         pool = [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
         if n == 1:
             return pool[:1], True
+        if not hasattr(torch.cuda, "_sleep"):                     # the spin kernel is a private torch helper: without it nothing can be verified
+            return pool[:n], False
         torch.cuda._sleep(1000)                                   # load the spin kernel before anything is timed
         serial = min(_spin_pair_ms(pool[0], pool[0]) for _ in range(2))
         chosen = [pool[0]]

@@ -1,0 +1,29 @@
+"""lanes.concurrent_streams: the streams it returns must be distinct and — when it says so — really overlap."""
+import time
+
+import pytest
+import torch
+
+from blindshadowremoval_amd.lanes import _SPIN_CYCLES, concurrent_streams
+
+
+@pytest.mark.gpu
+def test_streams_seen_to_overlap_do_overlap():
+    lanes, ok = concurrent_streams(0, 2)
+    assert len(lanes) == 2 and lanes[0] != lanes[1]
+    single, _ = concurrent_streams(0, 1)
+    assert len(single) == 1
+
+    def spin(a, b):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(4 * _SPIN_CYCLES)
+        with torch.cuda.stream(b):
+            torch.cuda._sleep(4 * _SPIN_CYCLES)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    serial = min(spin(lanes[0], lanes[0]) for _ in range(3))
+    both = min(spin(lanes[0], lanes[1]) for _ in range(3))
+    if ok:
+        assert both < 0.75 * serial, (both, serial)
