@@ -73,8 +73,6 @@ struct LayerW {
 
 enum KClass { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2, K_ATT = 3, K_CONV7 = 4, K_GLUE = 5, K_CONVT_NI2 = 6 };
 
-constexpr int C_RES = 257;   // ResBottleneck width (/root/reference/model.py:226)
-constexpr int CS_RES = 264;  // channel stride of its 257-wide tensors (multiple of the 24-wide K chunk)
 constexpr int CS_Y3X = 288;  // y3x = conv3 output + block input, all 9 channel tiles kept (TSM inputs are wider than 257: model_with_TSM.py:105-113)
 
 // Channel plan of the bottleneck trunk.  GSC (/root/reference/model.py:238,259): xa = cat[x 96 | uv 3], blocks 0-2 are 257

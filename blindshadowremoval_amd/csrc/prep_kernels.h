@@ -35,7 +35,7 @@ struct PrepRow {            // one row of the batch; offsets are bytes from the 
 __global__ __launch_bounds__(256) void prep_rows_kernel(const unsigned char* __restrict__ blob, const PrepRow* __restrict__ rows,
                                                         const double* __restrict__ grid, int S, float* __restrict__ out, float* __restrict__ hull) {
   __shared__ double s_tri[kPrepMaxTri * kPrepTriDoubles];
-  const PrepRow row = rows[blockIdx.y];
+  const PrepRow& row = rows[blockIdx.y];                        // read in place (wave-uniform scalar loads): a private copy indexed by the mesh number would live in scratch
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int oy = pix / S, ox = pix % S;
   float* o = out + ((size_t)blockIdx.y * S * S + pix) * 16;
