@@ -23,7 +23,7 @@ def test_streams_seen_to_overlap_do_overlap():
             torch.cuda._sleep(4 * _SPIN_CYCLES)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
-    serial = min(spin(lanes[0], lanes[0]) for _ in range(3))
-    both = min(spin(lanes[0], lanes[1]) for _ in range(3))
-    if ok:
-        assert both < 0.75 * serial, (both, serial)
+    serial = min(spin(lanes[0], lanes[0]) for _ in range(5))
+    both = min(spin(lanes[0], lanes[1]) for _ in range(5))
+    if ok:                                   # overlapping spin kernels take ~0.5x, serialised ones 1.0x: 0.85 leaves room for host timing noise
+        assert both < 0.85 * serial, (both, serial)
