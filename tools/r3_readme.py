@@ -56,6 +56,10 @@ Other round-3 artefacts (this block is written by `tools/r3_readme.py` from the 
 * `r3_bench_dist1.json` — `BSR_BENCH_FORCE_DIST=1 python bench.py` (the RCCL path on one rank; also run by the driver's `-m gpu` suite):
   all_gather of the 33.5-MB packed payload that the tail kernel writes directly (`bsr_forward_packed`), `verified: %s` (every rank's
   shard checked against what it packed), %.3f ms alone, %.3f ms exposed per step.
+* `r3_lane_overlap.txt` — `tools/lane_overlap.py` over `rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-secondary --repeats 1`
+  (the default two forwards in flight): the library's kernels run on two hardware queues, and while the second one is in use (warm-up +
+  timed region) two or more kernels are resident 93 %% of the time, the chip is never empty; a launch of the dominant kernel then lasts
+  455 us in the median (410 alone) because it shares the chip — which is why the per-kernel roofline is taken one forward at a time.
 * `r3_bench_tsm512.json` / `_f32x3` — BASELINE configs[4] per-rank shape (8 frames of 512x512, TSM generator, frame = 2): %.0f frames/s at f32, %.0f at f32x3.
 * `r3_loop_ffhq.json` / `r3_loop_ucb.json` — `python bench.py --loop ffhq|ucb`: the reference's test loops END TO END (input preparation ->
   forward -> post-processing -> PNG strips) on the GPU box, whose container is limited to **%d CPUs by its cgroup quota** (it shows 256).
