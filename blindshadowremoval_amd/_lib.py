@@ -8,7 +8,7 @@ from typing import Optional
 
 from .build import LIB_PATH
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_CLASSES = 7
 CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue", "convT3x3_ni2")
 
@@ -63,7 +63,7 @@ def load() -> ctypes.CDLL:
     lib.bsr_debug_attention.restype = c_i
     lib.bsr_debug_attention_dtype.argtypes = [c_v, c_v, c_i, c_i, c_i, c_v]
     lib.bsr_debug_attention_dtype.restype = c_i
-    lib.bsr_prep_rows.argtypes = [c_v, c_sz, c_sz, c_i, c_i, c_v, c_v, c_v]
+    lib.bsr_prep_rows.argtypes = [c_i, c_v, c_sz, c_sz, c_sz, c_i, c_i, c_v, c_v, c_v]
     lib.bsr_prep_rows.restype = c_i
     lib.bsr_check_range.argtypes = [c_v, c_v]
     lib.bsr_check_range.restype = c_i

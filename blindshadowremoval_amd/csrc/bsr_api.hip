@@ -385,7 +385,7 @@ int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
 
 extern "C" {
 
-int bsr_abi_version(void) { return 3; }
+int bsr_abi_version(void) { return 4; }
 
 const char* bsr_last_error(void) { return g_last_error.c_str(); }
 
@@ -504,9 +504,9 @@ int bsr_check_range(bsr_handle* h, void* stream) {
   DeviceGuard guard(h->device);
   HIP_TRY(guard.err);
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-  volatile unsigned* f = h->range_flag;
-  if (*f == 0u) return BSR_OK;
-  *f = 0u;
+  // read-and-clear in ONE atomic exchange: a report raised by another stream's forward between a separate read and clear would be
+  // lost (one stream per handle remains the rule — bsr_hip.h — but the flag itself no longer depends on it)
+  if (__atomic_exchange_n(h->range_flag, 0u, __ATOMIC_SEQ_CST) == 0u) return BSR_OK;
   return fail(BSR_ERR_RANGE, kRangeMsg);
 }
 
@@ -706,10 +706,18 @@ int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const f
   return forward_impl(h, inputs, uv, reg, frame, share != 0, B, H, W, gs, con_rgb, mask22, dif, stream);
 }
 
-int bsr_prep_rows(const void* d_blob, size_t rows_off, size_t grid_off, int B, int S, float* out, float* hull_tmp, void* stream) {
+int bsr_prep_rows(int device, const void* d_blob, size_t blob_bytes, size_t rows_off, size_t grid_off, int B, int S, float* out, float* hull_tmp,
+                  void* stream) {
   if (d_blob == nullptr || out == nullptr || hull_tmp == nullptr) return fail(BSR_ERR_ARG, "bsr_prep_rows: null argument");
   if (B <= 0 || S <= 0 || (S * S) % 256 != 0) return fail(BSR_ERR_ARG, "bsr_prep_rows: B must be positive and S*S a multiple of 256");
   if (rows_off % 8 != 0 || grid_off % 8 != 0) return fail(BSR_ERR_ARG, "bsr_prep_rows: table offsets must be 8-byte aligned");
+  // the two tables the kernels index directly must lie inside the blob (what the row records point to — images, triangle tables — is
+  // device memory this library cannot read back cheaply: prep.py validates every record against blob_bytes before the upload)
+  if (rows_off > blob_bytes || (size_t)B * sizeof(bsr::PrepRow) > blob_bytes - rows_off || grid_off > blob_bytes ||
+      (size_t)S * sizeof(double) > blob_bytes - grid_off)
+    return fail(BSR_ERR_ARG, "bsr_prep_rows: the row / grid tables do not fit in blob_bytes");
+  DeviceGuard guard(device);
+  HIP_TRY(guard.err);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned char* blob = static_cast<const unsigned char*>(d_blob);
   const dim3 grid((unsigned)(S * S / 256), (unsigned)B);

@@ -603,6 +603,10 @@ inline hipError_t launch_conv_n16(ConvN16Args a, int batch, hipStream_t stream, 
   a.tiles_x = a.W / C::TW;
   a.tiles_y = a.H / C::TH;
   a.batch = batch;
+  // FUSE: the boundary carry is double-buffered by TILE PARITY and a strip start clears the parity-0 half, which is only right when
+  // the previous strip ended on parity 1 — an even number of tiles per strip (bsr_forward's W % 256 == 0 guarantees it; refuse
+  // anything else here rather than corrupt gs / mask22 at strip boundaries)
+  if (FUSE && (a.tiles_x & 1)) return hipErrorInvalidValue;
   const int ntiles = a.tiles_x * a.tiles_y * batch;
   const int nunits = FUSE ? a.tiles_y * batch : ntiles;        // FUSE: a workgroup's unit of work is a row strip
   hipLaunchKernelGGL(kern, dim3(nunits < resident ? nunits : resident), dim3(256), C::SMEM_BYTES, stream, a);

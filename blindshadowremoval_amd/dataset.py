@@ -389,6 +389,10 @@ class Dataset:
             self.close()
 
 
+class _JobFailed(Exception):
+    """A worker's 'err' reply, parked in _SelectPool._done under the failed job's ticket until result() / imap() reaches it."""
+
+
 class _SelectPool:
     """N worker PROCESSES (`python -m blindshadowremoval_amd._row_worker`: plain subprocesses over pipes — nothing is forked from a process
     that may hold a GPU context, and the workers do not re-import the parent's __main__), driven from the CALLING thread with
@@ -450,14 +454,37 @@ class _SelectPool:
         return self._send(min(range(len(self.procs)), key=self._load.__getitem__), job)
 
     def result(self, seq: int):
+        """Value of ticket `seq`; a job that failed in its worker raises HERE (once, for its own ticket) — the worker's other tickets
+        stay valid and keep their order."""
         while seq not in self._done:
             self._pump(block=True)
-        return self._done.pop(seq)
+        value = self._done.pop(seq)
+        if isinstance(value, _JobFailed):
+            raise RuntimeError("loader worker failed: %s" % value.args[0])
+        return value
+
+    def _parse(self, w: int) -> int:
+        """Move every COMPLETE reply in worker w's buffer to _done (a failed job as a _JobFailed value under its own ticket: the
+        ticket queue and the load count advance for failures exactly as for results); -> replies parsed."""
+        import pickle
+        import struct
+        buf, n_done = self._buf[w], 0
+        while len(buf) >= 8:
+            n = struct.unpack_from("<Q", buf)[0]
+            if len(buf) < 8 + n:
+                break
+            status, value = pickle.loads(bytes(buf[8:8 + n]))
+            del buf[:8 + n]
+            seq = self._owner[w].pop(0)
+            self._load[w] -= 1
+            self._done[seq] = value if status == "ok" else _JobFailed(value)
+            n_done += 1
+        return n_done
 
     def _pump(self, block: bool) -> None:
-        import pickle
         import select
-        import struct
+        if sum(self._parse(w) for w in range(len(self.procs)) if self._buf[w]):
+            block = False                        # replies were already sitting in a buffer: hand them out before waiting for more
         fds = {p.stdout.fileno(): i for i, p in enumerate(self.procs) if self._load[i] > 0}
         wfds = {p.stdin.fileno(): i for i, p in enumerate(self.procs) if self._out[i]}
         if not fds and not wfds:
@@ -474,18 +501,10 @@ class _SelectPool:
                 except BlockingIOError:
                     break
                 if not chunk:
+                    self._parse(w)
                     raise RuntimeError("loader worker exited (code %s)" % self.procs[w].poll())
                 buf += chunk
-            while len(buf) >= 8:
-                n = struct.unpack_from("<Q", buf)[0]
-                if len(buf) < 8 + n:
-                    break
-                status, value = pickle.loads(bytes(buf[8:8 + n]))
-                del buf[:8 + n]
-                if status != "ok":
-                    raise RuntimeError("loader worker failed: %s" % value)
-                self._done[self._owner[w].pop(0)] = value
-                self._load[w] -= 1
+            self._parse(w)
 
     def imap(self, jobs, depth: int):
         jobs = iter(jobs)
@@ -505,7 +524,10 @@ class _SelectPool:
                 self._send(w, job)
                 sent += 1
             if nxt in self._done:
-                yield self._done.pop(nxt)
+                value = self._done.pop(nxt)
+                if isinstance(value, _JobFailed):
+                    raise RuntimeError("loader worker failed: %s" % value.args[0])
+                yield value
                 nxt += 1
                 self._pump(block=False)
                 continue

@@ -158,15 +158,21 @@ class Logging(object):
                 self._png_pool._pump(block=False)
                 if not all(t in self._png_pool._done for t in tickets):
                     return
+            first = None
             try:
-                for t in tickets:
-                    self._png_pool.result(t)
+                for t in tickets:                # every ticket of the batch is collected even when one strip failed (disk full, bad path) ...
+                    try:
+                        self._png_pool.result(t)
+                    except RuntimeError as e:
+                        first = first or e
             finally:
                 self._shm_batches.pop(0)
                 try:
                     os.unlink(shm)
                 except OSError:
                     pass
+            if first is not None:                # ... and the first failure is reported once the batch's shared-memory file is gone
+                raise first
             block = False
 
     def warm(self) -> None:
@@ -200,12 +206,18 @@ class Logging(object):
     def flush(self) -> None:
         """Wait for every queued PNG (re-raises a writer's exception)."""
         tickets, self._png_tickets = self._png_tickets, []
-        for t in tickets:                        # PNG worker processes: a failed job raises here
-            self._png_pool.result(t)
-        while self._shm_batches:
-            self._reap(block=True)
-        pending, self._pending = self._pending, []
         first = None
+        for t in tickets:                        # PNG worker processes: a failed job is reported after ALL of them were waited for
+            try:
+                self._png_pool.result(t)
+            except RuntimeError as e:
+                first = first or e
+        while self._shm_batches:
+            try:
+                self._reap(block=True)
+            except RuntimeError as e:
+                first = first or e
+        pending, self._pending = self._pending, []
         for f in pending:                        # wait for ALL of them even when one failed, then report the first failure
             try:
                 f.result()
@@ -515,7 +527,9 @@ class FSRNet(object):
         """train_test_GSC.py:360-408 + test_step :411-748.  Returns [(name, figs, {'ssim','psnr'})] with the reference's seven
         figures per item; ``postprocess=False`` returns the raw generator outputs [(name, [img, gs, con_rgb, dif, gt, face])].
         ``mask_files``: optional explicit per-item list (as ``_ucb_masks()`` returns it) instead of the folder listing."""
-        self._post_writes_png = bool(postprocess and self.post_workers > 0 and not self.return_figs)
+        # return_figs=False: nobody gets the figures back, so whoever post-processes an item (a pool worker, or this process when
+        # post_workers == 0) writes its PNG strip itself — the reference always writes the strip (utils.py:196-204)
+        self._post_writes_png = bool(postprocess and not self.return_figs)
         return self._loop(dataset_val, batch, ucb=True, postprocess=postprocess, mask_files=mask_files)
 
 

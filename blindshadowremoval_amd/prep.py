@@ -125,6 +125,12 @@ def _layout(parts, size: int):
             r["ntri"][m] = t.shape[0]
             pieces.append((int(r["tri_off"][m]), t))
     pieces.append((rows_off, rows))
+    # the kernel dereferences these offsets on the device without bounds information: every record is checked against the blob here
+    for i, r in enumerate(rows):
+        ends = [int(r["img_off"]) + int(r["h"]) * int(r["w"]) * 3, int(r["gt_off"]) + int(r["h"]) * int(r["w"]) * 3]
+        ends += [int(r["tri_off"][m]) + int(r["ntri"][m]) * TRI_DOUBLES * 8 for m in range(4)]
+        if min(int(r["img_off"]), int(r["gt_off"]), *(int(x) for x in r["tri_off"])) < 0 or max(ends) > off or any(int(n) > MAX_TRI or int(n) < 0 for n in r["ntri"]):
+            raise ValueError("prep blob: row %d points outside the %d-byte blob" % (i, off))
     return off, rows_off, grid_off, pieces
 
 
@@ -176,7 +182,7 @@ class DevicePrep:
             ev.record()
             out = torch.empty((B, S, S, 16), dtype=torch.float32, device=dev)
             tmp = torch.empty((B, S, S), dtype=torch.float32, device=dev)
-            rc = self._lib.bsr_prep_rows(d_blob.data_ptr(), rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
+            rc = self._lib.bsr_prep_rows(self.device, d_blob.data_ptr(), total, rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
                                          torch.cuda.current_stream().cuda_stream)
         self._check(rc, "bsr_prep_rows")
         boxes = np.stack([np.asarray(p[2], np.float32) for p in parts], axis=0)

@@ -116,8 +116,12 @@ int bsr_timing_entry(bsr_handle* h, int i, char* name, size_t name_cap, float* m
  * d_blob: ONE device buffer holding, at 8-byte aligned offsets, B row records (csrc/prep_kernels.h PrepRow: image / ground-truth
  * RGB8 offsets and size, crop box, four triangle tables), `S` float64 grid coordinates (numpy.linspace(0, 1, S)) and the data
  * they point to — blindshadowremoval_amd/prep.py builds it.  out: [B,S,S,16] float32 = img3 | gt3 | uvm3 | reg_in3 | reg_out3 |
- * face1 (the packed layout FSRNet.test_step / test_step_FFHQ split, train_test_GSC.py:419,870); hull_tmp: [B,S,S] float32 scratch. */
-int bsr_prep_rows(const void* d_blob, size_t rows_off, size_t grid_off, int B, int S, float* out, float* hull_tmp, void* stream);
+ * face1 (the packed layout FSRNet.test_step / test_step_FFHQ split, train_test_GSC.py:419,870); hull_tmp: [B,S,S] float32 scratch.
+ * device: the GPU d_blob / out / hull_tmp live on (the call runs there whatever the caller's current device is); blob_bytes: size of
+ * d_blob — the row and grid tables are checked against it (BSR_ERR_ARG), and the builder of the blob must keep every offset a row
+ * record holds (img_off / gt_off + h*w*3, tri_off[k] + ntri[k]*144) inside it: prep.py does, before the upload.  ABI 4. */
+int bsr_prep_rows(int device, const void* d_blob, size_t blob_bytes, size_t rows_off, size_t grid_off, int B, int S, float* out, float* hull_tmp,
+                  void* stream);
 
 /* Test hook: the fused NonLocalBlock attention kernel alone (/root/reference/model.py:51-53).
  * qkv [B,tokens,384] (theta | phi | g, 128 channels each) -> y [B,tokens,128]; tokens % 128 == 0. */

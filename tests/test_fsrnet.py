@@ -264,7 +264,7 @@ def test_ucb_post_processing_in_worker_processes_equals_the_in_process_form(gold
     cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
     w = init_weights(1)
     runs = []
-    for k, (pw, figs) in enumerate(((0, True), (3, True), (3, False))):
+    for k, (pw, figs) in enumerate(((0, True), (3, True), (3, False), (0, False))):      # (0, False): no pool, no figures back — the strips are still written
         cfg.CHECKPOINT_DIR = str(tmp_path / ("run%d" % k))
         ds = D.Dataset(cfg, "test", ucb=True, workers=2)
         ds.name_list = ds.name_list[:20]
@@ -290,4 +290,4 @@ def test_ucb_post_processing_in_worker_processes_equals_the_in_process_form(gold
                     # torch's CPU bilinear resize rounds differently with 1 thread (the workers) than with the parent's many: a handful of
                     # resized pixels land one grey level apart; anything more is a real difference
                     assert int(np.abs(A - B).max()) <= 1 and int((A != B).any(2).sum()) <= 64, (i, cols)
-    assert all(r[1] is None for r in runs[2][0]) and all(len(r[1]) == 7 for r in runs[1][0])
+    assert all(r[1] is None for r in runs[2][0]) and all(r[1] is None for r in runs[3][0]) and all(len(r[1]) == 7 for r in runs[1][0])
