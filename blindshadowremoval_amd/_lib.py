@@ -16,7 +16,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed")
+           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed")
 
 
 def load() -> ctypes.CDLL:
@@ -63,6 +63,8 @@ def load() -> ctypes.CDLL:
     lib.bsr_debug_attention.restype = c_i
     lib.bsr_debug_attention_dtype.argtypes = [c_v, c_v, c_i, c_i, c_i, c_v]
     lib.bsr_debug_attention_dtype.restype = c_i
+    lib.bsr_debug_attention_qw.argtypes = [c_v, c_v, c_i, c_i, c_i, c_v]
+    lib.bsr_debug_attention_qw.restype = c_i
     lib.bsr_prep_rows.argtypes = [c_i, c_v, c_sz, c_sz, c_sz, c_i, c_i, c_v, c_v, c_v]
     lib.bsr_prep_rows.restype = c_i
     lib.bsr_check_range.argtypes = [c_v, c_v]

@@ -33,16 +33,23 @@ constexpr int kAttSmemBytes = 4 * kAttStageFloats * 4;                  // two t
 static_assert(kAttSmemBytes <= 160 * 1024, "LDS budget");
 static_assert(66 * 64 * 4 <= 4 * kAttStageFloats, "merge scratch fits the staging buffers");
 
-__global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
+// QW = query waves per workgroup (x 2 key streams): 4 = the 8-wave, 128-query workgroup the B = 32 forward runs (one round of
+// B x 8 workgroups on 256 CUs).  Round 4: QW = 2 / 1 are the same kernel with 64 / 32 queries per workgroup for SMALL batches —
+// LDS (two staged tile pairs, 133 KB) allows one workgroup per CU whatever its size, so with B x 8 < 256 workgroups most CUs idle;
+// halving the query block doubles the grid, and a wave's own work (32 queries x half the keys) is unchanged.
+template <int QW>
+__global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = QW * 128;                                 // threads
+  constexpr int SV = 2048 / NT;                                // float4 per operand and thread that stage one tile pair
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wq = wave & 3;                    // key stream (even / odd tiles), query block of 32
+  const int grp = wave / QW, wq = wave % QW;                   // key stream (even / odd tiles), query block of 32
   const int h = lane >> 5, r = lane & 31;
   // Workgroup -> (image, query block).  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2;
   // all query blocks of an image re-read the same K/V (1 MB), so they are given ids that are congruent mod 8 and thus share
   // one XCD's L2 (measured before: 285 MB fetched per launch for 50 MB of qkv, every XCD pulling its own copy of every K/V).
-  const int qblocks = tokens / 128;
+  const int qblocks = tokens / (QW * 32);
   int img, qb;
   {
     const int nblk = gridDim.x, b = blockIdx.x;
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float*
     }
   }
   const float* base = qkv + (size_t)img * tokens * (3 * kAttD);
-  const int q = qb * 128 + wq * 32 + r;
+  const int q = qb * (QW * 32) + wq * 32 + r;
 
   // theta fragment of this lane's query: element j of group g is channel 8g + 4h + j
   f32x4 qf[kAttD / 8];
@@ -72,34 +79,34 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float*
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // staging of a tile PAIR (2p, 2p+1) by 512 threads: 2 x 1024 float4 per operand -> 4 + 4 per thread; float4 i of a thread belongs
-  // to tile 2p + (i >> 1)
+  // staging of a tile PAIR (2p, 2p+1) by NT threads: 2 x 1024 float4 per operand -> SV + SV per thread (4 + 4 at 512 threads); float4 i
+  // of a thread belongs to tile 2p + ((tid + i * NT) >> 10)
   constexpr int V4_PER_TILE = kAttKT * kAttD / 4;       // 1024
-  f32x4 kreg[4], vreg[4];
-  // K / V rows through a raw buffer over this image's qkv: the thread's part of an address is one of TWO constant VGPR offsets
-  // (float4 i and i + 2 of a thread are the same (key, channel) of the pair's two tiles), the tile is the SGPR offset, phi / g are the
-  // instruction's immediate offsets — no 64-bit multiply-add per row inside the key loop (VALU instructions there stand between this
-  // wave's MFMAs and take fp32 lanes from its partner's)
+  constexpr int NV = V4_PER_TILE / NT;                  // distinct (key, channel) positions per thread: float4 i and i + NV are the same position of the pair's two tiles
+  f32x4 kreg[SV], vreg[SV];
+  // K / V rows through a raw buffer over this image's qkv: the thread's part of an address is one of NV constant VGPR offsets, the
+  // tile is the SGPR offset, phi / g are the instruction's immediate offsets — no 64-bit multiply-add per row inside the key loop (VALU
+  // instructions there stand between this wave's MFMAs and take fp32 lanes from its partner's)
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t kv_rsrc = make_rsrc(base);
-  unsigned kv_voff[2];
+  unsigned kv_voff[NV];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = (tid + i * 512) & (V4_PER_TILE - 1);
+  for (int i = 0; i < NV; ++i) {
+    const int idx = (tid + i * NT) & (V4_PER_TILE - 1);
     kv_voff[i] = (unsigned)(((idx / (kAttD / 4)) * (3 * kAttD) + (idx % (kAttD / 4)) * 4) * 4);
   }
   auto fetch = [&](int pr) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned soff = (unsigned)((2 * pr + (i >> 1)) * kAttKT * (3 * kAttD) * 4);      // (tid + i * 512) >> 10 == i >> 1 for tid < 512
-      kreg[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_voff[i & 1] + (unsigned)(kAttD * 4), soff, 0));
-      vreg[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_voff[i & 1] + (unsigned)(2 * kAttD * 4), soff, 0));
+    for (int i = 0; i < SV; ++i) {
+      const unsigned soff = (unsigned)((2 * pr + (i / NV)) * kAttKT * (3 * kAttD) * 4);      // (tid + i * NT) >> 10 == i / NV for tid < NT
+      kreg[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_voff[i % NV] + (unsigned)(kAttD * 4), soff, 0));
+      vreg[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_voff[i % NV] + (unsigned)(2 * kAttD * 4), soff, 0));
     }
   };
   auto publish = [&](int pbuf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = (tid + i * 512) & (V4_PER_TILE - 1), sel = (tid + i * 512) >> 10;
+    for (int i = 0; i < SV; ++i) {
+      const int idx = (tid + i * NT) & (V4_PER_TILE - 1), sel = (tid + i * NT) >> 10;
       const int key = idx / (kAttD / 4), c4 = idx % (kAttD / 4);
       float* sk = smem + (2 * pbuf + sel) * kAttStageFloats;
       float* sv = sk + kAttKT * kAttLdK;
@@ -216,18 +223,41 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_kernel(const float*
   }
 }
 
-inline hipError_t launch_nonlocal_attention(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
-  if (tokens % (4 * kAttKT) != 0) return hipErrorInvalidValue;      // 128 queries per workgroup; the key loop takes two 64-key pairs per trip
+template <int QW>
+inline hipError_t launch_nonlocal_attention_qw(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
+  auto kern = nonlocal_attention_kernel<QW>;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nonlocal_attention_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kAttSmemBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kAttSmemBytes);
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
-  hipLaunchKernelGGL(nonlocal_attention_kernel, dim3(batch * (tokens / 128)), dim3(512), kAttSmemBytes, stream, qkv, out, tokens);
+  hipLaunchKernelGGL(kern, dim3(batch * (tokens / (QW * 32))), dim3(QW * 128), kAttSmemBytes, stream, qkv, out, tokens);
   return hipGetLastError();
+}
+
+// qw = 0: pick the query block by the grid it gives.  LDS allows ONE workgroup per CU whatever its size, and a wave's work is the same
+// in every shape, so a launch costs (rounds of workgroups over the CUs) x (time of one workgroup): measured 139 us for the 8-wave
+// shape (two waves share each SIMD), ~80 us for the 4- and 2-wave shapes (one wave per SIMD) — B = 32: 256 x 8 waves, one round;
+// B = 16: 256 x 4 waves; B = 10: 160 x 4 waves (not 320 x 2: two rounds); B <= 8: x 2 waves.  Every variant computes the same
+// arithmetic in the same order per query, so the choice does not change a single bit of the output.
+inline hipError_t launch_nonlocal_attention(const float* qkv, float* out, int batch, int tokens, hipStream_t stream, int qw = 0) {
+  if (tokens % (4 * kAttKT) != 0) return hipErrorInvalidValue;      // 128-query blocks; the key loop takes two 64-key pairs per trip
+  if (qw == 0) {
+    const long long cus = device_cu_count();
+    const long long blocks128 = (long long)batch * (tokens / 128);
+    long long best = -1;
+    for (int cand : {4, 2, 1}) {                                    // ties go to the larger workgroup
+      const long long rounds = (blocks128 * (4 / cand) + cus - 1) / cus;
+      const long long cost = rounds * (cand == 4 ? 17 : 10);
+      if (best < 0 || cost < best) { best = cost; qw = cand; }
+    }
+  }
+  if (qw == 4) return launch_nonlocal_attention_qw<4>(qkv, out, batch, tokens, stream);
+  if (qw == 2) return launch_nonlocal_attention_qw<2>(qkv, out, batch, tokens, stream);
+  if (qw == 1) return launch_nonlocal_attention_qw<1>(qkv, out, batch, tokens, stream);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace bsr

@@ -249,7 +249,15 @@ struct Launcher {
     }
     begin(cls, name);
     static_assert(k33 || k11, "igemm layers are 3x3 or 1x1");
-    if (!h16)
+    // Small batches (round 4): the 1/8-resolution trunk layers have B x 8 pixel tiles of 4x32 — fewer workgroups than CUs below
+    // B = 16.  Their 2x32-pixel variant (two waves on the pixel rows x two on the channel halves, the same per-element accumulation
+    // order: bit-identical) doubles the grid.
+    constexpr bool kTrunk = !TR && S == 1 && NI == 2 && (CC == 32 || (k11 && CC == 24));
+    bool half_tile = false;
+    if constexpr (kTrunk) half_tile = !h16 && mh % 2 == 0 && (long long)(mh / 4) * (mw / 32) * h->B * nb < bsr::device_cu_count();
+    if (half_tile) {
+      if constexpr (kTrunk) check(bsr::launch_igemm_conv<KH, KW, S, TR, 2, 32, 2, 2, 1, 1, CC, INB>(a, h->B, s), name);
+    } else if (!h16)
       check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
     else if (nsplit == 2)
       check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 2>(a, h->B, s), name);
@@ -269,8 +277,16 @@ struct Launcher {
     if (rc != BSR_OK) return;
     using C = bsr::GemmNLoopCfg<NI, NCH>;
     LayerW l;
-    constexpr int kNSplit = 2;                                  // two workgroups per CU share the N range
     const int tiles = (n_store + 31) / 32;
+    // two workgroups per CU share the N range; small batches (fewer than 2 x CUs workgroups that way) split it further, down to one
+    // channel group per range — every 32-channel tile is computed the same way whatever range it falls in (bit-identical)
+    int kNSplit = 2;
+    {
+      const long long mblocks = (long long)(pixels / C::BM);
+      const int want = (int)((2LL * bsr::device_cu_count() + mblocks - 1) / (mblocks > 0 ? mblocks : 1));
+      const int most = (tiles + NI - 1) / NI;
+      kNSplit = want < 2 ? 2 : (want > most ? most : want);
+    }
     rc = find_layer(h, name, NCH, 1, 36, (tiles + NI) * 32, &l);   // the last group of a range may read (zero) rows past its tiles
     if (rc != BSR_OK) return;
     if (pixels % C::BM != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': pixel count is not a multiple of 128"); return; }
@@ -738,6 +754,14 @@ int bsr_debug_attention_dtype(const float* qkv, float* y, int B, int tokens, int
     HIP_TRY(bsr::launch_nonlocal_attention_x3(qkv, y, B, tokens, static_cast<hipStream_t>(stream)));
   else
     return fail(BSR_ERR_ARG, "bsr_debug_attention: unknown dtype");
+  return BSR_OK;
+}
+
+int bsr_debug_attention_qw(const float* qkv, float* y, int B, int tokens, int qw, void* stream) {
+  if (qkv == nullptr || y == nullptr) return fail(BSR_ERR_ARG, "bsr_debug_attention_qw: null argument");
+  if (B <= 0 || tokens <= 0 || tokens % 128 != 0) return fail(BSR_ERR_ARG, "bsr_debug_attention_qw: tokens must be a positive multiple of 128");
+  if (qw != 0 && qw != 1 && qw != 2 && qw != 4) return fail(BSR_ERR_ARG, "bsr_debug_attention_qw: qw must be 0 (automatic), 1, 2 or 4 query waves per workgroup");
+  HIP_TRY(bsr::launch_nonlocal_attention(qkv, y, B, tokens, static_cast<hipStream_t>(stream), qw));
   return BSR_OK;
 }
 

@@ -281,6 +281,7 @@ inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, int nsplit,
   const int tiles_total = (a.n_store + 31) / 32;
   a.tiles_x = (tiles_total + nsplit - 1) / nsplit;            // tiles per blockIdx.y range
   if (a.tiles_x > C::MAX_TILES) return hipErrorInvalidValue;
+  nsplit = (tiles_total + a.tiles_x - 1) / a.tiles_x;         // no empty range
   hipLaunchKernelGGL(kern, dim3((unsigned)(total_pixels / C::BM), nsplit), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }

@@ -93,6 +93,17 @@ struct PerDeviceOnce {
   }
 };
 
+// compute units of the current device (cached per device ordinal; 256 on MI355X) — launchers that pick a tile size by the grid it gives
+inline int device_cu_count() {
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (dev >= 0 && once.done[dev]) return once.value[dev];
+  int cur = 0, cus = 0;
+  if (hipGetDevice(&cur) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur) != hipSuccess || cus <= 0) return 256;
+  if (dev >= 0) { once.value[dev] = cus; once.done[dev] = true; }
+  return cus;
+}
+
 struct ConvArgs {
   const float* in;      // NHWC activations, channel stride in_cs, first channel in_coff
   int in_cs, in_coff;

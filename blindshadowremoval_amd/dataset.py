@@ -62,6 +62,17 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def cpu_share() -> int:
+    """CPUs ONE rank of a node may plan its worker pools on: usable_cpus() divided by the ranks sharing the node (torchrun's
+    LOCAL_WORLD_SIZE; 1 outside a launcher) — eight ranks each sizing their loader / PNG / post-processing pools for the whole quota
+    would oversubscribe it eightfold."""
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local_world = 1
+    return max(1, usable_cpus() // local_world)
+
+
 def natural_key(s: str):
     """natsort-style key: digit runs compare numerically (dataset.py:47,57 use natsorted)."""
     return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)]
@@ -299,8 +310,9 @@ class Dataset:
             raise NotImplementedError("only the test loaders are provided (GSC: dset=None; TSM: dset='sfw' | 'sfw_video'); training loaders are out of scope")
         self.config, self.mode, self.ucb, self.rows, self.dset = config, mode, ucb, rows, dset
         self._rng = random.Random(seed)
+        self._shard = None
         if workers < 0:
-            workers = min(usable_cpus(), 16)
+            workers = min(cpu_share(), 16)
         self.workers = int(workers)
         self.prefetch = int(prefetch) if prefetch is not None else max(2, 2 * self.workers)
         self._pool = None
@@ -317,6 +329,17 @@ class Dataset:
                 self.name_list += sorted(glob.glob(os.path.join(folder, pattern)), key=natural_key)
         self.feed: Iterator = self._iterate()
 
+    def shard(self, lo: int, hi: int) -> None:
+        """Data-parallel loops (FSRNet under a process group): `feed` yields only items [lo, hi) of `name_list`, which itself stays
+        the FULL list (the loops index masks and report progress by the global position).  Must be called before the first element
+        is drawn.  The seeded sibling draws of `rows > 1` are still consumed for every item of the list, so an item's element is the
+        same whichever rank prepares it."""
+        if getattr(self, "_started", False):
+            raise RuntimeError("Dataset.shard() after the first element was drawn")
+        if not 0 <= lo <= hi <= len(self.name_list):
+            raise ValueError("shard [%d, %d) outside the %d-item name list" % (lo, hi, len(self.name_list)))
+        self._shard = (int(lo), int(hi))
+
     def _gt_path(self, lm_path: str) -> Optional[str]:
         if not self.ucb:
             return None
@@ -326,15 +349,21 @@ class Dataset:
     def _jobs(self):
         """Jobs in name_list order; the sibling draws consume the seeded RNG in that order whatever the worker count."""
         size = self.config.IMG_SIZE
+        self._started = True
+        lo, hi = self._shard if self._shard is not None else (0, len(self.name_list))
         if self.dset is not None:                                          # TSM loaders: the element is a group of 2 / 10 coupled frames
-            for label in self.name_list:
+            for label in self.name_list[lo:hi]:
                 yield (label, "<" + self.dset + ">", [], size)
             return
-        for lm_path in self.name_list:
+        for i, lm_path in enumerate(self.name_list):
+            if i >= hi:
+                break
             sibs = []
             if self.rows > 1:
                 siblings = sorted(glob.glob(os.path.join(os.path.dirname(lm_path), "*.npy")), key=natural_key)
                 sibs = [siblings[self._rng.randint(0, len(siblings) - 1)] for _ in range(self.rows - 1)]
+            if i < lo:
+                continue                                                   # another rank's item: only its RNG draws are consumed
             gt = self._gt_path(lm_path)
             yield (lm_path, ("<device>", gt) if self.device_prep is not None else gt, sibs, size)
 

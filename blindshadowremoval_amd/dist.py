@@ -2,6 +2,11 @@
 collective per batch — an all-gather (RCCL over xGMI on MI355X; gloo in the CPU tests) that re-assembles the
 outputs callers consume on every rank.  GSC inference has no cross-sample op (BatchNorm uses moving
 statistics, ShareLayer is never called: /root/reference/model.py:221 vs :228-290), so no other exchange exists.
+
+`ShardedGenerator` is the product form of what `bench.py` times at N > 1: the tail kernel writes con_rgb | dif straight into the
+`[B,H,W,4]` all-gather payload (`Generator(..., packed_out=)` = bsr_forward_packed), the gather is asynchronous and double-buffered,
+so batch k's gather runs beside batch k + 1's forward.  The data-parallel form of the reference's LOOPS (`FSRNet.test` /
+`testFFHQ` over a sharded name list) lives in fsrnet.py and needs no data-path collective at all.
 """
 from __future__ import annotations
 
@@ -20,6 +25,13 @@ def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
         out.append((lo, hi))
         lo = hi
     return out
+
+
+def rank_world(group=None) -> Tuple[int, int]:
+    """(rank, world size) in `group` (the default group when None); (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
 
 
 def all_gather_rows(local: torch.Tensor, counts: Sequence[int], group=None, async_op: bool = False,
@@ -45,30 +57,121 @@ def all_gather_rows(local: torch.Tensor, counts: Sequence[int], group=None, asyn
     return finish, work
 
 
-class ShardedGenerator:
-    """Runs `gen(inputs, uv)` on this rank's contiguous shard of a global batch and all-gathers
-    `cat[con_rgb, dif]` (the two outputs the reference's test loops consume: train_test_GSC.py:871-873)."""
+class _Ticket:
+    """One submitted global batch: the gather(s) in flight and how to cut the result."""
+    __slots__ = ("slot", "counts", "cmax", "work", "work2", "has2", "done")
 
-    def __init__(self, gen: Callable, group=None):
+    def __init__(self, slot, counts, cmax, work, work2, has2):
+        self.slot, self.counts, self.cmax, self.work, self.work2, self.has2, self.done = slot, counts, cmax, work, work2, has2, False
+
+
+class ShardedGenerator:
+    """Runs `gen(inputs, uv)` on this rank's contiguous shard of a global batch and all-gathers `con_rgb | dif` (the two outputs
+    the reference's test loops consume: train_test_GSC.py:871-873) — optionally `gs | mask22` too — so every rank holds the global
+    result.
+
+        sg = ShardedGenerator(gen)                       # under an initialised process group (torchrun: one process per GPU)
+        con_rgb, dif = sg.forward_global(inputs, uv)     # blocking form
+        t = sg.submit(inputs_k, uv_k)                    # pipelined form: the gather of batch k ...
+        t2 = sg.submit(inputs_k1, uv_k1)                 # ... overlaps the forward of batch k + 1 (two payload buffers)
+        con_rgb, dif = sg.result(t)
+
+    `packed`: the generator accepts `packed_out=` and writes con_rgb | dif into it from its tail kernel (blindshadowremoval_amd.Generator
+    does: bsr_forward_packed); None = detect (`Generator` instances, or objects with `accepts_packed_out = True`).  Without it the
+    payload is assembled by a `torch.cat` pass."""
+
+    def __init__(self, gen: Callable, group=None, packed: Optional[bool] = None):
         self.gen = gen
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank, self.world = rank_world(group)
+        if packed is None:
+            packed = bool(getattr(gen, "accepts_packed_out", False))
+            if not packed:
+                try:
+                    from .model import Generator
+                    packed = isinstance(gen, Generator) and not type(gen).__name__.endswith("TSM")
+                except Exception:       # the HIP library is not needed to shard a stand-in generator (CPU tests)
+                    packed = False
+        self.packed = packed
+        self._payload = [None, None]            # [cmax,H,W,4] con_rgb | dif of the local shard, two slots
+        self._payload2 = [None, None]           # [cmax,H,W,4] gs | mask22 (only when asked for)
+        self._gathered = [None, None]
+        self._gathered2 = [None, None]
+        self._pending: List[Optional[_Ticket]] = [None, None]
+        self._turn = 0
 
-    def forward_global(self, inputs: torch.Tensor, uv: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """inputs/uv: the GLOBAL batch (same on every rank).  Returns (con_rgb, dif) for the global batch."""
+    @staticmethod
+    def _buf(old, shape, like):
+        if old is None or tuple(old.shape) != tuple(shape) or old.device != like.device or old.dtype != like.dtype:
+            return torch.empty(shape, dtype=like.dtype, device=like.device)
+        return old
+
+    def submit(self, inputs: torch.Tensor, uv: torch.Tensor, want_gs_mask22: bool = False) -> _Ticket:
+        """inputs / uv: the GLOBAL batch (the same tensors on every rank).  Runs the local shard and starts the gather(s)."""
         n = inputs.shape[0]
         bounds = shard_bounds(n, self.world)
         lo, hi = bounds[self.rank]
         counts = [b - a for a, b in bounds]
+        cmax = max(counts)
+        slot = self._turn
+        self._turn ^= 1
+        old = self._pending[slot]
+        if old is not None and not old.done:            # the buffers of two submissions ago: free once their gather completed
+            self._wait(old)
+        H, W = inputs.shape[1], inputs.shape[2]
+        pay = self._payload[slot] = self._buf(self._payload[slot], (cmax, H, W, 4), inputs)
+        pay2 = None
+        if want_gs_mask22:
+            pay2 = self._payload2[slot] = self._buf(self._payload2[slot], (cmax, H, W, 4), inputs)
         if hi > lo:
-            _, con_rgb, _, dif = self.gen(inputs[lo:hi].contiguous(), uv[lo:hi].contiguous())
-            local = torch.cat([con_rgb, dif], dim=3)
-        else:
-            local = torch.zeros((0,) + tuple(inputs.shape[1:3]) + (4,), dtype=inputs.dtype, device=inputs.device)
+            x, u = inputs[lo:hi].contiguous(), uv[lo:hi].contiguous()
+            if self.packed:
+                gs, _, mask22, _ = self.gen(x, u, packed_out=pay[:hi - lo])
+            else:
+                gs, con_rgb, mask22, dif = self.gen(x, u)
+                torch.cat([con_rgb, dif], dim=3, out=pay[:hi - lo])
+            if pay2 is not None:
+                torch.cat([gs, mask22], dim=3, out=pay2[:hi - lo])
+        if hi - lo < cmax:                              # ragged split: the pad rows travel as zeros
+            pay[hi - lo:].zero_()
+            if pay2 is not None:
+                pay2[hi - lo:].zero_()
+        work = work2 = None
+        if self.world > 1:
+            g = self._gathered[slot] = self._buf(self._gathered[slot], (self.world * cmax, H, W, 4), inputs)
+            work = dist.all_gather_into_tensor(g, pay, group=self.group, async_op=True)
+            if pay2 is not None:
+                g2 = self._gathered2[slot] = self._buf(self._gathered2[slot], (self.world * cmax, H, W, 4), inputs)
+                work2 = dist.all_gather_into_tensor(g2, pay2, group=self.group, async_op=True)
+        t = _Ticket(slot, counts, cmax, work, work2, pay2 is not None)
+        self._pending[slot] = t
+        return t
+
+    def _wait(self, t: _Ticket) -> None:
+        for w in (t.work, t.work2):
+            if w is not None:
+                w.wait()
+        t.done = True
+
+    def _cut(self, full: torch.Tensor, t: _Ticket) -> torch.Tensor:
+        if all(c == t.cmax for c in t.counts):
+            return full
+        return torch.cat([full[r * t.cmax:r * t.cmax + c] for r, c in enumerate(t.counts)], dim=0)
+
+    def result(self, t: _Ticket):
+        """Wait for ticket `t`; -> (con_rgb, dif) of the GLOBAL batch, or (con_rgb, dif, gs, mask22) when it was submitted with
+        want_gs_mask22.  The tensors are views of this object's buffers: valid until the submission after next."""
+        self._wait(t)
         if self.world == 1:
-            full = local
+            n = t.counts[0]
+            full, full2 = self._payload[t.slot][:n], (self._payload2[t.slot][:n] if t.has2 else None)
         else:
-            finish, _ = all_gather_rows(local, counts, self.group)
-            full = finish()
-        return full[..., :3], full[..., 3:4]
+            full = self._cut(self._gathered[t.slot], t)
+            full2 = self._cut(self._gathered2[t.slot], t) if t.has2 else None
+        if full2 is None:
+            return full[..., :3], full[..., 3:4]
+        return full[..., :3], full[..., 3:4], full2[..., :1], full2[..., 1:4]
+
+    def forward_global(self, inputs: torch.Tensor, uv: torch.Tensor, want_gs_mask22: bool = False):
+        """Blocking form: (con_rgb, dif[, gs, mask22]) for the global batch on every rank."""
+        return self.result(self.submit(inputs, uv, want_gs_mask22))

@@ -63,6 +63,7 @@ class Logging(object):
         self._png_tickets: List[int] = []
         self._shm_batches: List[Tuple[str, List[int]]] = []
         self.losses: Dict[str, List[float]] = {}
+        self.quiet = False
         self.saved: List[str] = []
         # PNG encoding (zlib) releases the GIL: with png_threads > 0 (the FSRNet loops use 4) strips are encoded by background
         # threads while the loop goes on and flush() — called by the loops before they return — waits for them; the default
@@ -71,13 +72,23 @@ class Logging(object):
         self._pool = None
         self._pending: List = []
 
-    def display(self, losses: Dict[str, float], epoch: int, step: int, training: bool, allstep: int) -> None:
+    @staticmethod
+    def accumulate(acc: Dict[str, List[float]], losses: Dict[str, float]) -> None:
         for k, v in losses.items():
-            acc = self.losses.setdefault(k, [0.0, 0])
-            acc[0] += float(v)
-            acc[1] += 1
-        txt = ''.join('%s:%.3g, ' % (k, s / max(c, 1)) for k, (s, c) in self.losses.items())
-        print('\r Testing ' + str(step + 1) + '/' + str(allstep) + ': ' + txt + '     ', end='', flush=True)
+            a = acc.setdefault(k, [0.0, 0])
+            a[0] += float(v)
+            a[1] += 1
+
+    @staticmethod
+    def format_line(acc: Dict[str, List[float]], step: int, allstep: int) -> str:
+        """The reference's progress line (utils.py:152-167): running means as name:%.3g."""
+        txt = ''.join('%s:%.3g, ' % (k, s / max(c, 1)) for k, (s, c) in acc.items())
+        return '\r Testing ' + str(step + 1) + '/' + str(allstep) + ': ' + txt + '     '
+
+    def display(self, losses: Dict[str, float], epoch: int, step: int, training: bool, allstep: int) -> None:
+        self.accumulate(self.losses, losses)
+        if not self.quiet:                       # data-parallel loops: only rank 0 talks (FSRNet._loop_body)
+            print(self.format_line(self.losses, step, allstep), end='', flush=True)
 
     @staticmethod
     def get_imgs(fig: Sequence[torch.Tensor]) -> np.ndarray:
@@ -97,11 +108,17 @@ class Logging(object):
         """get_imgs for a whole batch, on whatever device the figures live: [B,S,S,C] each -> uint8 [B,S,S*len(figs),3].  The same
         float32 arithmetic (clip, * 255, round half to even) as get_imgs, one device-to-host copy of bytes instead of one float copy
         per figure and item."""
+        return Logging.strips_on_device(figs).cpu().numpy()
+
+    @staticmethod
+    def strips_on_device(figs: Sequence[torch.Tensor]) -> torch.Tensor:
+        """strips_from_batch without the copy to the host: uint8 [B,S,S*len(figs),3] on the figures' device (the pipelined loops
+        copy it into pinned memory asynchronously)."""
         cols = []
         for f in figs:
             a = torch.clamp(f.detach().float(), 0.0, 1.0) * 255.0
             cols.append(a.expand(-1, -1, -1, 3) if a.shape[3] == 1 else a[..., :3])
-        return torch.round(torch.cat(cols, dim=2)).to(torch.uint8).cpu().numpy()
+        return torch.round(torch.cat(cols, dim=2)).to(torch.uint8)
 
     def _png_path(self, fname: str) -> str:
         parts = fname.replace('\\', '/').split('/')
@@ -264,12 +281,23 @@ def _name(x) -> str:
 
 
 class FSRNet(object):
-    def __init__(self, config: Config, weights: Optional[Dict[str, np.ndarray]] = None, dtype: str = "f32"):
+    def __init__(self, config: Config, weights: Optional[Dict[str, np.ndarray]] = None, dtype: str = "f32", group=None, gen=None):
+        """``group``: a torch.distributed process group; with one (or with the default group initialised — `torchrun`, one process per
+        GPU) ``test`` / ``testFFHQ`` run DATA-PARALLEL: rank r takes the contiguous shard r of ``dataset.name_list``, writes the PNG
+        strips of its own items, and the per-item losses are gathered at the end (``all_losses``; rank 0 prints the running means over
+        ALL items exactly like the single-process loop).  ``gen``: a ready generator object to drive instead of constructing one
+        (the multi-process CPU tests pass a stand-in: the product path has no CPU generator)."""
         self.config = config
-        self.gen = Generator(device=config.GPU_INDEX if torch.cuda.is_available() else None, dtype=dtype)
-        if weights is not None:
-            self.gen.load_weights(weights)
+        self.group = group
+        if gen is not None:
+            self.gen = gen
+        else:
+            self.gen = Generator(device=config.GPU_INDEX if torch.cuda.is_available() else None, dtype=dtype)
+            if weights is not None:
+                self.gen.load_weights(weights)
         self.log = Logging(config, png_threads=4)
+        self.gpu_inflight = 2                    # batches whose forward + device-to-host copy may be outstanding while the loop feeds the next one
+        self.all_losses: List[Tuple[str, Dict[str, float]]] = []      # (name, losses) of EVERY item in list order — on every rank after a data-parallel loop
         self.timings: Dict[str, float] = {}      # wall-clock split of the last test / testFFHQ loop (see _loop)
         self.post_threads = 8                    # threads that post-process the items of one UCB batch (post_workers == 0)
         self.post_workers = 0                    # > 0: UCB post-processing in that many worker PROCESSES, pipelined one batch behind the GPU
@@ -304,9 +332,10 @@ class FSRNet(object):
     # -- checkpoint -------------------------------------------------------------------------
     def _restore(self) -> int:
         last_epoch = self.gen.restore(self.config.CHECKPOINT_DIR) if self.gen._handle is None else -1
-        print('**********************************************************')
-        print('Restore from Epoch ' + (str(last_epoch) if last_epoch >= 0 else '(weights supplied)'))
-        print('**********************************************************')
+        if not self.log.quiet:
+            print('**********************************************************')
+            print('Restore from Epoch ' + (str(last_epoch) if last_epoch >= 0 else '(weights supplied)'))
+            print('**********************************************************')
         if self.gen._handle is None:
             raise RuntimeError("no generator weights: checkpoint data shard missing under %s" % self.config.CHECKPOINT_DIR)
         return last_epoch
@@ -364,12 +393,29 @@ class FSRNet(object):
             self.log.flush()
 
     def _loop_body(self, dataset, batch: int, ucb: bool, postprocess: bool, mask_files):
+        """The reference's loops (train_test_GSC.py:360-408, 840-860), batched, data-parallel and pipelined:
+
+        * rank r of a process group works on the contiguous shard r of ``dataset.name_list`` (no data-path collective: items are
+          independent; one ``all_gather_object`` of the per-item losses at the end);
+        * the loop's own thread only FEEDS: it pulls elements from the loader, submits a batch's forward + strip assembly (or the
+          tensors the host post-processing reads) + the device-to-host copy into pinned memory, records an event, and goes back to
+          the loader; up to ``gpu_inflight`` batches are outstanding, and a batch is completed — PNG strips / post-processing jobs
+          handed to their worker pools, results appended — in submission order, so item order and every output bit are those of the
+          serial loop."""
+        from .dist import rank_world, shard_bounds
         names = list(dataset.name_list)
         num_list = len(names)
+        rank, world = rank_world(self.group)
+        lo, hi = shard_bounds(num_list, world)[rank] if world > 1 else (0, num_list)
+        feed_is_sharded = False
+        if world > 1 and hasattr(dataset, "shard"):
+            dataset.shard(lo, hi)               # the loader prepares only this rank's items (a plain .feed is consumed and skipped instead)
+            feed_is_sharded = True
+        self.log.quiet = rank != 0
         results = []
-        # where the loop's wall time goes: waiting for the loader, host->device + forward (+ device->host of what the host
-        # post-processing reads), the reference's UCB post-processing, PNG encoding
-        tm = {"prep_wait_s": 0.0, "forward_s": 0.0, "post_s": 0.0, "png_s": 0.0, "forwards": 0, "items": 0}
+        # where the loop's wall time goes: waiting for the loader, submitting / waiting for the GPU (host->device, forward,
+        # device->host of what the host reads), handing work to the post-processing pool, PNG encoding
+        tm = {"prep_wait_s": 0.0, "forward_s": 0.0, "post_s": 0.0, "png_s": 0.0, "forwards": 0, "items": 0, "rank": rank, "world": world}
         self.timings = tm
         pending: List[Tuple[int, str, torch.Tensor, object]] = []
         # the reference indexes its mask lists by the loop counter (train_test_GSC.py:386-396: masks[count]): item `step` is
@@ -382,6 +428,12 @@ class FSRNet(object):
             mask_files = None
         self._restore()
         start = time.time()
+        dev = "cuda:%d" % self.gen._device if getattr(self.gen, "_device", None) is not None else "cpu"
+        on_gpu = dev != "cpu"
+        depth = max(0, int(self.gpu_inflight)) if on_gpu else 0
+        pins: List[Optional[torch.Tensor]] = [None] * (depth + 1)      # pinned staging buffers, one per batch that may be outstanding (+ the one being filled)
+        gpu_q: List[Tuple] = []             # submitted batches whose device-to-host copy may still be running, oldest first
+        turn = [0]
 
         post_pool = self._get_post_pool() if ucb and postprocess and self.post_workers > 0 else None
         inflight: List[Tuple] = []          # UCB batches whose post-processing runs in the worker pool: (pending items, futures)
@@ -414,49 +466,88 @@ class FSRNet(object):
                 tm["post_s"] += time.perf_counter() - t1
                 finish(batch_items, post)
 
-        def flush():
+        def to_host_async(payload: torch.Tensor):
+            """-> (numpy view of the payload on the host, event | None).  GPU: an asynchronous copy into this batch's pinned buffer;
+            the view is valid once the event has completed and until the buffer's turn comes again (depth + 1 submissions later)."""
+            if not on_gpu:
+                return payload.numpy(), None
+            k = turn[0]
+            turn[0] = (k + 1) % len(pins)
+            nbytes = payload.numel() * payload.element_size()
+            if pins[k] is None or pins[k].numel() < nbytes:
+                pins[k] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+            view = pins[k][:nbytes].view(payload.dtype).reshape(payload.shape)
+            view.copy_(payload, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return view.numpy(), ev
+
+        def submit():
+            """one batch: rows -> device -> generator -> what the host needs, on its way to pinned memory; nothing here waits for the GPU"""
             if not pending:
                 return
             t0 = time.perf_counter()
-            dev = "cuda:%d" % self.gen._device
             rows = torch.cat([self._split_row0(p[2]) for p in pending], dim=0)
-            rows_d = rows.to(dev)                                   # ONE host-to-device copy of the packed rows (none when the loader prepared them on the device)
+            rows_d = rows.to(dev, non_blocking=True)                # ONE host-to-device copy of the packed rows (none when the loader prepared them on the device)
             im_d, gt_d, uv_d, _, face_d = torch.split(rows_d, list(SPLIT_FFHQ), dim=3)
             gs, con_rgb, _, mask_pred = self.gen(im_d, uv_d, None, chuck=4 if ucb else 1, training=False)
-            if self.gen.dtype != "f32":
-                self.gen.check_range()                              # 16-bit modes: an out-of-range activation is an error here, never a silent inf
             items = list(pending)
             pending.clear()
             if ucb and postprocess:
-                # train_test_GSC.py:424-748 on the host, one independent item per call.  What the host reads comes over in ONE copy.
-                host = torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3).cpu().numpy()         # [B,S,S,10]
-                torch.cuda.synchronize(self.gen._device)
-                tm["forward_s"] += time.perf_counter() - t0
-                tm["forwards"] += 1
-                tm.setdefault("first_batch_done_s", time.time() - start)
-                t1 = time.perf_counter()
+                # train_test_GSC.py:424-748 runs on the host, one independent item per call: what it reads comes over in ONE copy
+                host, ev = to_host_async(torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3))      # [B,S,S,10]
+                figs_b = None
+            else:
+                # FFHQ / raw-UCB: the figures stay on the device; the PNG strips of the whole batch are assembled there and come
+                # over as bytes in one copy (Logging.strips_on_device = get_imgs per item, same arithmetic)
+                if ucb:
+                    figs_b = [im_d, gs, con_rgb, mask_pred, gt_d, face_d]
+                    shown_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]
+                else:
+                    figs_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]        # train_test_GSC.py:872-873,889
+                    shown_b = figs_b
+                host, ev = to_host_async(self.log.strips_on_device(shown_b))
+            gpu_q.append((items, host, ev, figs_b))
+            tm["forward_s"] += time.perf_counter() - t0
+            tm["forwards"] += 1
+            while len(gpu_q) > depth:
+                complete(gpu_q.pop(0))
 
-                def job(j):
-                    step, name, _, box = items[j]
-                    return {"im": host[j, ..., 0:3], "gt": host[j, ..., 3:6], "con": host[j, ..., 6:9], "mp": host[j, ..., 9:10],
-                            "box": np.asarray(box, np.float32).reshape(-1)[:4], "masks": mask_files[step],
-                            "png": self.log._png_path(name) if self._post_writes_png else None, "return_figs": self.return_figs}
+        def complete(entry):
+            """the batch's device work has to be done now: wait for its event, then hand its host half on"""
+            items, host, ev, figs_b = entry
+            t0 = time.perf_counter()
+            if ev is not None:
+                ev.synchronize()
+            if getattr(self.gen, "dtype", "f32") != "f32":
+                self.gen.check_range()                              # 16-bit modes: an out-of-range activation is an error here, never a silent inf
+            tm["forward_s"] += time.perf_counter() - t0
+            tm.setdefault("first_batch_done_s", time.time() - start)
+            t1 = time.perf_counter()
+            if ucb and postprocess:
                 if post_pool is not None:
                     post_pool._pump(block=False)
                     shm = _shm_file("bsr_post_")
-                    host.tofile(shm)
+                    host.tofile(shm)                                # the arrays travel through the shared-memory file, not the pipe
                     shape = tuple(host.shape)
 
-                    def job(j, shm=shm, shape=shape):             # noqa: F811  — the arrays travel through the shared-memory file, not the pipe
+                    def job(j):
                         step, name, _, box = items[j]
                         return {"shm": shm, "shape": shape, "index": j, "box": np.asarray(box, np.float32).reshape(-1)[:4], "masks": mask_files[step],
                                 "png": self.log._png_path(name) if self._post_writes_png else None, "return_figs": self.return_figs}
-                    # worker PROCESSES (the post-processing is ~60 ms of small numpy / torch-CPU calls per item, GIL-bound in threads);
-                    # this batch is post-processed while the next one is prepared and run: results are collected one batch later
+                    # worker PROCESSES (the post-processing is ~30 ms of small numpy / torch-CPU calls per item, GIL-bound in threads);
+                    # results are collected up to post_inflight batches later
                     inflight.append((items, [post_pool.submit(("ucb_post", job(j))) for j in range(len(items))], shm))
                     tm["post_s"] += time.perf_counter() - t1
                     drain(keep=self.post_inflight)
                     return
+                host = np.array(host)                               # the pinned buffer is reused; the in-process results may keep views
+
+                def job(j):                                         # noqa: F811
+                    step, name, _, box = items[j]
+                    return {"im": host[j, ..., 0:3], "gt": host[j, ..., 3:6], "con": host[j, ..., 6:9], "mp": host[j, ..., 9:10],
+                            "box": np.asarray(box, np.float32).reshape(-1)[:4], "masks": mask_files[step],
+                            "png": self.log._png_path(name) if self._post_writes_png else None, "return_figs": self.return_figs}
                 from .ucb_post import run_post_job
                 if len(items) > 1 and self.post_threads > 1:
                     from concurrent.futures import ThreadPoolExecutor
@@ -467,19 +558,7 @@ class FSRNet(object):
                 tm["post_s"] += time.perf_counter() - t1
                 finish(items, post)
                 return
-            # FFHQ / raw-UCB: the figures stay on the device; the PNG strips of the whole batch are assembled there and come
-            # over as bytes in one copy (Logging.strips_from_batch = get_imgs per item, same arithmetic)
-            if ucb:
-                figs_b = [im_d, gs, con_rgb, mask_pred, gt_d, face_d]
-                shown_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]
-            else:
-                figs_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]            # train_test_GSC.py:872-873,889
-                shown_b = figs_b
-            strips = self.log.strips_from_batch(shown_b)
-            tm["forward_s"] += time.perf_counter() - t0
-            tm["forwards"] += 1
-            tm.setdefault("first_batch_done_s", time.time() - start)
-            t1 = time.perf_counter()
+            strips = host if self.log.png_workers > 0 else np.array(host)      # the worker path copies into shared memory at once; writer threads keep the array
             self.log.save_strips(strips, [it[1] for it in items])
             for j, (step, name, _, box) in enumerate(items):
                 self.log.display({}, 0, step, False, num_list)
@@ -489,14 +568,21 @@ class FSRNet(object):
 
         try:
             for step, img_name in enumerate(names):
+                mine = lo <= step < hi
+                if not mine and feed_is_sharded:
+                    continue
                 t0 = time.perf_counter()
                 element = next(dataset.feed)
                 tm["prep_wait_s"] += time.perf_counter() - t0
+                if not mine:                    # a plain iterator cannot be sharded: its other ranks' elements are dropped
+                    continue
                 img = element[0]
                 pending.append((step, _name(img_name), img, element[1] if len(element) > 1 else None))
                 if len(pending) >= batch:
-                    flush()
-            flush()
+                    submit()
+            submit()
+            while gpu_q:
+                complete(gpu_q.pop(0))
             drain(keep=0)
         except BaseException:
             self.close_pools()              # outstanding jobs of a failed loop are dropped with their workers
@@ -509,9 +595,34 @@ class FSRNet(object):
         t0 = time.perf_counter()
         self.log.flush()
         tm["png_s"] += time.perf_counter() - t0
+        self._gather_losses(results, names, lo, rank, world, num_list)
         tm["total_s"] = time.time() - start
-        print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
+        if rank == 0:
+            print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
         return results
+
+    def _gather_losses(self, results, names, lo: int, rank: int, world: int, num_list: int) -> None:
+        """``all_losses`` = (name, losses) of every item in list order.  Data-parallel: one all_gather_object of the shards' lists;
+        the running means are then re-accumulated in LIST order — the same floating-point sums as the single-process loop — into
+        ``log.losses`` on every rank, and rank 0 prints the final progress line (utils.py:152-167)."""
+        mine = [(lo + k, r[0], (r[2] if len(r) > 2 else {})) for k, r in enumerate(results)]
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            self.all_losses = [(n, l) for _, n, l in mine]
+            return
+        # under a process group the gather runs whatever its size (a one-rank RCCL group exercises the same path: tests/test_fsrnet.py)
+        shards = [None] * world
+        dist.all_gather_object(shards, mine, group=self.group)
+        flat = sorted((it for sh in shards for it in sh), key=lambda it: it[0])
+        if [it[0] for it in flat] != list(range(num_list)):
+            raise RuntimeError("data-parallel loop: the ranks' shards do not tile the name list (%d items gathered for %d names)" % (len(flat), num_list))
+        self.all_losses = [(n, l) for _, n, l in flat]
+        acc: Dict[str, List[float]] = {}
+        for _, _, losses in flat:
+            Logging.accumulate(acc, losses)
+        self.log.losses = acc
+        if rank == 0:
+            print(Logging.format_line(acc, num_list - 1, num_list), end='', flush=True)
 
     def _split_row0(self, img) -> torch.Tensor:
         s = self.config.IMG_SIZE

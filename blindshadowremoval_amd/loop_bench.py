@@ -31,11 +31,13 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
     cfg.UCB_MASK_ROOT = os.path.join(GOLDEN, "UCB_masks")
     fsr = FSRNet(cfg, weights=init_weights(1), dtype=dtype)
     from .dataset import usable_cpus as _ucpu
-    res = {"usable_cpus": _ucpu(), "loop": "FSRNet.test (UCB, batch %d, host post-processing + SSIM/PSNR)" % batch if ucb else "FSRNet.testFFHQ (batch %d)" % batch,
+    from .dist import rank_world
+    rank, world = rank_world()
+    res = {"usable_cpus": _ucpu(), "rank": rank, "world": world, "loop": "FSRNet.test (UCB, batch %d, host post-processing + SSIM/PSNR)" % batch if ucb else "FSRNet.testFFHQ (batch %d)" % batch,
            "dtype": dtype}
     try:
-        from .dataset import usable_cpus
-        ncpu = usable_cpus()                                             # affinity + cgroup quota, not the CPUs the box merely shows
+        from .dataset import cpu_share
+        ncpu = cpu_share()                                               # affinity + cgroup quota (not the CPUs the box merely shows), divided by the ranks of this node
         modes = [("serial_loader", dict(workers=0), {}), ("pooled_loader", dict(workers=workers), {}),
                  # round 3: rows prepared ON THE DEVICE (prep.py: the workers only decode PNGs and triangulate), PNG strips assembled
                  # on the device, UCB post-processing in worker processes one batch behind the GPU

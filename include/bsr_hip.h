@@ -129,6 +129,9 @@ int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* str
 /* The same with the kernel of a given BSR_DTYPE_*: F32 = fp32 matrix cores; F32X3 / F16 = the split-precision kernel (attention is
  * split-precision in both 16-bit modes). */
 int bsr_debug_attention_dtype(const float* qkv, float* y, int B, int tokens, int dtype, void* stream);
+/* The fp32 kernel with a given workgroup shape: qw = query waves per workgroup (4 = 128 queries, 2 = 64, 1 = 32; 0 = what the
+ * forward picks for this batch: the largest block that still gives every CU a workgroup).  All shapes give bit-identical outputs. */
+int bsr_debug_attention_qw(const float* qkv, float* y, int B, int tokens, int qw, void* stream);
 
 void bsr_destroy(bsr_handle* h);
 

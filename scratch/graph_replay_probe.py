@@ -4,8 +4,7 @@ import torch
 from blindshadowremoval_amd import Generator, init_weights
 
 
-def main():
-    B = 32
+def main(B=32):
     gen = Generator().load_weights(init_weights(1))
     torch.manual_seed(0)
     inp = torch.rand(B, 256, 256, 3).cuda(); uv = torch.rand(B, 256, 256, 3).cuda()
@@ -16,7 +15,7 @@ def main():
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(n): fn()
         torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
-    print("eager ms", timeit(lambda: gen(inp, uv, out=outs)))
+    print("B", B, "eager ms", timeit(lambda: gen(inp, uv, out=outs)))
     ref = [o.clone() for o in outs]
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
@@ -35,4 +34,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    for b in ([int(a) for a in sys.argv[1:]] or [32]):
+        main(b)

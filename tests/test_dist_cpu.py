@@ -30,6 +30,18 @@ def fake_gen(inputs, uv, *a, **k):
     return gs, con_rgb, mask22, dif
 
 
+class PackedFake:
+    """fake_gen with the `packed_out=` keyword of blindshadowremoval_amd.Generator (bsr_forward_packed)."""
+    accepts_packed_out = True
+
+    def __call__(self, inputs, uv, packed_out=None):
+        gs, con_rgb, mask22, dif = fake_gen(inputs, uv)
+        assert packed_out is not None and tuple(packed_out.shape) == tuple(inputs.shape[:3]) + (4,) and packed_out.is_contiguous()
+        packed_out[..., :3].copy_(con_rgb)
+        packed_out[..., 3:].copy_(dif)
+        return gs, packed_out[..., :3], mask22, packed_out[..., 3:]
+
+
 def _worker(rank, world, port, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -39,8 +51,22 @@ def _worker(rank, world, port, n, q):
         inp = torch.rand(n, 8, 8, 3, generator=g)
         uv = torch.rand(n, 8, 8, 3, generator=g)
         con_rgb, dif = ShardedGenerator(fake_gen).forward_global(inp, uv)
-        _, want_rgb, _, want_dif = fake_gen(inp, uv)
+        want_gs, want_rgb, want_m22, want_dif = fake_gen(inp, uv)
         ok = torch.equal(con_rgb, want_rgb) and torch.equal(dif, want_dif)
+        # the pipelined form: two submissions in flight (double-buffered payloads), a third one recycles the first slot; the packed
+        # stand-in writes con_rgb | dif straight into the payload like the HIP generator's tail kernel; gs | mask22 on request
+        sg = ShardedGenerator(PackedFake())
+        assert sg.packed
+        t1 = sg.submit(inp, uv)
+        t2 = sg.submit(inp * 0.5, uv, want_gs_mask22=True)
+        r1 = sg.result(t1)
+        ok = ok and torch.equal(r1[0], want_rgb) and torch.equal(r1[1], want_dif)
+        r2 = sg.result(t2)
+        g2 = fake_gen(inp * 0.5, uv)
+        ok = ok and len(r2) == 4 and all(torch.equal(a, b) for a, b in zip(r2, (g2[1], g2[3], g2[0], g2[2])))
+        t3 = sg.submit(inp, uv, want_gs_mask22=True)
+        r3 = sg.result(t3)
+        ok = ok and all(torch.equal(a, b) for a, b in zip(r3, (want_rgb, want_dif, want_gs, want_m22)))
         # async ragged gather
         counts = [hi - lo for lo, hi in shard_bounds(n, world)]
         lo, hi = shard_bounds(n, world)[rank]

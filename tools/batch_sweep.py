@@ -15,6 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _groups(lt):
+    """per-launch events folded by layer kind (res3.conv2 -> res*.conv2)"""
+    out = {}
+    for name, ms, _cls in lt:
+        key = ("res*." + name.split(".", 1)[1]) if name.startswith("res") and "." in name else name
+        out[key] = out.get(key, 0.0) + ms
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
@@ -57,8 +66,9 @@ def main():
         gen.set_timing(False)
         dev_ms = sum(ms for _n, ms, _c in lt)
         rows.append({"batch": B, "images_per_sec": round(B / best, 1), "ms_per_forward": round(best * 1e3, 4), "launches_per_forward": len(lt),
-                     "device_ms_sum_of_launches": round(dev_ms, 4), "forwards_timed": n})
-        print(rows[-1], file=sys.stderr)
+                     "device_ms_sum_of_launches": round(dev_ms, 4), "forwards_timed": n,
+                     "layer_us": {k: round(v * 1e3, 1) for k, v in _groups(lt).items()}})
+        print({k: v for k, v in rows[-1].items() if k != 'layer_us'}, file=sys.stderr)
     full = rows[-1]["images_per_sec"]
     for r in rows:
         r["rate_vs_largest_batch"] = round(r["images_per_sec"] / full, 4)
