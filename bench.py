@@ -62,6 +62,18 @@ for _i in range(6):
     LAYER_IO_ELEMS["res%d.c3q" % _i] = _io(32, 128 + _cin, 32, 288 + 384)          # + the block input (skip folded into y3x)
     LAYER_IO_ELEMS["res%d.attention" % _i] = _io(32, 384, 32, 128)
     LAYER_IO_ELEMS["res%d.w" % _i] = _io(32, 128 + 288, 32, 264)
+# Launches that compute SEVERAL reference layers (round 4: at full batches the `w` GEMM is the tail of the attention kernel): priced with
+# the sum of their parts; LAYER_MMAC stays the per-layer table of SURVEY Appendix C.
+FUSED_LAUNCHES = {"res%d.attw" % _i: ("res%d.attention" % _i, "res%d.w" % _i) for _i in range(6)}
+for _i in range(6):
+    LAYER_IO_ELEMS["res%d.attw" % _i] = _io(32, 384 + 288, 32, 264)          # qkv + y3x in, block output out (att never reaches HBM)
+
+
+def launch_mmac(name):
+    parts = FUSED_LAUNCHES.get(name)
+    return sum(LAYER_MMAC[p] for p in parts) if parts else LAYER_MMAC[name]
+
+
 # f16 mode: bytes per element of each launch's (input, output) tensor — the fp16 activation pack; everything else 4 / 4
 F16_IO_BYTES = {"conv1": (4, 2), "down1": (2, 2), "down2": (2, 2), "down3": (2, 4), "up1": (4, 2), "up2": (2, 2), "up3": (2, 2), "heads": (2, 4),
                 "clr_up1": (4, 2), "clr_up2": (2, 2), "clr_up3": (2, 2), "clr_conv1": (2, 4)}
@@ -84,6 +96,7 @@ KERNEL_GROUPS = {
     "igemm_conv_kernel<3,3,1> (res*.conv2)": ["res%d.conv2" % i for i in range(6)],
     "igemm_conv_kernel<3,3,2> (down1-3)": ["down1", "down2", "down3"],
     "nonlocal_attention_kernel": ["res%d.attention" % i for i in range(6)],
+    "nonlocal_attention_kernel<4, FUSEW> (res*.attention + res*.w tail)": ["res%d.attw" % i for i in range(6)],
     "gemm_nloop_kernel (res*.c3q, res*.w)": ["res%d.%s" % (i, n) for i in range(6) for n in ("c3q", "w")],
     "igemm_conv_kernel<1,1,1> (res*.conv1)": ["res%d.conv1" % i for i in range(6)],
     "conv_n16_kernel<3,3,GS,TAIL> (clr_conv1 + clr_conv2 + clr_conv3 + dif)": ["clr_conv1"],
@@ -265,7 +278,7 @@ H16_LAYERS = (["down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_u
 
 
 # layers that run split-precision (hi/lo fp16 planes, three fp16 matrix instructions per K group) in BOTH 16-bit modes = pack.X3_LAYERS + attention
-X3_LAYERS = (["res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w", "attention")] + ["heads", "clr_conv1", "conv1"])
+X3_LAYERS = (["res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w", "attention", "attw")] + ["heads", "clr_conv1", "conv1"])
 
 
 def group_peak(layers, dtype):
@@ -305,7 +318,7 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
         ms = sum(layer_ms.get(n, 0.0) for n in layers)
         if ms <= 0:
             continue
-        gflop = 2e-3 * sum(LAYER_MMAC[n] for n in layers) * B
+        gflop = 2e-3 * sum(launch_mmac(n) for n in layers) * B
         gpeak = group_peak(layers, dtype)
         label = gname
         if gpeak != PEAK_F32_MFMA_TFLOPS:          # the 16-bit instantiations (csrc/igemm_h16.h, attention_x3.h, gemm_nloop / conv_n16 with H = 2)
@@ -323,14 +336,15 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
     path = GFLOP_3X3_PER_IMAGE * B / t33
     peak33 = group_peak(["up3"], dtype)
     t_all = sum(layer_ms.values())
-    glue_ms = sum(ms for n, ms in layer_ms.items() if n not in LAYER_MMAC)
+    glue_ms = sum(ms for n, ms in layer_ms.items() if n not in LAYER_MMAC and n not in FUSED_LAUNCHES)
     # the dominant kernel is priced against both roofs; `bound` names the nearer one (fp32 kernels: the fp32 matrix pipe; the 16-bit
     # kernels of f32x3 / f16: HBM once the matrix work has shrunk by 16/3 or 16)
     mfma_view = {"achieved_TFLOPs": dom["tflops"], "peak_TFLOPs": peak, "frac": dom["frac"]}
     hbm_view = {"alg_GBps": dom["alg_GBps"], "peak_GBps": PEAK_HBM_GBPS, "frac": dom["hbm_frac"],
                 "note": "algorithmic activation bytes (input read once + output written once) / device time of the same launches"}
     hbm_bound = dom["hbm_frac"] > dom["frac"]
-    rf = {"bound": "hbm" if hbm_bound else "mfma", "achieved": dom["alg_GBps"] if hbm_bound else dom["tflops"],
+    rf = {"mode": "one forward at a time (one handle, one stream): every per-kernel figure of this object",
+          "bound": "hbm" if hbm_bound else "mfma", "achieved": dom["alg_GBps"] if hbm_bound else dom["tflops"],
           "peak": PEAK_HBM_GBPS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
           "frac": dom["hbm_frac"] if hbm_bound else dom["frac"], "traffic": None, "mfma_view": mfma_view, "hbm_view": hbm_view,
           "kernel": dom_name + " — the largest kernel instantiation, %.0f %% of the forward's device time" % (100 * dom["ms"] / t_all),
@@ -345,6 +359,47 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
           "kernel_groups": {k: {kk: vv for kk, vv in v.items() if kk != "gflop"} for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
           "glue_ms": round(glue_ms, 4)}
     return rf, dom_name
+
+
+def roofline_in_flight(gens, lanes, run_on, B, dtype, dom_name, ms_per_step, n_rep=3):
+    """The dominant kernel and the whole forward in the mode `value` is taken in — two forwards in flight on two handles / streams:
+    HIP events around every launch of BOTH handles while steps alternate between them (an event pair then brackets the kernel's
+    residency including what the other lane's kernels take from it), and the whole-forward rate from the timed region itself."""
+    import torch
+    layers = None
+    for key, names in KERNEL_GROUPS.items():
+        if key == dom_name or dom_name.startswith(key):
+            layers = names
+    if layers is None:
+        return None
+    for g in gens:
+        g.set_timing(True)
+    tot, cnt = 0.0, 0
+    for _ in range(n_rep):
+        for k in range(len(gens)):
+            run_on(k)
+        torch.cuda.synchronize()
+        for g in gens:
+            for name, ms, _cls in g.get_launch_timing():
+                if name in layers:
+                    tot += ms
+                    cnt += 1
+    for g in gens:
+        g.set_timing(False)
+    if cnt == 0:
+        return None
+    avg = tot / cnt
+    gflop = 2e-3 * sum(launch_mmac(n) for n in layers) * B / len(layers)
+    peak = group_peak(layers, dtype)
+    whole = GFLOP_PER_IMAGE * B / ms_per_step
+    return {"mode": "two forwards in flight (two handles, two HIP streams) = the mode of `value`", "kernel": dom_name,
+            "avg_launch_ms": round(avg, 4), "launches_timed": cnt, "algorithmic_gflop_per_launch": round(gflop, 2),
+            "achieved": round(gflop / avg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gflop / avg / peak, 4),
+            "whole_forward": {"achieved": round(whole, 2), "peak": PEAK_F32_MFMA_TFLOPS if dtype == "f32" else None, "unit": "TFLOP/s",
+                              "frac": round(whole / PEAK_F32_MFMA_TFLOPS, 4) if dtype == "f32" else None,
+                              "note": "18.104 GFLOP x images / ms_per_step of the timed region"},
+            "note": "a launch's event-bracketed time here includes the share of the chip the other lane's concurrent kernels take, so `frac` "
+                    "is a per-kernel LOWER bound in this mode; the chip-level figure is whole_forward"}
 
 
 # kernel-group label (KERNEL_GROUPS / the 16-bit relabelling) -> substring of the rocprofv3 kernel names of that group
@@ -463,6 +518,33 @@ def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_p
         res["parity"] = {"max_abs_err": max(float((a - r).abs().max()) for a, r in zip(hip, ref)), "bmask_flips": int((bmask != pr["bmask"]).sum()),
                          "sample": "8 synthetic images, all four outputs vs the CPU oracle (tolerance 1e-3)"}
     gen.close()
+    return res
+
+
+def secondary_batch16(gen, dev, rate_b32):
+    """BASELINE configs[2]'s batch (B = 16) forward only, one at a time, on the same handle — beside the B = 32 line, never `value`.
+    Below B = 32 the 1/8-resolution trunk picks smaller workgroup shapes (csrc/attention.h QW, 2x32 conv tiles) to keep the chip
+    covered; the full sweep B = 1 ... 32 is tools/batch_sweep.py -> profiles/r4_batch_sweep.json."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    inp = torch.rand(16, 256, 256, 3, generator=g).to(dev)
+    uv = torch.rand(16, 256, 256, 3, generator=g).to(dev)
+    out = tuple(torch.empty((16, 256, 256, c), device=dev) for c in (1, 3, 3, 1))
+    for _ in range(3):
+        gen(inp, uv, out=out)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gen(inp, uv, out=out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        best = dt if best is None else min(best, dt)
+    res = {"workload": "BASELINE configs[2] batch: 16 synthetic 256x256x3 images, forward only, one at a time", "value": round(16 / best, 2),
+           "unit": "images/sec", "ms_per_forward": round(best * 1e3, 4), "forwards_timed": 60}
+    if rate_b32:
+        res["rate_vs_batch32_single_stream"] = round(16 / best / rate_b32, 4)
     return res
 
 
@@ -674,7 +756,10 @@ def run_rank(args):
             "repeats": {"n": len(rs), "ms_per_step_min": round(rs[0], 4), "ms_per_step_median": round(rs[len(rs) // 2], 4),
                         "ms_per_step_all": [round(r, 4) for r in rs], "note": "`value` is the FIRST timed region of exactly K steps; the others repeat it"},
         }
+        result["value_mode"] = ("two forwards in flight (steps alternate between two handles on two HIP streams; every step is one whole B-image forward)"
+                                if nlanes > 1 else "one forward at a time")
         if single is not None:
+            result["single_stream_value"] = single["value"]        # the strictly serial figure of the same process, comparable with rounds 1-2
             result["single_stream"] = single
         if args.stub:
             result["stub"] = True
@@ -688,6 +773,10 @@ def run_rank(args):
                 attach_traffic(rf, dom_name, B, args.dtype)
                 attach_mfma(rf, dom_name, B, args.dtype)
                 result["roofline"] = rf
+                if nlanes > 1 and not distributed:
+                    result["roofline_in_flight"] = roofline_in_flight(gens, lanes, lambda k: forward(k, lane=k), B, args.dtype, dom_name, ms_per_step)
+                if args.dtype == "f32" and world == 1 and not args.no_secondary:
+                    result["batch16"] = secondary_batch16(gen, dev, value if nlanes == 1 else (single or {}).get("value"))
             if not args.no_cpu_baseline and world == 1 and not tsm:
                 result["cpu_baseline"] = cpu_baseline(weights, gen=gen, device=dev)
             else:

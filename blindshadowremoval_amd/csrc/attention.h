@@ -37,8 +37,32 @@ static_assert(66 * 64 * 4 <= 4 * kAttStageFloats, "merge scratch fits the stagin
 // B x 8 workgroups on 256 CUs).  Round 4: QW = 2 / 1 are the same kernel with 64 / 32 queries per workgroup for SMALL batches —
 // LDS (two staged tile pairs, 133 KB) allows one workgroup per CU whatever its size, so with B x 8 < 256 workgroups most CUs idle;
 // halving the query block doubles the grid, and a wave's own work (32 queries x half the keys) is unchanged.
-template <int QW>
-__global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens) {
+// FUSEW (round 4, QW = 4 only): the NonLocalBlock's `w` 1x1 conv + BN, the block's residual and its LeakyReLU
+// (/root/reference/model.py:56-59, 105-113: out = LeakyReLU(y3x + BN(w(att))), the launch that used to follow as gemm_nloop_kernel) run
+// as the TAIL of this kernel: a workgroup's 128 queries are 128 pixels of the K = 128 GEMM, their normalised attention output goes
+// through LDS into the A-fragment layout (never to HBM), and the two key-stream wave groups take the channel tiles [0,5) / [5,9) of
+// N = 288 with the weight images of both streaming through one 3-slot LDS ring — the same MFMA order per output element as
+// gemm_nloop_kernel (bit-identical results), one launch, one prologue and 17 MB of HBM round trip less per block.
+struct AttWArgs {
+  const float* w;       // packed [4][1][n_pad][36] (pack.py: res{i}.w), n_pad >= 12 * 32
+  const float* bias;    // [n_pad]
+  int n_pad;
+  const float* res;     // y3x: conv3 output + block input, NHWC at the trunk resolution, channels [0, res_c)
+  int res_cs, res_c;
+  float* out;           // block output, channel stride out_cs, channels [0, n_store) written
+  int out_cs, n_store;
+  int act;              // 1: LeakyReLU(0.3)
+};
+constexpr int kAttWSlot = 2 * 96 * 36;                         // floats per ring slot: the (3 tiles x 36-word rows) images of BOTH wave groups
+constexpr int kAttWAttFloats = 128 * kAttLdK;                  // normalised attention output of the workgroup, [query][D + 4]
+constexpr int kAttWSmemFloats = kAttWAttFloats + 3 * kAttWSlot + 12 * 32;
+constexpr int kAttWSmemBytes = kAttWSmemFloats * 4;
+static_assert(kAttWSmemBytes <= 160 * 1024 && kAttWSmemBytes >= kAttSmemBytes, "LDS budget of the fused tail");
+static_assert(4 * 66 * 64 <= kAttWAttFloats, "the merge scratch sits under the attention tile, clear of the weight ring");
+
+template <int QW, bool FUSEW = false>
+__global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens, AttWArgs wa) {
+  static_assert(!FUSEW || QW == 4, "the fused w tail is the 8-wave shape's");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = QW * 128;                                 // threads
   constexpr int SV = 2048 / NT;                                // float4 per operand and thread that stage one tile pair
@@ -189,6 +213,39 @@ __global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_
 
   // merge the two key streams: waves 4-7 hand (m, l, O^T) to waves 0-3 through LDS ([wq][66 values][64 lanes])
   __syncthreads();
+  // FUSEW: the staging buffers are dead from here on; the weight images of GEMM steps 0 and 1 and the bias are requested now, by all
+  // eight waves, so that their latency hides behind the merge (ring and bias live ABOVE the merge scratch / attention tile)
+  [[maybe_unused]] float* s_ring = smem + kAttWAttFloats;
+  [[maybe_unused]] float* s_bias = s_ring + 3 * kAttWSlot;
+  constexpr int WPT = 4;                                       // float4 per thread and ring slot: 2 x 864 images over 512 threads (the surplus re-copies)
+  [[maybe_unused]] unsigned w_voff[WPT], w_loff[WPT];
+  [[maybe_unused]] f32x4 w_regs[WPT], w_regs1[WPT];
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t w_rsrc;
+  auto fetch_w = [&](int s, f32x4 (&regs)[WPT]) {              // GEMM step s = (channel group, K chunk); both wave groups' images
+    const int ng = s >> 2, ch = s & 3;
+    const unsigned soff = (unsigned)((ch * wa.n_pad + ng * 96) * 36 * 4);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      regs[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], soff, 0));
+  };
+  auto store_w = [&](int slot_floats, const f32x4 (&regs)[WPT]) {
+    char* dst = reinterpret_cast<char*>(s_ring + slot_floats);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(dst + w_loff[i]) = regs[i];
+  };
+  if constexpr (FUSEW) {
+    w_rsrc = make_rsrc(wa.w);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int e = (tid + i * NT) % (2 * 864);                // float4 index inside a slot: image of group 0 | image of group 1
+      const int sub = e / 864, within = e % 864;
+      w_voff[i] = (unsigned)(within * 16 + sub * (5 * 32 * 36 * 4));      // group 1's tiles start 5 tiles (160 channel rows) after group 0's
+      w_loff[i] = (unsigned)(e * 16);
+    }
+    fetch_w(0, w_regs);
+    fetch_w(1, w_regs1);
+    for (int i = tid; i < 12 * 32; i += NT) s_bias[i] = wa.bias[i];
+  }
   float* sx = smem + (size_t)wq * 66 * 64 + lane;
   if (grp == 1) {
     sx[0] = m_run;
@@ -199,8 +256,11 @@ __global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_
       for (int i = 0; i < 16; ++i) sx[(2 + dt * 16 + i) * 64] = o[dt][i];
   }
   __syncthreads();
-  if (grp == 1) return;
-  {
+  if constexpr (!FUSEW) {
+    if (grp == 1) return;
+  }
+  float inv = 0.f;
+  if (grp == 0) {
     const float m1 = sx[0], l1 = sx[64];
     const float m = fmaxf(m_run, m1);
     const float s0 = __builtin_amdgcn_exp2f(m_run - m), s1 = __builtin_amdgcn_exp2f(m1 - m);
@@ -209,23 +269,135 @@ __global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[dt][i] = o[dt][i] * s0 + sx[(2 + dt * 16 + i) * 64] * s1;
+    // combine the two key halves' partial sums, normalise
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    inv = 1.f / l_tot;
   }
 
-  // combine the two key halves' partial sums, normalise, store y[q][d], d = 4*row + dt
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_tot;
-  float* orow = out + ((size_t)img * tokens + q) * kAttD;
+  if constexpr (!FUSEW) {
+    // store y[q][d], d = 4*row + dt
+    float* orow = out + ((size_t)img * tokens + q) * kAttD;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-    f32x4 v = {o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv};
-    *reinterpret_cast<f32x4*>(orow + 4 * row) = v;
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      f32x4 v = {o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv};
+      *reinterpret_cast<f32x4*>(orow + 4 * row) = v;
+    }
+  } else {
+    // ---- the `w` GEMM tail (gemm_nloop_kernel<3, 4> with the activation tile coming from registers instead of HBM) ----
+    __syncthreads();                                           // every read of the merge scratch is done: the attention tile may overwrite it
+    float* s_att = smem;                                       // [128 queries][kAttLdK]
+    if (grp == 0) {
+      float* arow = s_att + (wq * 32 + r) * kAttLdK;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        f32x4 v = {o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv};      // the values the unfused kernel stores as att
+        *reinterpret_cast<f32x4*>(arow + 4 * row) = v;
+      }
+    }
+    store_w(0, w_regs);
+    store_w(kAttWSlot, w_regs1);
+    __syncthreads();
+    constexpr int NI = 3, NCH = 4, G = 4, LDP = 36, NSTEPS = 2 * NCH;
+    f32x4 afr[NCH * G];                                        // this lane's pixel (query wq*32 + r), channels 8g + 4h .. +3
+#pragma unroll
+    for (int g = 0; g < NCH * G; ++g) afr[g] = *reinterpret_cast<const f32x4*>(s_att + (wq * 32 + r) * kAttLdK + g * 8 + 4 * h);
+    const int t0 = grp ? 5 : 0, t1 = grp ? 9 : 5;              // this wave group's channel tiles of N = 288
+    int b_base[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b_base[ni] = grp * (96 * LDP) + (ni * 32 + r) * LDP + 4 * h;
+    int w_cur = 0, w_n1 = kAttWSlot, w_n2 = 2 * kAttWSlot;
+    f32x4 bf[2][NI];
+    auto read_frags = [&](int slot, int b_off) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_ring + b_base[ni] + b_off);
+    };
+    read_frags(0, w_cur);
+    const float act_alpha = wa.act ? kLeakyAlpha : 1.f;
+    const size_t tile_pix = (size_t)img * tokens + (size_t)qb * 128 + (size_t)__builtin_amdgcn_readfirstlane(wq) * 32;
+    const unsigned lane_out = ((unsigned)(4 * h) * (unsigned)wa.out_cs + (unsigned)r) * 4u;
+    const unsigned lane_res = (unsigned)(4 * h) * (unsigned)wa.res_cs * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc_out = make_rsrc(wa.out + tile_pix * wa.out_cs);
+    const __amdgpu_buffer_rsrc_t rsrc_res = make_rsrc(wa.res + tile_pix * wa.res_cs);
+    for (int ng = 0; ng < 2; ++ng) {
+      const int tg = t0 + ng * NI;
+      const int nvalid = min(NI, t1 - tg);                     // 3 | 2 (group 0), 3 | 1 (group 1)
+      f32x16 acc[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[ni] = bias_tile(h, s_bias[(tg + ni) * 32 + r]);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int s_ = ng * NCH + ch;
+        const bool has1 = s_ + 1 < NSTEPS, has2 = s_ + 2 < NSTEPS;
+        if (has2) fetch_w(s_ + 2, w_regs);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int cur = g & 1, nxt = cur ^ 1;
+          if (g + 1 < G) {
+            read_frags(nxt, w_cur + (g + 1) * 8);
+          } else if (has1) {
+            read_frags(nxt, w_n1);
+          }
+          if (g == G - 1 && has2) store_w(w_n2, w_regs);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 a = afr[ch * G + g];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if (ni < nvalid) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[cur][ni][j], acc[ni], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = tw;
+      }
+      // epilogue of this channel group: residual (y3x) + LeakyReLU, NHWC store — gemm_nloop_kernel's, one destination
+      __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (ni >= nvalid) continue;
+        const int nt = (tg + ni) * 32;
+        const int n = nt + r;
+        f32x16 v = acc[ni];
+        if (nt < wa.res_c) {
+          const unsigned rcs4 = (unsigned)wa.res_cs * 4u;
+          const unsigned l1 = n < wa.res_c ? lane_res + (unsigned)r * 4u : kLaneOff;
+          const unsigned lj[4] = {l1, l1 + rcs4, l1 + 2u * rcs4, l1 + 3u * rcs4};
+          float r1[16];
+          unsigned so = (unsigned)nt * 4u;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r1[4 * q4 + j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_res, lj[j], so, 0));
+            so += 8u * rcs4;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] += r1[i];
+        }
+        leaky_relu_tile(v, act_alpha);
+        const unsigned vb = n < wa.n_store ? lane_out : kLaneOff;
+        const unsigned cs4 = (unsigned)wa.out_cs * 4u;
+        const unsigned vj[4] = {vb, vb + cs4, vb + 2u * cs4, vb + 3u * cs4};
+        unsigned so = (unsigned)nt * 4u;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[4 * q4 + j]), rsrc_out, vj[j], so, 0);
+          so += 8u * cs4;
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
   }
 }
 
 template <int QW>
 inline hipError_t launch_nonlocal_attention_qw(const float* qkv, float* out, int batch, int tokens, hipStream_t stream) {
-  auto kern = nonlocal_attention_kernel<QW>;
+  auto kern = nonlocal_attention_kernel<QW, false>;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {
@@ -233,7 +405,36 @@ inline hipError_t launch_nonlocal_attention_qw(const float* qkv, float* out, int
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(batch * (tokens / (QW * 32))), dim3(QW * 128), kAttSmemBytes, stream, qkv, out, tokens);
+  hipLaunchKernelGGL(kern, dim3(batch * (tokens / (QW * 32))), dim3(QW * 128), kAttSmemBytes, stream, qkv, out, tokens, AttWArgs{});
+  return hipGetLastError();
+}
+
+// The workgroup shape launch_nonlocal_attention picks for a batch (see there).
+inline int attention_auto_qw(int batch, int tokens) {
+  const long long cus = device_cu_count();
+  const long long blocks128 = (long long)batch * (tokens / 128);
+  long long best = -1;
+  int qw = 4;
+  for (int cand : {4, 2, 1}) {                                    // ties go to the larger workgroup
+    const long long rounds = (blocks128 * (4 / cand) + cus - 1) / cus;
+    const long long cost = rounds * (cand == 4 ? 17 : 10);
+    if (best < 0 || cost < best) { best = cost; qw = cand; }
+  }
+  return qw;
+}
+
+// attention + `w` GEMM tail in one launch (the 8-wave shape; callers use it when attention_auto_qw() == 4)
+inline hipError_t launch_nonlocal_attention_w(const float* qkv, int batch, int tokens, const AttWArgs& wa, hipStream_t stream) {
+  if (tokens % (4 * kAttKT) != 0 || wa.n_pad < 12 * 32 || wa.n_store > 288 || wa.res_c > 288) return hipErrorInvalidValue;
+  auto kern = nonlocal_attention_kernel<4, true>;
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (dev < 0 || !once.done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kAttWSmemBytes);
+    if (e != hipSuccess) return e;
+    if (dev >= 0) once.done[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(batch * (tokens / 128)), dim3(512), kAttWSmemBytes, stream, qkv, static_cast<float*>(nullptr), tokens, wa);
   return hipGetLastError();
 }
 
@@ -244,16 +445,7 @@ inline hipError_t launch_nonlocal_attention_qw(const float* qkv, float* out, int
 // arithmetic in the same order per query, so the choice does not change a single bit of the output.
 inline hipError_t launch_nonlocal_attention(const float* qkv, float* out, int batch, int tokens, hipStream_t stream, int qw = 0) {
   if (tokens % (4 * kAttKT) != 0) return hipErrorInvalidValue;      // 128-query blocks; the key loop takes two 64-key pairs per trip
-  if (qw == 0) {
-    const long long cus = device_cu_count();
-    const long long blocks128 = (long long)batch * (tokens / 128);
-    long long best = -1;
-    for (int cand : {4, 2, 1}) {                                    // ties go to the larger workgroup
-      const long long rounds = (blocks128 * (4 / cand) + cus - 1) / cus;
-      const long long cost = rounds * (cand == 4 ? 17 : 10);
-      if (best < 0 || cost < best) { best = cost; qw = cand; }
-    }
-  }
+  if (qw == 0) qw = attention_auto_qw(batch, tokens);
   if (qw == 4) return launch_nonlocal_attention_qw<4>(qkv, out, batch, tokens, stream);
   if (qw == 2) return launch_nonlocal_attention_qw<2>(qkv, out, batch, tokens, stream);
   if (qw == 1) return launch_nonlocal_attention_qw<1>(qkv, out, batch, tokens, stream);

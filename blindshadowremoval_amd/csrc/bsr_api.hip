@@ -147,6 +147,7 @@ struct bsr_handle {
   // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
   unsigned* range_flag = nullptr;
   bool fuse_heads = true;        // env BSR_FUSE_HEADS=0: always the two-launch heads (A/B measurements, bit-identity tests)
+  bool fuse_attw = true;         // env BSR_FUSE_ATTW=0: attention and the `w` GEMM as two launches (A/B measurements, bit-identity tests)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
   std::vector<int> ev_class;
@@ -429,6 +430,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   h->device = device;
   h->dtype = dtype;
   if (const char* e_ = getenv("BSR_FUSE_HEADS")) h->fuse_heads = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_FUSE_ATTW")) h->fuse_attw = atoi(e_) != 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -653,18 +655,38 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     snprintf(nm, sizeof nm, "res%d.c3q", i);
     // The y3 output also absorbs the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
     L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
-    if (L.rc == BSR_OK) {
-      snprintf(nm, sizeof nm, "res%d.attention", i);
-      L.begin(K_ATT, nm);
-      if (h->dtype == BSR_DTYPE_F32)
-        L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
-      else
-        L.check(bsr::launch_nonlocal_attention_x3(ws + p.qkv, ws + p.att[i], B, H8 * W8, s, h->range_flag), "attention_x3");
-      L.end();
+    // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att))).
+    // fp32, full batches: ONE launch — the `w` GEMM runs as the tail of the attention kernel on the workgroup's own 128 pixels
+    // (attention.h, FUSEW; the attention output never goes to HBM).  Small batches (the 4- / 2-wave attention shapes) and the 16-bit
+    // modes keep the two launches; both forms give the same bits (tests/test_gpu_parity.py).
+    const bool fuse_w = h->dtype == BSR_DTYPE_F32 && h->fuse_attw && bsr::attention_auto_qw(B, H8 * W8) == 4;
+    if (fuse_w && L.rc == BSR_OK) {
+      LayerW l;
+      snprintf(nm, sizeof nm, "res%d.w", i);
+      L.rc = find_layer(h, nm, 4, 1, 36, 12 * 32, &l);
+      if (L.rc == BSR_OK) {
+        bsr::AttWArgs wa{};
+        wa.w = l.w; wa.bias = l.b; wa.n_pad = l.n_pad;
+        wa.res = y3; wa.res_cs = CS_Y3X; wa.res_c = CS_Y3X;
+        wa.out = r_out; wa.out_cs = o_cs; wa.n_store = o_cs < 288 ? o_cs : 288; wa.act = 1;
+        snprintf(nm, sizeof nm, "res%d.attw", i);
+        L.begin(K_ATT, nm);
+        L.check(bsr::launch_nonlocal_attention_w(ws + p.qkv, B, H8 * W8, wa, s), "attention+w");
+        L.end();
+      }
+    } else {
+      if (L.rc == BSR_OK) {
+        snprintf(nm, sizeof nm, "res%d.attention", i);
+        L.begin(K_ATT, nm);
+        if (h->dtype == BSR_DTYPE_F32)
+          L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
+        else
+          L.check(bsr::launch_nonlocal_attention_x3(ws + p.qkv, ws + p.att[i], B, H8 * W8, s, h->range_flag), "attention_x3");
+        L.end();
+      }
+      snprintf(nm, sizeof nm, "res%d.w", i);
+      L.gemm<3, 4>(K_CONV1, nm, ws + p.att[i], 128, ncell, r_out, o_cs, o_cs < 288 ? o_cs : 288, 1, y3, CS_Y3X, CS_Y3X);
     }
-    // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att)))
-    snprintf(nm, sizeof nm, "res%d.w", i);
-    L.gemm<3, 4>(K_CONV1, nm, ws + p.att[i], 128, ncell, r_out, o_cs, o_cs < 288 ? o_cs : 288, 1, y3, CS_Y3X, CS_Y3X);
     if (x_c > 288 && L.rc == BSR_OK) {      // the block output keeps the wider of x / y (model.py:105-113): channels the GEMM does not cover
       glue_begin("lrelu_copy");
       hipLaunchKernelGGL(bsr::lrelu_copy_kernel, dim3((unsigned)((ncell * (x_c - 288) + 255) / 256)), dim3(256), 0, s, x, x_cs, r_out, o_cs, 288, x_c, ncell);

@@ -314,7 +314,9 @@ class Dataset:
         if workers < 0:
             workers = min(cpu_share(), 16)
         self.workers = int(workers)
-        self.prefetch = int(prefetch) if prefetch is not None else max(2, 2 * self.workers)
+        # elements the workers may run ahead of the consumer: two per worker on the host path; four with device preparation, whose
+        # consumer (the pipelined FSRNet loop) spends milliseconds at a time away from the feed
+        self.prefetch = int(prefetch) if prefetch is not None else max(2, (4 if device_prep is not None else 2) * self.workers)
         self._pool = None
         # device_prep = GPU index: rows are prepared ON THE DEVICE (prep.py / csrc/prep_kernels.h) in groups of `device_batch`; the
         # workers then only decode PNGs and triangulate, and `feed` yields (img CUDA tensor [1,1,S,S,16], box[1,4], name) — the
@@ -371,6 +373,12 @@ class Dataset:
         pool, self._pool = self._pool, None
         if pool is not None:
             pool.shutdown()
+
+    def poll(self) -> None:
+        """Non-blocking: move the results the workers have finished out of their pipes (a worker whose pipe is full waits with its
+        next element).  The loops call it while they are busy with the GPU / the PNG pool."""
+        if self._pool is not None:
+            self._pool._pump(block=False)
 
     def warm(self) -> None:
         """Start the worker processes and let them import their modules now (otherwise the first elements pay for it)."""

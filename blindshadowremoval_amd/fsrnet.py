@@ -146,31 +146,38 @@ class Logging(object):
             self._write_png(strip, out)
         return out
 
-    def save_strips(self, strips: np.ndarray, names: Sequence[str]) -> None:
-        """save_strip for a whole batch [B,S,W,3]; with png_workers > 0 the batch goes to the workers through one shared-memory file."""
+    def save_strips(self, strips: np.ndarray, names: Sequence[str], parked: Optional[Tuple[str, object]] = None) -> None:
+        """save_strip for a whole batch [B,S,W,3]; with png_workers > 0 the batch goes to the workers through one shared-memory file.
+        ``parked`` = (shared-memory file that ALREADY holds `strips`, callback to run when every strip of it is written): the
+        pipelined loops copy device -> that file directly (_ShmPinnedRing), so nothing is copied here."""
         if self.png_workers <= 0:
             for strip, name in zip(strips, names):
                 self.save_strip(strip, name)
+            if parked is not None:
+                parked[1]()
             return
         if self._png_pool is None:
             from .dataset import _SelectPool
             self._png_pool = _SelectPool(self.png_workers)
         while len(self._shm_batches) >= 4:                   # bound what sits in /dev/shm: wait for the oldest batch
             self._reap(block=True)
-        shm = _shm_file("bsr_png_")
-        np.ascontiguousarray(strips).tofile(shm)
+        if parked is None:
+            shm, done = _shm_file("bsr_png_"), None
+            np.ascontiguousarray(strips).tofile(shm)
+        else:
+            shm, done = parked
         tickets = []
         for j, name in enumerate(names):
             out = self._png_path(name)
             self.saved.append(out)
             tickets.append(self._png_pool.submit(("png", out, (shm, tuple(strips.shape), j))))
-        self._shm_batches.append((shm, tickets))
+        self._shm_batches.append((shm, tickets, done))
         self._reap(block=False)
 
     def _reap(self, block: bool) -> None:
         """Collect finished PNG batches (oldest first) and unlink their shared-memory files."""
         while self._shm_batches:
-            shm, tickets = self._shm_batches[0]
+            shm, tickets, done = self._shm_batches[0]
             if not block:
                 self._png_pool._pump(block=False)
                 if not all(t in self._png_pool._done for t in tickets):
@@ -184,10 +191,13 @@ class Logging(object):
                         first = first or e
             finally:
                 self._shm_batches.pop(0)
-                try:
-                    os.unlink(shm)
-                except OSError:
-                    pass
+                if done is not None:             # a ring slot: goes back to its owner
+                    done()
+                else:
+                    try:
+                        os.unlink(shm)
+                    except OSError:
+                        pass
             if first is not None:                # ... and the first failure is reported once the batch's shared-memory file is gone
                 raise first
             block = False
@@ -254,11 +264,12 @@ class Logging(object):
             if self._png_pool is not None:
                 self._png_pool.shutdown()
                 self._png_pool = None
-            for shm, _ in self._shm_batches:
-                try:
-                    os.unlink(shm)
-                except OSError:
-                    pass
+            for shm, _, done in self._shm_batches:
+                if done is None:
+                    try:
+                        os.unlink(shm)
+                    except OSError:
+                        pass
             self._shm_batches = []
 
 
@@ -270,6 +281,64 @@ def _shm_file(prefix: str) -> str:
     fd, path = tempfile.mkstemp(prefix=prefix, dir=d)
     os.close(fd)
     return path
+
+
+class _ShmPinnedRing:
+    """Staging buffers that are BOTH pinned host memory (the target of an asynchronous device-to-host copy) and shared-memory files a
+    worker process opens by name: a batch's PNG strips / post-processing inputs land where the workers read them, with no copy in
+    the loop's thread in between (parking a batch with ndarray.tofile cost 3 ms per 16 strips and 13 ms per 16 post-processing
+    items — a quarter of the loops' wall time).  Each slot is a file in /dev/shm mapped MAP_SHARED and registered with the HIP
+    runtime (hipHostRegister).  `acquire(nbytes)` hands out a free slot, `release(slot)` returns it once its readers are done.
+    If the runtime refuses the registration the constructor raises and the loops fall back to private pinned buffers + tofile."""
+
+    def __init__(self, n: int, nbytes: int):
+        import mmap
+        self.nbytes = int(nbytes)
+        self.slots = []                          # (path, mmap, uint8 tensor)
+        self.free: List[int] = []
+        self._rt = torch.cuda.cudart()
+        try:
+            for i in range(n):
+                path = _shm_file("bsr_ring_")
+                with open(path, "r+b") as f:
+                    f.truncate(self.nbytes)
+                    mm = mmap.mmap(f.fileno(), self.nbytes, flags=mmap.MAP_SHARED)
+                t = torch.frombuffer(mm, dtype=torch.uint8)
+                self.slots.append([path, mm, t, False])
+                rc = self._rt.cudaHostRegister(t.data_ptr(), self.nbytes, 1)
+                if int(rc) != 0:
+                    raise RuntimeError("hipHostRegister of a /dev/shm mapping failed (%s)" % rc)
+                self.slots[-1][3] = True
+                self.free.append(i)
+        except BaseException:
+            self.close()
+            raise
+
+    def acquire(self) -> Optional[int]:
+        return self.free.pop(0) if self.free else None
+
+    def release(self, slot: int) -> None:
+        self.free.append(slot)
+
+    def view(self, slot: int, dtype, shape) -> torch.Tensor:
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        return self.slots[slot][2][:n].view(dtype).reshape(shape)
+
+    def path(self, slot: int) -> str:
+        return self.slots[slot][0]
+
+    def close(self) -> None:
+        for path, mm, t, registered in self.slots:
+            try:
+                if registered:
+                    self._rt.cudaHostUnregister(t.data_ptr())
+            except Exception:
+                pass
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        self.slots, self.free = [], []
 
 
 def _name(x) -> str:
@@ -296,6 +365,7 @@ class FSRNet(object):
             if weights is not None:
                 self.gen.load_weights(weights)
         self.log = Logging(config, png_threads=4)
+        self.shm_ring = True                     # device-to-host copies of pool-bound batches land in pinned shared-memory slots (_ShmPinnedRing); False: private pinned buffers + a file copy
         self.gpu_inflight = 2                    # batches whose forward + device-to-host copy may be outstanding while the loop feeds the next one
         self.all_losses: List[Tuple[str, Dict[str, float]]] = []      # (name, losses) of EVERY item in list order — on every rank after a data-parallel loop
         self.timings: Dict[str, float] = {}      # wall-clock split of the last test / testFFHQ loop (see _loop)
@@ -434,9 +504,14 @@ class FSRNet(object):
         pins: List[Optional[torch.Tensor]] = [None] * (depth + 1)      # pinned staging buffers, one per batch that may be outstanding (+ the one being filled)
         gpu_q: List[Tuple] = []             # submitted batches whose device-to-host copy may still be running, oldest first
         turn = [0]
+        # batches bound for a worker pool (PNG strips, UCB post-processing) are copied device -> a pinned SHARED-MEMORY slot the workers
+        # read in place (_ShmPinnedRing); [ring | None, already tried]
+        ring_state = [None, not (on_gpu and self.shm_ring)]
 
         post_pool = self._get_post_pool() if ucb and postprocess and self.post_workers > 0 else None
         inflight: List[Tuple] = []          # UCB batches whose post-processing runs in the worker pool: (pending items, futures)
+
+        poll = getattr(dataset, "poll", lambda: None)      # lets the loader's workers hand over finished elements while this thread is busy elsewhere
 
         def finish(batch_items, post):
             """log + save + collect one batch, in item order (post = [(losses, figs | None)] for the UCB post-processing mode)"""
@@ -455,32 +530,68 @@ class FSRNet(object):
         def drain(keep: int):
             while len(inflight) > keep:
                 t1 = time.perf_counter()
-                batch_items, futs, shm = inflight.pop(0)
+                batch_items, futs, shm, slot_ = inflight.pop(0)
                 try:
                     post = [post_pool.result(fu) for fu in futs]
                 finally:
-                    try:
-                        os.unlink(shm)
-                    except OSError:
-                        pass
+                    if slot_ is not None:
+                        ring_state[0].release(slot_)
+                    else:
+                        try:
+                            os.unlink(shm)
+                        except OSError:
+                            pass
                 tm["post_s"] += time.perf_counter() - t1
                 finish(batch_items, post)
 
-        def to_host_async(payload: torch.Tensor):
-            """-> (numpy view of the payload on the host, event | None).  GPU: an asynchronous copy into this batch's pinned buffer;
-            the view is valid once the event has completed and until the buffer's turn comes again (depth + 1 submissions later)."""
+        def ring_slot(nbytes: int, to_pool: bool, nrows: int):
+            """a free slot of the shared pinned ring for a batch that goes to a worker pool, or None (no pool / ring unavailable)"""
+            if not to_pool:
+                return None
+            if ring_state[0] is None and not ring_state[1]:
+                ring_state[1] = True
+                try:
+                    full = nbytes // max(1, nrows) * max(nrows, batch)                  # sized for a full batch
+                    ring_state[0] = _ShmPinnedRing(depth + 6, full)
+                except Exception as e:            # the runtime would not register a /dev/shm mapping: private pinned buffers + tofile (as in round 3)
+                    tm["shm_ring_error"] = str(e)
+            ring = ring_state[0]
+            if ring is None or nbytes > ring.nbytes:
+                return None
+            slot = ring.acquire()
+            while slot is None:                   # every slot is with a worker pool: collect the oldest batch
+                if inflight:
+                    drain(keep=len(inflight) - 1)
+                elif self.log._shm_batches:
+                    self.log._reap(block=True)
+                else:
+                    return None
+                slot = ring.acquire()
+            return slot
+
+        def to_host_async(payload: torch.Tensor, to_pool: bool = False):
+            """-> (numpy view of the payload on the host, event | None, ring slot | None).  GPU: an asynchronous copy into this batch's
+            pinned buffer; the view is valid once the event has completed and until the buffer's turn comes again (depth + 1
+            submissions later) — or, in a ring slot, until the slot is released."""
             if not on_gpu:
-                return payload.numpy(), None
+                return payload.numpy(), None, None
+            nbytes = payload.numel() * payload.element_size()
+            slot = ring_slot(nbytes, to_pool, int(payload.shape[0]))
+            if slot is not None:
+                view = ring_state[0].view(slot, payload.dtype, tuple(payload.shape))
+                view.copy_(payload, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                return view.numpy(), ev, slot
             k = turn[0]
             turn[0] = (k + 1) % len(pins)
-            nbytes = payload.numel() * payload.element_size()
             if pins[k] is None or pins[k].numel() < nbytes:
                 pins[k] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
             view = pins[k][:nbytes].view(payload.dtype).reshape(payload.shape)
             view.copy_(payload, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            return view.numpy(), ev
+            return view.numpy(), ev, None
 
         def submit():
             """one batch: rows -> device -> generator -> what the host needs, on its way to pinned memory; nothing here waits for the GPU"""
@@ -495,7 +606,7 @@ class FSRNet(object):
             pending.clear()
             if ucb and postprocess:
                 # train_test_GSC.py:424-748 runs on the host, one independent item per call: what it reads comes over in ONE copy
-                host, ev = to_host_async(torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3))      # [B,S,S,10]
+                host, ev, slot = to_host_async(torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3), to_pool=post_pool is not None)      # [B,S,S,10]
                 figs_b = None
             else:
                 # FFHQ / raw-UCB: the figures stay on the device; the PNG strips of the whole batch are assembled there and come
@@ -506,16 +617,18 @@ class FSRNet(object):
                 else:
                     figs_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]        # train_test_GSC.py:872-873,889
                     shown_b = figs_b
-                host, ev = to_host_async(self.log.strips_on_device(shown_b))
-            gpu_q.append((items, host, ev, figs_b))
+                host, ev, slot = to_host_async(self.log.strips_on_device(shown_b), to_pool=self.log.png_workers > 0)
+            gpu_q.append((items, host, ev, figs_b, slot))
             tm["forward_s"] += time.perf_counter() - t0
             tm["forwards"] += 1
+            poll()
             while len(gpu_q) > depth:
                 complete(gpu_q.pop(0))
 
         def complete(entry):
             """the batch's device work has to be done now: wait for its event, then hand its host half on"""
-            items, host, ev, figs_b = entry
+            items, host, ev, figs_b, slot = entry
+            ring = ring_state[0]
             t0 = time.perf_counter()
             if ev is not None:
                 ev.synchronize()
@@ -523,12 +636,16 @@ class FSRNet(object):
                 self.gen.check_range()                              # 16-bit modes: an out-of-range activation is an error here, never a silent inf
             tm["forward_s"] += time.perf_counter() - t0
             tm.setdefault("first_batch_done_s", time.time() - start)
+            poll()
             t1 = time.perf_counter()
             if ucb and postprocess:
                 if post_pool is not None:
                     post_pool._pump(block=False)
-                    shm = _shm_file("bsr_post_")
-                    host.tofile(shm)                                # the arrays travel through the shared-memory file, not the pipe
+                    if slot is not None:
+                        shm = ring.path(slot)                       # the copy from the device landed in the shared-memory slot itself
+                    else:
+                        shm = _shm_file("bsr_post_")
+                        host.tofile(shm)                            # the arrays travel through a shared-memory file, not the pipe
                     shape = tuple(host.shape)
 
                     def job(j):
@@ -537,7 +654,7 @@ class FSRNet(object):
                                 "png": self.log._png_path(name) if self._post_writes_png else None, "return_figs": self.return_figs}
                     # worker PROCESSES (the post-processing is ~30 ms of small numpy / torch-CPU calls per item, GIL-bound in threads);
                     # results are collected up to post_inflight batches later
-                    inflight.append((items, [post_pool.submit(("ucb_post", job(j))) for j in range(len(items))], shm))
+                    inflight.append((items, [post_pool.submit(("ucb_post", job(j))) for j in range(len(items))], shm, slot))
                     tm["post_s"] += time.perf_counter() - t1
                     drain(keep=self.post_inflight)
                     return
@@ -558,8 +675,11 @@ class FSRNet(object):
                 tm["post_s"] += time.perf_counter() - t1
                 finish(items, post)
                 return
-            strips = host if self.log.png_workers > 0 else np.array(host)      # the worker path copies into shared memory at once; writer threads keep the array
-            self.log.save_strips(strips, [it[1] for it in items])
+            if slot is not None:                    # the strips already sit in a shared-memory slot: the PNG workers read them there
+                self.log.save_strips(host, [it[1] for it in items], parked=(ring.path(slot), lambda k=slot: ring.release(k)))
+            else:
+                strips = host if self.log.png_workers > 0 else np.array(host)      # the worker path copies into shared memory at once; writer threads keep the array
+                self.log.save_strips(strips, [it[1] for it in items])
             for j, (step, name, _, box) in enumerate(items):
                 self.log.display({}, 0, step, False, num_list)
                 tm["items"] += 1
@@ -586,15 +706,25 @@ class FSRNet(object):
             drain(keep=0)
         except BaseException:
             self.close_pools()              # outstanding jobs of a failed loop are dropped with their workers
-            for _, _, shm in inflight:
+            for _, _, shm, slot_ in inflight:
+                if slot_ is None:
+                    try:
+                        os.unlink(shm)
+                    except OSError:
+                        pass
+            if ring_state[0] is not None:
                 try:
-                    os.unlink(shm)
-                except OSError:
+                    self.log.flush()        # PNG workers may still be reading ring slots
+                except BaseException:       # noqa: BLE001
                     pass
+                ring_state[0].close()
             raise
         t0 = time.perf_counter()
         self.log.flush()
         tm["png_s"] += time.perf_counter() - t0
+        if ring_state[0] is not None:
+            tm["shm_ring_slots"] = len(ring_state[0].slots)
+            ring_state[0].close()
         self._gather_losses(results, names, lo, rank, world, num_list)
         tm["total_s"] = time.time() - start
         if rank == 0:

@@ -62,7 +62,9 @@ def test_roofline_tables_are_consistent():
     spec.loader.exec_module(bench)
     assert abs(sum(bench.LAYER_MMAC.values()) - 9052.06) < 1.0
     grouped = [n for layers in bench.KERNEL_GROUPS.values() for n in layers]
-    assert sorted(grouped) == sorted(bench.LAYER_MMAC)
+    assert sorted(grouped) == sorted(list(bench.LAYER_MMAC) + list(bench.FUSED_LAUNCHES))      # every launch name sits in exactly one group
+    for name, parts in bench.FUSED_LAUNCHES.items():                                            # a fused launch is priced as the sum of its layers
+        assert abs(bench.launch_mmac(name) - sum(bench.LAYER_MMAC[p] for p in parts)) < 1e-9 and name in bench.LAYER_IO_ELEMS
     assert abs(2e-3 * sum(bench.LAYER_MMAC[n] for n in bench.LAYERS_3X3) - 2e-3 * (16.78 + 3.15) - bench.GFLOP_3X3_PER_IMAGE) < 0.01
     assert bench.physical_cores() >= 1
 

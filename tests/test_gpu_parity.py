@@ -713,6 +713,39 @@ def test_fused_heads_epilogue_is_bit_identical_to_the_two_launch_form(dtype, mon
     plain.close()
 
 
+def test_attention_with_fused_w_tail_is_bit_identical_to_the_two_launch_form(monkeypatch):
+    """Round 4: at full batches (the 8-wave attention shape) the NonLocalBlock's `w` GEMM + residual + LeakyReLU runs as the tail of the
+    attention kernel on the workgroup's own 128 pixels (csrc/attention.h FUSEW) — the same MFMA order per output element as the
+    separate gemm_nloop launch => the same bits on every probe and output.  BSR_FUSE_ATTW=0 at handle creation forces two launches."""
+    from blindshadowremoval_amd import Generator
+    w = init_weights(1)
+    fused = Generator().load_weights(w)
+    monkeypatch.setenv("BSR_FUSE_ATTW", "0")
+    plain = Generator().load_weights(w)
+    monkeypatch.delenv("BSR_FUSE_ATTW")
+    g = torch.Generator().manual_seed(72)
+    # (33, ...): 264 query blocks of 128 = two rounds of the 8-wave shape — the launcher prefers three rounds of the 4-wave one there,
+    # and that shape keeps the two launches: still the same bits
+    for (B, H, W, want_fused) in ((32, 256, 256, True), (64, 256, 256, True), (8, 512, 512, True), (33, 256, 256, False)):
+        inp, uv = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
+        fused.set_timing(True)
+        a = [t.clone() for t in fused(inp, uv)]
+        torch.cuda.synchronize()
+        names = [n for n, _, _ in fused.get_launch_timing()]
+        fused.set_timing(False)
+        if want_fused:
+            assert "res0.attw" in names and "res5.attw" in names and "res0.w" not in names and "res0.attention" not in names, (B, H, W)
+        else:
+            assert "res0.attention" in names and "res0.w" in names, (B, H, W)
+        b = plain(inp, uv)
+        for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
+            assert torch.equal(x, y), (B, H, W, name)
+        for pr in ("res0", "res2", "res3", "res5"):
+            assert torch.equal(fused.probe(pr), plain.probe(pr)), (B, H, W, pr)
+    fused.close()
+    plain.close()
+
+
 def test_packed_output_is_bit_identical(gen_w):
     """bsr_forward_packed: con_rgb | dif written as one [B,H,W,4] tensor by the tail kernel (the all-gather payload of bench.py /
     dist.py) — the same bits as the two separate outputs."""
