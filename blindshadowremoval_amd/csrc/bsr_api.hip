@@ -147,6 +147,7 @@ struct bsr_handle {
   // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
   unsigned* range_flag = nullptr;
   bool fuse_heads = true;        // env BSR_FUSE_HEADS=0: always the two-launch heads (A/B measurements, bit-identity tests)
+  bool exp_half_tile = false, exp_c3q_ni4 = false;      // experiments (env BSR_EXP_HALF_TILE / BSR_EXP_C3Q_NI4): measured and left off, see profiles/README.md
   bool fuse_attw = true;         // env BSR_FUSE_ATTW=0: attention and the `w` GEMM as two launches (A/B measurements, bit-identity tests)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
@@ -255,7 +256,7 @@ struct Launcher {
     // order: bit-identical) doubles the grid.
     constexpr bool kTrunk = !TR && S == 1 && NI == 2 && (CC == 32 || (k11 && CC == 24));
     bool half_tile = false;
-    if constexpr (kTrunk) half_tile = !h16 && mh % 2 == 0 && (long long)(mh / 4) * (mw / 32) * h->B * nb < bsr::device_cu_count();
+    if constexpr (kTrunk) half_tile = !h16 && mh % 2 == 0 && ((long long)(mh / 4) * (mw / 32) * h->B * nb < bsr::device_cu_count() || h->exp_half_tile);
     if (half_tile) {
       if constexpr (kTrunk) check(bsr::launch_igemm_conv<KH, KW, S, TR, 2, 32, 2, 2, 1, 1, CC, INB>(a, h->B, s), name);
     } else if (!h16)
@@ -288,7 +289,7 @@ struct Launcher {
       const int most = (tiles + NI - 1) / NI;
       kNSplit = want < 2 ? 2 : (want > most ? most : want);
     }
-    rc = find_layer(h, name, NCH, 1, 36, (tiles + NI) * 32, &l);   // the last group of a range may read (zero) rows past its tiles
+    rc = find_layer(h, name, NCH, 1, 36, (tiles + NI - 1) * 32, &l);   // the last group of a range may read (zero) rows past its tiles
     if (rc != BSR_OK) return;
     if (pixels % C::BM != 0) { rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': pixel count is not a multiple of 128"); return; }
     bsr::ConvArgs a{};
@@ -431,6 +432,8 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   h->dtype = dtype;
   if (const char* e_ = getenv("BSR_FUSE_HEADS")) h->fuse_heads = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_FUSE_ATTW")) h->fuse_attw = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_EXP_HALF_TILE")) h->exp_half_tile = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_EXP_C3Q_NI4")) h->exp_c3q_ni4 = atoi(e_) != 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -654,6 +657,9 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     // K = 128 GEMM: the qkv weights are composed offline with conv3's (pack.py), N = [y3 288 | qkv 384]
     snprintf(nm, sizeof nm, "res%d.c3q", i);
     // The y3 output also absorbs the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
+    if (h->exp_c3q_ni4)
+      L.gemm<4, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
+    else
     L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att))).
     // fp32, full batches: ONE launch — the `w` GEMM runs as the tail of the attention kernel on the workgroup's own 128 pixels

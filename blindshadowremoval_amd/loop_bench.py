@@ -43,8 +43,11 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
                  # on the device, UCB post-processing in worker processes one batch behind the GPU
                  # worker counts from sweeps on the GPU box (16-CPU quota): loader ~1 per usable CPU, PNG 3/4 of that; UCB: loader 1/2,
                  # post 5/4 (the post-processing alone peaks at ONE process per usable CPU — scratch/post_scaling.py), three batches in flight
-                 ("device_prep", dict(workers=max(2, ncpu // 2) if ucb else max(2, ncpu), device_prep=fsr.gen._device, device_batch=batch),
-                  dict(post_workers=max(2, ncpu * 5 // 4), png_workers=max(2, ncpu * 3 // 4), post_inflight=3))]
+                 # round 4 (pipelined loop, shared pinned ring): FFHQ loader 7/8 + PNG 7/8 of the usable CPUs; UCB loader 5/8 + post-processing
+                 # ONE process per usable CPU (more only adds contention: 20 workers 300 /s, 16 workers 356 /s) and no PNG pool (the
+                 # post-processing workers write the strips themselves)
+                 ("device_prep", dict(workers=max(2, ncpu * 5 // 8) if ucb else max(2, ncpu * 7 // 8), device_prep=fsr.gen._device, device_batch=batch),
+                  dict(post_workers=max(2, ncpu), png_workers=0 if ucb else max(2, ncpu * 7 // 8), post_inflight=3))]
         for label, ds_kw, fsr_kw in modes:
             ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
             fsr.post_workers = fsr_kw.get("post_workers", 0)

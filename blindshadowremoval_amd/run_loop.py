@@ -65,15 +65,15 @@ def main(argv=None) -> int:
     os.makedirs(os.path.join(cfg.CHECKPOINT_DIR, "test"), exist_ok=True)
     ucb = args.loop == "ucb"
     ncpu = cpu_share()                      # this rank's share of the node's usable CPUs
-    ds_kw = dict(workers=max(1, ncpu // 2 if ucb else ncpu))
+    ds_kw = dict(workers=max(1, ncpu * 5 // 8 if ucb else ncpu * 7 // 8))      # worker counts: sweeps on the 16-CPU GPU box (loop_bench.py)
     if not args.host_prep:
         ds_kw.update(device_prep=local_rank, device_batch=args.batch)
     ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
     fsr = FSRNet(cfg, weights=init_weights(args.random_weights) if args.random_weights is not None else None, dtype=args.dtype)
-    fsr.post_workers = max(2, ncpu * 5 // 4) if ucb else 0
+    fsr.post_workers = max(2, ncpu) if ucb else 0
     fsr.post_inflight = 3
     fsr.return_figs = False
-    fsr.log.png_workers = max(1, ncpu * 3 // 4)
+    fsr.log.png_workers = 0 if ucb else max(1, ncpu * 7 // 8)
     rc = 0
     try:
         ds.warm()
