@@ -65,8 +65,10 @@ for _i in range(6):
 # Launches that compute SEVERAL reference layers (round 4: at full batches the `w` GEMM is the tail of the attention kernel): priced with
 # the sum of their parts; LAYER_MMAC stays the per-layer table of SURVEY Appendix C.
 FUSED_LAUNCHES = {"res%d.attw" % _i: ("res%d.attention" % _i, "res%d.w" % _i) for _i in range(6)}
+FUSED_LAUNCHES.update({"res%d.c2c3q" % _i: ("res%d.conv2" % _i, "res%d.c3q" % _i) for _i in range(6)})      # conv2 with conv3 | theta|phi|g as its tail
 for _i in range(6):
     LAYER_IO_ELEMS["res%d.attw" % _i] = _io(32, 384 + 288, 32, 264)          # qkv + y3x in, block output out (att never reaches HBM)
+    LAYER_IO_ELEMS["res%d.c2c3q" % _i] = _io(32, 128 + (99, 257, 257, 261, 261, 261)[_i], 32, 288 + 384)      # t1 + block input in, y3x + qkv out (t2 never reaches HBM)
 
 
 def launch_mmac(name):
@@ -94,6 +96,7 @@ KERNEL_GROUPS = {
     "igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=2,CC=32> (transposed 3x3: up2, up3, clr_up3)": ["up2", "up3", "clr_up3"],
     "igemm_conv_kernel<3,3,1,TR,...> other instantiations (up1, clr_up1, clr_up2)": ["up1", "clr_up1", "clr_up2"],
     "igemm_conv_kernel<3,3,1> (res*.conv2)": ["res%d.conv2" % i for i in range(6)],
+    "igemm_conv_kernel<3,3,1,..,WN=2,FUSE_TAIL> (res*.conv2 + conv3|theta|phi|g tail)": ["res%d.c2c3q" % i for i in range(6)],
     "igemm_conv_kernel<3,3,2> (down1-3)": ["down1", "down2", "down3"],
     "nonlocal_attention_kernel": ["res%d.attention" % i for i in range(6)],
     "nonlocal_attention_kernel<4, FUSEW> (res*.attention + res*.w tail)": ["res%d.attw" % i for i in range(6)],
@@ -332,8 +335,15 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
     dom_name = max(groups, key=lambda k: groups[k]["ms"])
     dom = groups[dom_name]
     peak = dom["peak"]
+    # the "3x3-conv path": every launch that computes a 3x3 layer.  A fused launch (res*.c2c3q = conv2 + the conv3 | theta|phi|g GEMM)
+    # cannot be split, so it enters with ALL its time and ALL its algorithmic work — the path's FLOPs grow by the GEMM's, never its rate
     t33 = sum(layer_ms.get(n, 0.0) for n in LAYERS_3X3)
-    path = GFLOP_3X3_PER_IMAGE * B / t33
+    gflop33 = GFLOP_3X3_PER_IMAGE * B
+    fused33 = [n for n, parts in FUSED_LAUNCHES.items() if n in layer_ms and any(p_ in LAYERS_3X3 for p_ in parts)]
+    for n in fused33:
+        t33 += layer_ms[n]
+        gflop33 += 2e-3 * B * sum(LAYER_MMAC[p_] for p_ in FUSED_LAUNCHES[n] if p_ not in LAYERS_3X3)
+    path = gflop33 / t33
     peak33 = group_peak(["up3"], dtype)
     t_all = sum(layer_ms.values())
     glue_ms = sum(ms for n, ms in layer_ms.items() if n not in LAYER_MMAC and n not in FUSED_LAUNCHES)
@@ -354,7 +364,9 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
                               "launches carry ~1-2 us of event overhead each, so all_kernels_ms slightly exceeds ms_per_step" % n_rep),
           "algorithmic_gflop_per_launch": round(dom["gflop"] / dom["launches"], 2),
           "path_3x3": {"achieved": round(path, 2), "peak": round(peak33, 1), "frac": round(path / peak33, 4), "unit": "TFLOP/s", "launches": len(LAYERS_3X3), "ms": round(t33, 4),
-                       "algorithmic_gflop": round(GFLOP_3X3_PER_IMAGE * B, 2)},
+                       "algorithmic_gflop": round(gflop33, 2),
+                       "note": ("%d of the launches are res*.conv2 fused with the conv3 | theta|phi|g GEMM: counted with their whole time and the GEMM's work "
+                                "(%.1f GFLOP beyond the path's %.1f)" % (len(fused33), gflop33 - GFLOP_3X3_PER_IMAGE * B, GFLOP_3X3_PER_IMAGE * B)) if fused33 else None},
           "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all, 2), "all_kernels_ms": round(t_all, 4),
           "kernel_groups": {k: {kk: vv for kk, vv in v.items() if kk != "gflop"} for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
           "glue_ms": round(glue_ms, 4)}
@@ -415,7 +427,7 @@ def attach_traffic(rf, dom_name, B, dtype):
     from blindshadowremoval_amd.build import source_sha16
     sha = source_sha16()
     sfx = "" if dtype == "f32" else "_" + dtype
-    for tag in ("r3", "r2", "r1"):
+    for tag in ("r4", "r3", "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx))
         if not os.path.isfile(tpath):
             continue
@@ -448,27 +460,28 @@ def attach_mfma(rf, dom_name, B, dtype):
     from blindshadowremoval_amd.build import source_sha16
     sha = source_sha16()
     sfx = "" if dtype == "f32" else "_" + dtype
-    mpath = os.path.join(ROOT, "profiles", "r3_pmc_mfma%s.json" % sfx)
     rf["mfma_busy"] = rf["clock_ghz"] = None
-    if not os.path.isfile(mpath):
-        rf["mfma_note"] = "no profiles/r3_pmc_mfma%s.json" % sfx
+    mtag = next((t for t in ("r4", "r3") if os.path.isfile(os.path.join(ROOT, "profiles", "%s_pmc_mfma%s.json" % (t, sfx)))), None)
+    if mtag is None:
+        rf["mfma_note"] = "no profiles/r*_pmc_mfma%s.json" % sfx
         return
+    mpath = os.path.join(ROOT, "profiles", "%s_pmc_mfma%s.json" % (mtag, sfx))
     with open(mpath) as fm:
         m = json.load(fm)
     key = [k for g, k in GROUP_KERNEL_KEY if g in dom_name]
     rows = [v for k, v in (m.get("per_kernel") or {}).items() if key and key[0] in k]
     if B != m.get("batch") or m.get("kernel_src_sha16") != sha:
-        rf["mfma_note"] = ("profiles/r3_pmc_mfma%s.json was measured on kernel sources %s / batch %s, this build is %s / batch %d: not reported"
+        rf["mfma_note"] = ("profiles/%s_pmc_mfma%%s.json was measured on kernel sources %%s / batch %%s, this build is %%s / batch %%d: not reported" % mtag
                            % (sfx, m.get("kernel_src_sha16"), m.get("batch"), sha, B))
     elif not rows or "mfma_busy" not in rows[0]:
-        rf["mfma_note"] = "profiles/r3_pmc_mfma%s.json has no matrix-pipe counters for the dominant kernel of this run" % sfx
+        rf["mfma_note"] = "profiles/%s_pmc_mfma%s.json has no matrix-pipe counters for the dominant kernel of this run" % (mtag, sfx)
     else:
         us = sum(r["us_per_forward"] for r in rows)
         rf["mfma_busy"] = round(sum(r["mfma_busy"] * r["us_per_forward"] for r in rows) / us, 4)
         rf["clock_ghz"] = round(sum(r["clock_ghz"] * r["us_per_forward"] for r in rows) / us, 3)
         rf["mfma_busy_of_nominal_clock"] = round(sum(r["mfma_busy_nominal"] * r["us_per_forward"] for r in rows) / us, 4)
         rf["mfma_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) and GRBM_GUI_ACTIVE / 8 / duration of the same kernel "
-                           "(profiles/r3_pmc_mfma%s.csv, separate rocprofv3 --pmc passes on kernel sources %s = this build; profiled dispatches are "
+                           "(profiles/" + mtag + "_pmc_mfma%s.csv, separate rocprofv3 --pmc passes on kernel sources %s = this build; profiled dispatches are "
                            "serialised and clock 2-5 %% differently from the un-profiled run; the in-kernel s_memtime / s_memrealtime clock of the "
                            "same kernel is in profiles/r3_clock_stamps.txt)" % (sfx, sha))
 

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "igemm_conv.h"
+#include "gemm_tail.h"
 
 namespace bsr {
 
@@ -43,22 +44,11 @@ static_assert(66 * 64 * 4 <= 4 * kAttStageFloats, "merge scratch fits the stagin
 // through LDS into the A-fragment layout (never to HBM), and the two key-stream wave groups take the channel tiles [0,5) / [5,9) of
 // N = 288 with the weight images of both streaming through one 3-slot LDS ring — the same MFMA order per output element as
 // gemm_nloop_kernel (bit-identical results), one launch, one prologue and 17 MB of HBM round trip less per block.
-struct AttWArgs {
-  const float* w;       // packed [4][1][n_pad][36] (pack.py: res{i}.w), n_pad >= 12 * 32
-  const float* bias;    // [n_pad]
-  int n_pad;
-  const float* res;     // y3x: conv3 output + block input, NHWC at the trunk resolution, channels [0, res_c)
-  int res_cs, res_c;
-  float* out;           // block output, channel stride out_cs, channels [0, n_store) written
-  int out_cs, n_store;
-  int act;              // 1: LeakyReLU(0.3)
-};
-constexpr int kAttWSlot = 2 * 96 * 36;                         // floats per ring slot: the (3 tiles x 36-word rows) images of BOTH wave groups
-constexpr int kAttWAttFloats = 128 * kAttLdK;                  // normalised attention output of the workgroup, [query][D + 4]
-constexpr int kAttWSmemFloats = kAttWAttFloats + 3 * kAttWSlot + 12 * 32;
-constexpr int kAttWSmemBytes = kAttWSmemFloats * 4;
+typedef GemmTailArgs AttWArgs;                               // the fused `w` GEMM: gemm_tail.h, channel tiles [0,5) | [5,9) of N = 288
+typedef GemmTailCfg<5, 4> AttWCfg;
+constexpr int kAttWSmemBytes = AttWCfg::SMEM_FLOATS * 4;
 static_assert(kAttWSmemBytes <= 160 * 1024 && kAttWSmemBytes >= kAttSmemBytes, "LDS budget of the fused tail");
-static_assert(4 * 66 * 64 <= kAttWAttFloats, "the merge scratch sits under the attention tile, clear of the weight ring");
+static_assert(4 * 66 * 64 <= kTailAFloats && kTailLdA == kAttLdK, "the merge scratch sits under the attention tile, clear of the weight ring");
 
 template <int QW, bool FUSEW = false>
 __global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens, AttWArgs wa) {
@@ -215,37 +205,10 @@ __global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_
   __syncthreads();
   // FUSEW: the staging buffers are dead from here on; the weight images of GEMM steps 0 and 1 and the bias are requested now, by all
   // eight waves, so that their latency hides behind the merge (ring and bias live ABOVE the merge scratch / attention tile)
-  [[maybe_unused]] float* s_ring = smem + kAttWAttFloats;
-  [[maybe_unused]] float* s_bias = s_ring + 3 * kAttWSlot;
-  constexpr int WPT = 4;                                       // float4 per thread and ring slot: 2 x 864 images over 512 threads (the surplus re-copies)
-  [[maybe_unused]] unsigned w_voff[WPT], w_loff[WPT];
-  [[maybe_unused]] f32x4 w_regs[WPT], w_regs1[WPT];
-  [[maybe_unused]] __amdgpu_buffer_rsrc_t w_rsrc;
-  auto fetch_w = [&](int s, f32x4 (&regs)[WPT]) {              // GEMM step s = (channel group, K chunk); both wave groups' images
-    const int ng = s >> 2, ch = s & 3;
-    const unsigned soff = (unsigned)((ch * wa.n_pad + ng * 96) * 36 * 4);
-#pragma unroll
-    for (int i = 0; i < WPT; ++i)
-      regs[i] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], soff, 0));
-  };
-  auto store_w = [&](int slot_floats, const f32x4 (&regs)[WPT]) {
-    char* dst = reinterpret_cast<char*>(s_ring + slot_floats);
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(dst + w_loff[i]) = regs[i];
-  };
-  if constexpr (FUSEW) {
-    w_rsrc = make_rsrc(wa.w);
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = (tid + i * NT) % (2 * 864);                // float4 index inside a slot: image of group 0 | image of group 1
-      const int sub = e / 864, within = e % 864;
-      w_voff[i] = (unsigned)(within * 16 + sub * (5 * 32 * 36 * 4));      // group 1's tiles start 5 tiles (160 channel rows) after group 0's
-      w_loff[i] = (unsigned)(e * 16);
-    }
-    fetch_w(0, w_regs);
-    fetch_w(1, w_regs1);
-    for (int i = tid; i < 12 * 32; i += NT) s_bias[i] = wa.bias[i];
-  }
+  [[maybe_unused]] float* s_ring = smem + kTailAFloats;
+  [[maybe_unused]] float* s_bias = s_ring + 3 * kTailSlot;
+  [[maybe_unused]] GemmTailState<5, 4> tail;
+  if constexpr (FUSEW) gemm_tail_prefetch(tail, wa, s_bias, tid);
   float* sx = smem + (size_t)wq * 66 * 64 + lane;
   if (grp == 1) {
     sx[0] = m_run;
@@ -284,11 +247,11 @@ __global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_
       *reinterpret_cast<f32x4*>(orow + 4 * row) = v;
     }
   } else {
-    // ---- the `w` GEMM tail (gemm_nloop_kernel<3, 4> with the activation tile coming from registers instead of HBM) ----
+    // ---- the `w` GEMM tail (gemm_tail.h: gemm_nloop_kernel<3, 4> with the activation tile coming through LDS instead of HBM) ----
     __syncthreads();                                           // every read of the merge scratch is done: the attention tile may overwrite it
-    float* s_att = smem;                                       // [128 queries][kAttLdK]
+    float* s_att = smem;                                       // [128 queries][kTailLdA]
     if (grp == 0) {
-      float* arow = s_att + (wq * 32 + r) * kAttLdK;
+      float* arow = s_att + (wq * 32 + r) * kTailLdA;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -296,102 +259,8 @@ __global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_
         *reinterpret_cast<f32x4*>(arow + 4 * row) = v;
       }
     }
-    store_w(0, w_regs);
-    store_w(kAttWSlot, w_regs1);
-    __syncthreads();
-    constexpr int NI = 3, NCH = 4, G = 4, LDP = 36, NSTEPS = 2 * NCH;
-    f32x4 afr[NCH * G];                                        // this lane's pixel (query wq*32 + r), channels 8g + 4h .. +3
-#pragma unroll
-    for (int g = 0; g < NCH * G; ++g) afr[g] = *reinterpret_cast<const f32x4*>(s_att + (wq * 32 + r) * kAttLdK + g * 8 + 4 * h);
-    const int t0 = grp ? 5 : 0, t1 = grp ? 9 : 5;              // this wave group's channel tiles of N = 288
-    int b_base[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b_base[ni] = grp * (96 * LDP) + (ni * 32 + r) * LDP + 4 * h;
-    int w_cur = 0, w_n1 = kAttWSlot, w_n2 = 2 * kAttWSlot;
-    f32x4 bf[2][NI];
-    auto read_frags = [&](int slot, int b_off) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_ring + b_base[ni] + b_off);
-    };
-    read_frags(0, w_cur);
-    const float act_alpha = wa.act ? kLeakyAlpha : 1.f;
     const size_t tile_pix = (size_t)img * tokens + (size_t)qb * 128 + (size_t)__builtin_amdgcn_readfirstlane(wq) * 32;
-    const unsigned lane_out = ((unsigned)(4 * h) * (unsigned)wa.out_cs + (unsigned)r) * 4u;
-    const unsigned lane_res = (unsigned)(4 * h) * (unsigned)wa.res_cs * 4u;
-    const __amdgpu_buffer_rsrc_t rsrc_out = make_rsrc(wa.out + tile_pix * wa.out_cs);
-    const __amdgpu_buffer_rsrc_t rsrc_res = make_rsrc(wa.res + tile_pix * wa.res_cs);
-    for (int ng = 0; ng < 2; ++ng) {
-      const int tg = t0 + ng * NI;
-      const int nvalid = min(NI, t1 - tg);                     // 3 | 2 (group 0), 3 | 1 (group 1)
-      f32x16 acc[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[ni] = bias_tile(h, s_bias[(tg + ni) * 32 + r]);
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) {
-        const int s_ = ng * NCH + ch;
-        const bool has1 = s_ + 1 < NSTEPS, has2 = s_ + 2 < NSTEPS;
-        if (has2) fetch_w(s_ + 2, w_regs);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const int cur = g & 1, nxt = cur ^ 1;
-          if (g + 1 < G) {
-            read_frags(nxt, w_cur + (g + 1) * 8);
-          } else if (has1) {
-            read_frags(nxt, w_n1);
-          }
-          if (g == G - 1 && has2) store_w(w_n2, w_regs);
-          __builtin_amdgcn_sched_barrier(0);
-          const f32x4 a = afr[ch * G + g];
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            if (ni < nvalid) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[cur][ni][j], acc[ni], 0, 0, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = tw;
-      }
-      // epilogue of this channel group: residual (y3x) + LeakyReLU, NHWC store — gemm_nloop_kernel's, one destination
-      __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        if (ni >= nvalid) continue;
-        const int nt = (tg + ni) * 32;
-        const int n = nt + r;
-        f32x16 v = acc[ni];
-        if (nt < wa.res_c) {
-          const unsigned rcs4 = (unsigned)wa.res_cs * 4u;
-          const unsigned l1 = n < wa.res_c ? lane_res + (unsigned)r * 4u : kLaneOff;
-          const unsigned lj[4] = {l1, l1 + rcs4, l1 + 2u * rcs4, l1 + 3u * rcs4};
-          float r1[16];
-          unsigned so = (unsigned)nt * 4u;
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r1[4 * q4 + j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_res, lj[j], so, 0));
-            so += 8u * rcs4;
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] += r1[i];
-        }
-        leaky_relu_tile(v, act_alpha);
-        const unsigned vb = n < wa.n_store ? lane_out : kLaneOff;
-        const unsigned cs4 = (unsigned)wa.out_cs * 4u;
-        const unsigned vj[4] = {vb, vb + cs4, vb + 2u * cs4, vb + 3u * cs4};
-        unsigned so = (unsigned)nt * 4u;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[4 * q4 + j]), rsrc_out, vj[j], so, 0);
-          so += 8u * cs4;
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-    }
+    gemm_tail_run(tail, wa, s_att, s_ring, s_bias, grp, wq, tile_pix, lane);
   }
 }
 
@@ -425,7 +294,7 @@ inline int attention_auto_qw(int batch, int tokens) {
 
 // attention + `w` GEMM tail in one launch (the 8-wave shape; callers use it when attention_auto_qw() == 4)
 inline hipError_t launch_nonlocal_attention_w(const float* qkv, int batch, int tokens, const AttWArgs& wa, hipStream_t stream) {
-  if (tokens % (4 * kAttKT) != 0 || wa.n_pad < 12 * 32 || wa.n_store > 288 || wa.res_c > 288) return hipErrorInvalidValue;
+  if (tokens % (4 * kAttKT) != 0 || wa.n_pad * 32 < AttWCfg::BIAS_FLOATS * 32 || wa.n_pad < 12 * 32 || wa.n_store > 288 || wa.res_c > 288 || wa.out2 != nullptr) return hipErrorInvalidValue;
   auto kern = nonlocal_attention_kernel<4, true>;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();

@@ -147,7 +147,10 @@ struct bsr_handle {
   // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
   unsigned* range_flag = nullptr;
   bool fuse_heads = true;        // env BSR_FUSE_HEADS=0: always the two-launch heads (A/B measurements, bit-identity tests)
-  bool exp_half_tile = false, exp_c3q_ni4 = false;      // experiments (env BSR_EXP_HALF_TILE / BSR_EXP_C3Q_NI4): measured and left off, see profiles/README.md
+  bool tail_stagger = true;      // env BSR_TAIL_STAGGER=0: both wave groups of a fused GEMM tail walk their channel groups in the same order
+  bool fuse_c3q = false;         // env BSR_FUSE_C3Q=1: res*.conv2 with the conv3 | theta|phi|g GEMM as its tail (one launch).  Built, bit-identical, and
+                                 // OFF: one forward at a time it is 0.2 % faster, with two forwards in flight 0.8 % slower (its 150-KB, 8-wave workgroups
+                                 // leave the other lane's kernels no room on the CU) — profiles/HISTORY.md, round 4
   bool fuse_attw = true;         // env BSR_FUSE_ATTW=0: attention and the `w` GEMM as two launches (A/B measurements, bit-identity tests)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
@@ -256,7 +259,7 @@ struct Launcher {
     // order: bit-identical) doubles the grid.
     constexpr bool kTrunk = !TR && S == 1 && NI == 2 && (CC == 32 || (k11 && CC == 24));
     bool half_tile = false;
-    if constexpr (kTrunk) half_tile = !h16 && mh % 2 == 0 && ((long long)(mh / 4) * (mw / 32) * h->B * nb < bsr::device_cu_count() || h->exp_half_tile);
+    if constexpr (kTrunk) half_tile = !h16 && mh % 2 == 0 && (long long)(mh / 4) * (mw / 32) * h->B * nb < bsr::device_cu_count();
     if (half_tile) {
       if constexpr (kTrunk) check(bsr::launch_igemm_conv<KH, KW, S, TR, 2, 32, 2, 2, 1, 1, CC, INB>(a, h->B, s), name);
     } else if (!h16)
@@ -269,6 +272,27 @@ struct Launcher {
       else if (io == 1) check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1, 1>(a, h->B, s), name);
       else check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1, 0>(a, h->B, s), name);
     }
+    end();
+  }
+  // res*.conv2 (3x3, 128 -> 128, + BN + LeakyReLU) with the conv3 | theta|phi|g GEMM (K = 128, N = 288 + 384, + the block skip) as its tail:
+  // one 8-wave workgroup per 4x32-pixel tile computes all 128 channels and runs the GEMM on them (igemm_conv.h FUSE_TAIL, gemm_tail.h)
+  void conv2_c3q(const char* name, const char* conv_name, const char* gemm_name, const float* in, int H, int W, float* y3, float* qkv,
+                 const float* x, int x_cs) {
+    if (rc != BSR_OK) return;
+    LayerW lc, lg;
+    rc = find_layer(h, conv_name, 4, 9, 36, 128, &lc);
+    if (rc == BSR_OK) rc = find_layer(h, gemm_name, 4, 1, 36, bsr::ConvTailCfg::BIAS_FLOATS, &lg);
+    if (rc != BSR_OK) return;
+    bsr::ConvArgs a{};
+    a.in = in; a.in_cs = 128; a.in_coff = 0; a.H = H; a.W = W; a.out = nullptr; a.out_cs = 128; a.out_coff = 0; a.Ho = H; a.Wo = W;
+    a.w = lc.w; a.bias = lc.b; a.nchunk = lc.nchunk; a.n_pad = lc.n_pad; a.n_store = 128; a.pad_t = 1; a.pad_l = 1; a.act = 1;
+    bsr::GemmTailArgs t{};
+    t.w = lg.w; t.bias = lg.b; t.n_pad = lg.n_pad;
+    t.res = x; t.res_cs = x_cs; t.res_c = x_cs < 288 ? x_cs : 288;
+    t.out = y3; t.out_cs = CS_Y3X; t.n_store1 = CS_Y3X;
+    t.out2 = qkv; t.out2_cs = 384; t.n_split = 288; t.n_store = 288 + 384; t.act = 0; t.stagger = h->tail_stagger ? 1 : 0;
+    begin(K_CONV3, name);
+    check(bsr::launch_igemm_conv<3, 3, 1, false, 4, 32, 4, 2, 1, 2, 32, 1, true>(a, h->B, s, &t), name);
     end();
   }
   // 1x1 conv as a resident-activation GEMM (K = NCH*32) over all N
@@ -432,8 +456,8 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   h->dtype = dtype;
   if (const char* e_ = getenv("BSR_FUSE_HEADS")) h->fuse_heads = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_FUSE_ATTW")) h->fuse_attw = atoi(e_) != 0;
-  if (const char* e_ = getenv("BSR_EXP_HALF_TILE")) h->exp_half_tile = atoi(e_) != 0;
-  if (const char* e_ = getenv("BSR_EXP_C3Q_NI4")) h->exp_c3q_ni4 = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_FUSE_C3Q")) h->fuse_c3q = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_TAIL_STAGGER")) h->tail_stagger = atoi(e_) != 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -651,16 +675,25 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     float* y3 = ws + p.y3[i];
     snprintf(nm, sizeof nm, "res%d.conv1", i);
     L.conv<1, 1, 1, false, 2, 24, 3>(K_CONV1, nm, x, x_cs, 0, x_cs, H8, W8, ws + p.t1, 128, 0, 128, 1);
-    snprintf(nm, sizeof nm, "res%d.conv2", i);
-    L.conv<3, 3, 1, false, 2, 32, 1>(K_CONV3, nm, ws + p.t1, 128, 0, 128, H8, W8, ws + p.t2, 128, 0, 128, 1);
-    // conv3+BN (128 -> 257 = y3) and theta|phi|g (257 -> 3x128, no activation in between: model.py:101,33-46) as ONE
-    // K = 128 GEMM: the qkv weights are composed offline with conv3's (pack.py), N = [y3 288 | qkv 384]
-    snprintf(nm, sizeof nm, "res%d.c3q", i);
-    // The y3 output also absorbs the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
-    if (h->exp_c3q_ni4)
-      L.gemm<4, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
-    else
-    L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
+    // conv3+BN (128 -> 257 = y3) and theta|phi|g (257 -> 3x128, no activation in between: model.py:101,33-46) are ONE
+    // K = 128 GEMM: the qkv weights are composed offline with conv3's (pack.py), N = [y3 288 | qkv 384].  The y3 output also absorbs
+    // the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
+    // Opt-in (BSR_FUSE_C3Q=1; fp32, full batches): conv2 and that GEMM as ONE launch — the conv2 tile goes through LDS, never to HBM
+    // (igemm_conv.h FUSE_TAIL).  Same bits either way; see the note at bsr_handle::fuse_c3q for why it is off.
+    const bool fuse_c3q = h->dtype == BSR_DTYPE_F32 && h->fuse_c3q && H8 % 4 == 0 && W8 % 32 == 0 &&
+                          (long long)(H8 / 4) * (W8 / 32) * B >= bsr::device_cu_count();
+    if (fuse_c3q) {
+      char nc[32], ng[32];
+      snprintf(nm, sizeof nm, "res%d.c2c3q", i);
+      snprintf(nc, sizeof nc, "res%d.conv2", i);
+      snprintf(ng, sizeof ng, "res%d.c3q", i);
+      L.conv2_c3q(nm, nc, ng, ws + p.t1, H8, W8, y3, ws + p.qkv, x, x_cs);
+    } else {
+      snprintf(nm, sizeof nm, "res%d.conv2", i);
+      L.conv<3, 3, 1, false, 2, 32, 1>(K_CONV3, nm, ws + p.t1, 128, 0, 128, H8, W8, ws + p.t2, 128, 0, 128, 1);
+      snprintf(nm, sizeof nm, "res%d.c3q", i);
+      L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
+    }
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att))).
     // fp32, full batches: ONE launch — the `w` GEMM runs as the tail of the attention kernel on the workgroup's own 128 pixels
     // (attention.h, FUSEW; the attention output never goes to HBM).  Small batches (the 4- / 2-wave attention shapes) and the 16-bit
@@ -674,7 +707,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
         bsr::AttWArgs wa{};
         wa.w = l.w; wa.bias = l.b; wa.n_pad = l.n_pad;
         wa.res = y3; wa.res_cs = CS_Y3X; wa.res_c = CS_Y3X;
-        wa.out = r_out; wa.out_cs = o_cs; wa.n_store = o_cs < 288 ? o_cs : 288; wa.act = 1;
+        wa.out = r_out; wa.out_cs = o_cs; wa.n_store = o_cs < 288 ? o_cs : 288; wa.n_store1 = wa.n_store; wa.act = 1; wa.stagger = h->tail_stagger ? 1 : 0;
         snprintf(nm, sizeof nm, "res%d.attw", i);
         L.begin(K_ATT, nm);
         L.check(bsr::launch_nonlocal_attention_w(ws + p.qkv, B, H8 * W8, wa, s), "attention+w");

@@ -24,114 +24,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef BSR_PAIR_S2
-#define BSR_PAIR_S2 1
-#endif
+#include "mfma_common.h"
+#include "gemm_tail.h"
 
 
 namespace bsr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr float kLeakyAlpha = 0.3f;   // tf.keras.layers.LeakyReLU default (/root/reference/model.py:130,161)
-
-// LeakyReLU(0.3) = max(x, 0.3 x).  fmaxf() costs three VALU instructions per element under the default IEEE mode (multiply,
-// a canonicalising v_max x,x, the v_max); as the median of {x, 0.3x, FLT_MAX} it is one v_med3_f32, and the multiply of a
-// register pair is one v_pk_mul_f32.  (No inline asm: the hazard recogniser must see these instructions next to MFMAs.)
-// VALU time in an epilogue is not hidden: it runs beside a co-resident wave's MFMA stream and is starved by it.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 leaky_relu2(f32x2 x) {
-  const f32x2 t = x * kLeakyAlpha;
-  return f32x2{__builtin_amdgcn_fmed3f(x[0], t[0], 3.4028234664e38f), __builtin_amdgcn_fmed3f(x[1], t[1], 3.4028234664e38f)};
-}
-__device__ __forceinline__ float leaky_relu(float x) { return __builtin_amdgcn_fmed3f(x, x * kLeakyAlpha, 3.4028234664e38f); }
-// A whole accumulator tile: the eight packed multiplies first, then the sixteen medians (a median right behind the multiply it reads
-// costs a wait state — an s_nop, i.e. one more issue slot — each time).  alpha = 1 turns the activation off without a branch
-// (median of {x, x, FLT_MAX} = x).
-__device__ __forceinline__ void leaky_relu_tile(f32x16& v, float alpha) {
-  f32x2 t[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] = f32x2{v[2 * i], v[2 * i + 1]} * alpha;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v[2 * i] = __builtin_amdgcn_fmed3f(v[2 * i], t[i][0], 3.4028234664e38f);
-    v[2 * i + 1] = __builtin_amdgcn_fmed3f(v[2 * i + 1], t[i][1], 3.4028234664e38f);
-  }
-}
-// A 32x32 accumulator tile whose rows all hold the bias of its 32 output channels (register i of lane l = bias[l & 31]), produced by
-// ONE matrix instruction instead of 16 v_mov_b32: A = [1 | 0] (the k = 0 column all ones: lanes 0-31 supply 1, lanes 32-63 supply 0),
-// B row 0 = bias, row 1 = 0, C = 0 -> acc[m][n] = 1 * bias[n] + 0 * 0 + 0 = bias[n] exactly.  Beside a co-resident wave's MFMA stream
-// a VALU instruction waits for a matrix instruction to drain every time; the 128 moves of a transposed-conv tile were 2-3 k cycles of
-// every workgroup's prologue (and of every channel group of gemm_nloop, there at priority 0), eight matrix instructions are ~0.5 k.
-__device__ __forceinline__ f32x16 bias_tile(int h, float bias_col) {
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float one = h ? 0.f : 1.f;
-  asm volatile("" : "+v"(one));        // an empty statement, only to keep the compiler from computing ONE tile and copying it (v_mov) to the others
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(one, h ? 0.f : bias_col, zero, 0, 0, 0);
-}
-// Epilogue addressing through a raw buffer resource: buffer_store_dword v_data, v_lane_off, s[rsrc], s_uniform_off offen.
-// The wave-uniform part of an element's address is a 32-bit SGPR byte offset from a per-workgroup base, the per-lane part one
-// constant VGPR: no vector address arithmetic at all per element, and a lane whose offset has bit 31 set falls outside
-// num_records and is dropped by the hardware (masking without touching exec).
-constexpr unsigned kLaneOff = 0x80000000u;          // voffset of a lane that must not store / load
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);   // raw, stride 0, 2 GiB window
-}
-
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are PER DEVICE: launchers keep their one-time state per
-// device ordinal, so one process may hold handles on several GPUs (the deployment rule stays one process per GPU).
-constexpr int kMaxDevices = 64;
-struct PerDeviceOnce {
-  bool done[kMaxDevices] = {};
-  int value[kMaxDevices] = {};
-  // returns the current device ordinal, or -1 (never cached) when it is out of range / unknown
-  static int current() {
-    int d = -1;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return -1;
-    return d;
-  }
-};
-
-// compute units of the current device (cached per device ordinal; 256 on MI355X) — launchers that pick a tile size by the grid it gives
-inline int device_cu_count() {
-  static PerDeviceOnce once;
-  const int dev = PerDeviceOnce::current();
-  if (dev >= 0 && once.done[dev]) return once.value[dev];
-  int cur = 0, cus = 0;
-  if (hipGetDevice(&cur) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur) != hipSuccess || cus <= 0) return 256;
-  if (dev >= 0) { once.value[dev] = cus; once.done[dev] = true; }
-  return cus;
-}
-
-struct ConvArgs {
-  const float* in;      // NHWC activations, channel stride in_cs, first channel in_coff
-  int in_cs, in_coff;
-  int H, W;             // input spatial size per image
-  float* out;           // NHWC, channel stride out_cs, first channel out_coff
-  int out_cs, out_coff;
-  int Ho, Wo;           // output spatial size per image
-  const float* w;       // packed [nchunk][T][n_pad][CC+4]
-  const float* bias;    // [n_pad]
-  int nchunk, n_pad;
-  int n_store;          // channels [0, n_store) are written
-  int pad_t, pad_l;     // TF SAME pad-before (rows, cols); unused for transposed
-  int act;              // 1: LeakyReLU(0.3)
-  // --- used by gemm_nloop_kernel only ---
-  float* out2;          // optional second destination: channels [n_split, n_store) go to out2[.., n - n_split]
-  int out2_cs, n_split; // (n_split is a multiple of 32; channels [n_store1, n_split) of the first range are dropped)
-  int n_store1;         // with out2: channels [0, n_store1) go to `out`
-  const float* res1;    // optional residual, NHWC at the output resolution, added before the activation
-  int res1_cs, res1_c;  // channel stride; channels [0,res1_c) are read
-  int tiles_x, tiles_y; // M tiles per image
-  int n_blocks;         // igemm_h16_kernel: > 0 = 1-D grid with the N block as the FASTEST index (the N blocks of a tile share its input through L2)
-  unsigned* range_flag; // 16-bit kernels: set to 1 when a staged activation does not fit fp16 (|x| >= 65520); may be null
-#ifdef BSR_STAMPS
-  unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
-  unsigned long long* stamps3;  // diagnostic build only: where the prologue's cycles go, [block][wave][6] = entry, addresses set up, loads issued, loads landed + LDS written, barrier passed, accumulators + first fragments ready
-  unsigned long long* stamps2;  // diagnostic build only: per-step timeline of 64 mid-kernel workgroups (1024 .. 1087): [block][wave][step][3] = step start, matrix work done, barrier passed
-#endif
-};
 
 // INB = number of LDS input-tile buffers: 1 (reload synchronously at chunk boundaries), 2 (taps > 1: next chunk's
 // tile is staged one tap ahead) or 3 (1x1 convs: ring, like the weights).
@@ -175,9 +72,17 @@ struct ConvCfg {
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
-__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p) {
+// FUSE_TAIL (round 4; the 8-wave 3x3 shape WM = 4, WN = 2, NI = 2: one workgroup = a 4x32-pixel tile x ALL 128 output channels):
+// the layer's output tile does not go to HBM — after bias + LeakyReLU it is written to LDS and becomes the activation tile of a
+// K = 128 GEMM that runs as the tail of this kernel (gemm_tail.h).  res*.conv2 followed by conv3 | theta|phi|g
+// (/root/reference/model.py:85-86,100-101,10-13) is ONE launch that way.
+typedef GemmTailCfg<11, 10> ConvTailCfg;                       // N = 288 + 384 = 21 channel tiles: wave group 0 takes [0, 11), group 1 [11, 21)
+
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, bool FUSE_TAIL = false>
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p, GemmTailArgs ta) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
+  static_assert(!FUSE_TAIL || (!TR && S == 1 && WM == 4 && WN == 2 && MI == 1 && NI == 2 && TH == 4 && TW == 32),
+                "the fused GEMM tail needs the whole 128-pixel x 128-channel tile in one 8-wave workgroup");
   constexpr bool PAIR = C::PAIR;
   constexpr int NT = C::NT;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH, G = C::G;
@@ -196,7 +101,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // tells the compiler the wave index is uniform: SGPR address math
   const int h = lane >> 5, r = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
+  // FUSE_TAIL: waves w and w + 4 share a SIMD; giving them DIFFERENT channel halves (wn) puts them into different wave groups of the
+  // GEMM tail, whose schedules are staggered against each other (gemm_tail.h)
+  const int wm = FUSE_TAIL ? wave % WM : wave / WN, wn = FUSE_TAIL ? wave / WM : wave % WN;
 
   int bid = blockIdx.x;
   const int tile_x = bid % p.tiles_x;
@@ -500,6 +407,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
 #ifdef BSR_STAMPS
   st2 = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (FUSE_TAIL) {
+    // The main loop's last barrier has passed: every LDS byte of this kernel is dead.  Request the tail's first weight images, park
+    // the activation tile (bias is already in the accumulators; LeakyReLU here) as [pixel][128 + 4], and run the GEMM on it.
+    float* s_a = smem;
+    float* s_ring = smem + kTailAFloats;
+    float* s_bias = s_ring + 3 * kTailSlot;
+    GemmTailState<11, 10> tail;
+    gemm_tail_prefetch(tail, ta, s_bias, tid);
+    const float alpha = p.act ? kLeakyAlpha : 1.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      f32x16 v = acc[0][0][ni];
+      leaky_relu_tile(v, alpha);
+      float* col = s_a + (wm * 32 + 4 * h) * kTailLdA + (wn * NI + ni) * 32 + r;      // register i = pixel (i & 3) + 8 (i >> 2) + 4 h of the wave's row, channel r of tile ni
+#pragma unroll
+      for (int i = 0; i < 16; ++i) col[((i & 3) + 8 * (i >> 2)) * kTailLdA] = v[i];
+    }
+    __builtin_amdgcn_s_setprio(0);
+    const size_t row_pix = (size_t)img * p.Ho * p.Wo + (size_t)(y0 + wm) * p.Wo + x0;      // the wave's 32 consecutive output pixels
+    gemm_tail_run(tail, ta, s_a, s_ring, s_bias, wn, wm, row_pix, lane);
+    return;
+  }
   // ---- epilogue: bias (+ residuals) + LeakyReLU, NHWC store (32 consecutive channels per half-wave) ----
   // With TW == 32 a wave's 32 pixels are one tile row, so every element address is a wave-uniform base plus a
   // 32-bit lane offset plus a compile-time multiple of the pixel stride: no 64-bit per-element arithmetic.
@@ -563,14 +492,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p)
 #endif
 }
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
-inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream) {
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, bool FUSE_TAIL = false>
+inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream, const GemmTailArgs* tail = nullptr) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
-  auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
+  auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, FUSE_TAIL>;
+  constexpr int kSmem = FUSE_TAIL && ConvTailCfg::SMEM_FLOATS * 4 > C::SMEM_BYTES ? ConvTailCfg::SMEM_FLOATS * 4 : C::SMEM_BYTES;
+  static_assert(kSmem <= 160 * 1024, "LDS budget");
+  if (FUSE_TAIL && (tail == nullptr || a.n_store != C::BN || tail->n_pad * 32 < ConvTailCfg::BIAS_FLOATS * 32 || tail->n_store > 21 * 32)) return hipErrorInvalidValue;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
-  if (C::SMEM_BYTES > 48 * 1024 && (dev < 0 || !once.done[dev])) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
+  if (kSmem > 48 * 1024 && (dev < 0 || !once.done[dev])) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
@@ -578,7 +510,7 @@ inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream) {
   a.tiles_x = mw / TW;
   a.tiles_y = mh / TH;
   dim3 grid(a.tiles_x * a.tiles_y * batch, (a.n_store + C::BN - 1) / C::BN);
-  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::SMEM_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NT), kSmem, stream, a, tail != nullptr ? *tail : GemmTailArgs{});
   return hipGetLastError();
 }
 

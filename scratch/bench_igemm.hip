@@ -49,7 +49,7 @@ int run(const char* name, int B, int H, int W, int Cin, int Cout) {
       CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
       ConvArgs b = a;
       b.tiles_x = mw / 32; b.tiles_y = mh / 4;
-      hipLaunchKernelGGL(kern, dim3(b.tiles_x * b.tiles_y * B, (Cout + C::BN - 1) / C::BN), dim3(C::NT), smem, 0, b);
+      hipLaunchKernelGGL(kern, dim3(b.tiles_x * b.tiles_y * B, (Cout + C::BN - 1) / C::BN), dim3(C::NT), smem, 0, b, GemmTailArgs{});
       CK(hipGetLastError());
     } else
     CK((launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, WN, 1, NI, CC, INB>(a, B, 0)));

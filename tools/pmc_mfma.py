@@ -43,7 +43,7 @@ def short(name: str) -> str:
     import re
     for a in ("void bsr::", "bsr::", "(bsr::ConvArgs)", "(ConvArgs)", "(bsr::ConvN16Args)", "(ConvN16Args)", "(bsr::StemArgs)", "(StemArgs)"):
         name = name.replace(a, "")
-    return re.sub(r"\((float|bsr::|unsigned|int|void).*", "", name)
+    return re.sub(r"\((ConvArgs|ConvN16Args|StemArgs|float|bsr::|unsigned|int|void).*", "", name)
 
 
 def load_pass(d):

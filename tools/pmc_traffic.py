@@ -42,8 +42,7 @@ def load(d, name):
     ids = sorted(c["Dispatch_Id"].unique())
     assert len(ids) % 2 == 0, "expected exactly two forwards"
     c = c[c["Dispatch_Id"].isin(ids[len(ids) // 2:])].copy()            # the second forward
-    c["kernel"] = (c["Kernel_Name"].str.replace("void bsr::", "").str.replace("bsr::", "").str.replace("(bsr::ConvArgs)", "").str.replace("(ConvArgs)", "")
-                   .str.replace("(bsr::ConvN16Args)", "").str.replace("(ConvN16Args)", "").str.replace("(bsr::StemArgs)", "").str.replace("(StemArgs)", "")
+    c["kernel"] = (c["Kernel_Name"].str.replace("void bsr::", "").str.replace("bsr::", "").str.replace(r"\((bsr::)?(Conv|ConvN16|Stem)Args.*\)$", "", regex=True)
                    .str.replace(r"\(float const\*.*", "", regex=True))
     return c.groupby("kernel")["Counter_Value"].agg(["sum", "count"])
 

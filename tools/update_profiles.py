@@ -24,7 +24,7 @@ b = json.load(open(os.path.join(ROOT, bench_json)))
 nfwd = b["steps"] + b["warmup"] + 3
 d = pd.read_csv(stats)
 d = d[d["Name"].str.contains("bsr::")].copy()
-d["kernel"] = (d["Name"].str.replace("void bsr::", "").str.replace("bsr::", "").str.replace(r"\((Conv|ConvN16|Stem)Args\)", "", regex=True)
+d["kernel"] = (d["Name"].str.replace("void bsr::", "").str.replace("bsr::", "").str.replace(r"\((Conv|ConvN16|Stem)Args.*\)$", "", regex=True)
                .str.replace(r"\(float const\*.*", "", regex=True))
 d["launches/fwd"] = (d["Calls"] / nfwd).round(2)
 d["avg us"] = (d["AverageNs"] / 1000).round(1)
