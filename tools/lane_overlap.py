@@ -43,7 +43,7 @@ if len(per_q) > 1:                                   # inside the window in whic
     w = hi - lo
     print("while queue %s is in use (%.1f ms): >= 2 kernels resident %.1f %% of the time, exactly 1 %.1f %%, none %.1f %%" % (
         q2, w / 1e6, 100.0 * sum(v for k, v in b2.items() if k >= 2) / w, 100.0 * b2.get(1, 0) / w, 100.0 * b2.get(0, 0) / w))
-dom = t[t["Kernel_Name"].str.contains("igemm_conv_kernel<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32, 1>")]
+dom = t[t["Kernel_Name"].str.contains("igemm_conv_kernel<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32, 1")]
 dur = (dom["End_Timestamp"] - dom["Start_Timestamp"]) / 1e3
 print("dominant kernel: %d launches, duration min %.0f / median %.0f / max %.0f us (alone: ~410 us; longer = it shared the chip with the other forward's kernels)" % (
     len(dom), dur.min(), dur.median(), dur.max()))
