@@ -379,7 +379,21 @@ def test_per_launch_timing_names_every_layer(gen_w):
     assert all(ms > 0 for _, ms, _ in entries)
     assert abs(sum(bench.LAYER_MMAC.values()) - 9052.06) < 1.0          # SURVEY Appendix C total
     grouped = [n for layers in bench.KERNEL_GROUPS.values() for n in layers]
-    assert sorted(grouped) == sorted(bench.LAYER_MMAC)
+    assert sorted(grouped) == sorted(list(bench.LAYER_MMAC) + list(bench.FUSED_LAUNCHES))
+    # a full batch: some layers run as the tail of another launch (round 4) — every reference layer is still covered exactly once,
+    # directly or through the fused launch that names it, and bench.py can price every launch
+    t32 = torch.rand(32, 256, 256, 3).cuda()
+    gen.set_timing(True)
+    gen(t32, t32)
+    torch.cuda.synchronize()
+    names32 = [n for n, _, _ in gen.get_launch_timing()]
+    gen.set_timing(False)
+    covered = []
+    for n in names32:
+        covered += list(bench.FUSED_LAUNCHES.get(n, (n,) if n in bench.LAYER_MMAC else ()))
+    assert sorted(covered) == sorted(bench.LAYER_MMAC), sorted(set(bench.LAYER_MMAC) ^ set(covered))
+    if gen.dtype == "f32":
+        assert "res0.attw" in names32
 
 
 def test_handle_lifecycle_returns_its_memory():

@@ -33,6 +33,14 @@ for q, r in per_q.iterrows():
 if len(per_q) > 1:                                   # inside the window in which the second queue is in use (the warm-up + timed region of --streams 2)
     q2 = per_q.sort_values("n").index[0]
     lo, hi = per_q.loc[q2, "first"], per_q.loc[q2, "last"]
+    # the second queue is used again late in the run (round 4: the event-timed two-lane forwards of `roofline_in_flight`): the window is
+    # its FIRST busy period — warm-up + timed region — which ends where the queue then stays idle for more than 5 ms (the single-stream region)
+    tq = t[t["Queue_Id"] == q2].sort_values("Start_Timestamp")
+    starts, ends = tq["Start_Timestamp"].tolist(), tq["End_Timestamp"].tolist()
+    for i in range(1, len(starts)):
+        if starts[i] - ends[i - 1] > 5e6:
+            hi = ends[i - 1]
+            break
     active, last, b2 = 0, ev[0][0], {}
     for ts, dlt in ev:
         a, c = max(last, lo), min(ts, hi)
@@ -44,6 +52,8 @@ if len(per_q) > 1:                                   # inside the window in whic
     print("while queue %s is in use (%.1f ms): >= 2 kernels resident %.1f %% of the time, exactly 1 %.1f %%, none %.1f %%" % (
         q2, w / 1e6, 100.0 * sum(v for k, v in b2.items() if k >= 2) / w, 100.0 * b2.get(1, 0) / w, 100.0 * b2.get(0, 0) / w))
 dom = t[t["Kernel_Name"].str.contains("igemm_conv_kernel<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32, 1")]
+if len(per_q) > 1:
+    dom = dom[(dom["Start_Timestamp"] >= lo) & (dom["End_Timestamp"] <= hi)]          # the launches of the two-lane window
 dur = (dom["End_Timestamp"] - dom["Start_Timestamp"]) / 1e3
 print("dominant kernel: %d launches, duration min %.0f / median %.0f / max %.0f us (alone: ~410 us; longer = it shared the chip with the other forward's kernels)" % (
     len(dom), dur.min(), dur.median(), dur.max()))
