@@ -331,7 +331,8 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
         kgroups["igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=2,CC=32> (transposed 3x3: up2, up3, clr_up3, clr_up1)"] = ["up2", "up3", "clr_up3", "clr_up1"]
         kgroups["igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=1,CC=32> (transposed 3x3: up1, clr_up2)"] = ["up1", "clr_up2"]
     for gname, layers in kgroups.items():
-        ms = sum(layer_ms.get(n, 0.0) for n in layers)
+        layers = [n for n in layers if n in layer_ms]        # a group's layers that ran as their own launch in this forward (others: a fused launch's group)
+        ms = sum(layer_ms[n] for n in layers)
         if ms <= 0:
             continue
         gflop = 2e-3 * sum(launch_mmac(n) for n in layers) * B

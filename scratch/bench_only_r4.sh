@@ -1,0 +1,9 @@
+# The bench lines of final_pass_r4.sh alone — re-run after tools/pmc_traffic.py / pmc_mfma.py refreshed profiles/r4_pmc_*.json (so that the
+# lines carry `traffic` / `mfma_busy` for the current kernel sources) or after bench.py changed.  BSR_SKIP_TESTS=1 skips the pytest leg.
+set -x
+T=r4
+[ -n "$BSR_SKIP_TESTS" ] || { python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/${T}_final_tests.log; cat gpurun_out/${T}_final_tests.log; }
+python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+python bench.py --dtype f32x3 > gpurun_out/${T}_bench_f32x3.json 2>/dev/null
+python bench.py --dtype f16 > gpurun_out/${T}_bench_f16.json 2>/dev/null
+BSR_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 python bench.py --no-cpu-baseline --no-secondary > gpurun_out/${T}_bench_dist1.json 2>/dev/null
