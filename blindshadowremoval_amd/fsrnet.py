@@ -296,6 +296,15 @@ class _ShmPinnedRing:
         self.nbytes = int(nbytes)
         self.slots = []                          # (path, mmap, uint8 tensor)
         self.free: List[int] = []
+        # a mapping of a tmpfs file that the file system cannot back kills the process with SIGBUS on first touch (truncate() succeeds
+        # on a full /dev/shm): refuse up front unless the slots fit with room to spare
+        probe = _shm_file("bsr_ring_probe_")
+        try:
+            vfs = os.statvfs(os.path.dirname(probe))
+        finally:
+            os.unlink(probe)
+        if vfs.f_bavail * vfs.f_frsize < int(1.25 * n * self.nbytes) + (64 << 20):
+            raise RuntimeError("shared memory has %.0f MB free, the ring needs %.0f MB" % (vfs.f_bavail * vfs.f_frsize / 1e6, n * self.nbytes / 1e6))
         self._rt = torch.cuda.cudart()
         try:
             for i in range(n):

@@ -338,3 +338,38 @@ def test_sharded_generator_packed_payload_on_the_gpu():
     con_rgb, dif = sg.forward_global(a, ua)
     assert torch.equal(con_rgb, want_a[1]) and torch.equal(dif, want_a[3])
     gen.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_loop_with_and_without_the_shared_pinned_ring(golden_dir, tmp_path):
+    """Round 4: the loops keep up to `gpu_inflight` batches in flight and copy pool-bound batches device -> pinned shared-memory slots the
+    worker processes read in place (fsrnet._ShmPinnedRing).  Same items, same order, same PNG bytes and losses as the synchronous form
+    (gpu_inflight = 0, private buffers + file copy) — for the FFHQ strips (PNG pool) and the UCB post-processing pool."""
+    from blindshadowremoval_amd import dataset as D
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    w = init_weights(1)
+    runs = {}
+    for ucb in (False, True):
+        for label, ring, depth in (("sync", False, 0), ("ring", True, 2), ("pipelined_no_ring", False, 2)):
+            cfg.CHECKPOINT_DIR = str(tmp_path / ("%s_%d" % (label, ucb)))
+            ds = D.Dataset(cfg, "test", ucb=True, workers=2, device_prep=0, device_batch=8)
+            ds.name_list = ds.name_list[:20]
+            fsr = FSRNet(cfg, weights=w)
+            fsr.shm_ring, fsr.gpu_inflight = ring, depth
+            fsr.log.png_workers = 0 if ucb else 2
+            fsr.post_workers, fsr.return_figs = (3 if ucb else 0), False
+            res = fsr.test(ds, batch=8) if ucb else fsr.testFFHQ(ds, batch=8)
+            ds.close()
+            assert len(res) == 20 and len(fsr.log.saved) == 20
+            if ring:
+                assert fsr.timings.get("shm_ring_slots", 0) > 0, fsr.timings.get("shm_ring_error")      # the ring really carried the batches
+            runs[(ucb, label)] = ([r[0] for r in res], [dict(r[2]) if len(r) > 2 else {} for r in res], [open(f, "rb").read() for f in fsr.log.saved])
+            fsr.close()
+        base = runs[(ucb, "sync")]
+        for label in ("ring", "pipelined_no_ring"):
+            got = runs[(ucb, label)]
+            assert got[0] == base[0] and got[1] == base[1], (ucb, label)
+            assert got[2] == base[2], (ucb, label)                         # PNG strips byte for byte
