@@ -31,11 +31,18 @@ def main(argv=None) -> int:
     ap.add_argument("--random-weights", type=int, default=None, metavar="SEED", help="seeded random-init weights in the checkpoint layout instead of a restore")
     ap.add_argument("--host-prep", action="store_true", help="prepare the rows on the host (default: on the device, prep.py)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl")
+    ap.add_argument("--device", type=int, default=None, help="GPU index of this rank (default: LOCAL_RANK).  With --backend gloo several ranks may share one "
+                                                              "GPU — how the world-2 loop is exercised on a one-GPU box (tests/test_fsrnet.py)")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device is not None:
+        if args.backend == "nccl" and world > 1:
+            sys.stderr.write("run_loop: --device with several ranks needs --backend gloo (RCCL wants one GPU per rank)\n")
+            return 2
+        local_rank = args.device
     import torch
     if not torch.cuda.is_available():
         sys.stderr.write("run_loop: no ROCm GPU visible — the generator has no CPU path\n")

@@ -373,3 +373,34 @@ def test_pipelined_loop_with_and_without_the_shared_pinned_ring(golden_dir, tmp_
             got = runs[(ucb, label)]
             assert got[0] == base[0] and got[1] == base[1], (ucb, label)
             assert got[2] == base[2], (ucb, label)                         # PNG strips byte for byte
+
+
+@pytest.mark.gpu
+def test_data_parallel_loop_world2_on_one_gpu_over_gloo(golden_dir, tmp_path):
+    """The world-2 data-parallel loop with the REAL generator: two ranks of `run_loop` share GPU 0 (`--device 0 --backend gloo`; RCCL needs a
+    GPU per rank, the loop's only collective is an all_gather_object, which gloo carries).  Together they must write every item's strip
+    exactly once, byte-identical to a one-process run, and rank 0's report must carry the one-process means."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["-m", "blindshadowremoval_amd.run_loop", "--loop", "ucb", "--data", os.path.join(golden_dir, "UCB", "train", "input", "*"),
+              "--mask-root", os.path.join(golden_dir, "UCB_masks"), "--random-weights", "1", "--batch", "8"]
+    one = subprocess.run([sys.executable] + common + ["--checkpoint-dir", str(tmp_path / "one")], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29667"]
+                         + common + ["--checkpoint-dir", str(tmp_path / "two"), "--backend", "gloo", "--device", "0"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-3000:]
+    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r2["ranks"] == 2 and r2["process_group"] == "gloo" and r2["items"] == r1["items"] and 0 < r2["items_this_rank"] < r2["items"]
+    assert r2["means"] == r1["means"]                                   # re-accumulated in list order: the same float sums
+    f1 = sorted(os.listdir(os.path.join(str(tmp_path / "one"), "test")))
+    f2 = sorted(os.listdir(os.path.join(str(tmp_path / "two"), "test")))
+    assert f1 == f2 and len(f1) == r1["items"]
+    for f in f1:
+        assert open(os.path.join(str(tmp_path / "one"), "test", f), "rb").read() == open(os.path.join(str(tmp_path / "two"), "test", f), "rb").read(), f
