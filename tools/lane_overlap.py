@@ -57,3 +57,19 @@ if len(per_q) > 1:
 dur = (dom["End_Timestamp"] - dom["Start_Timestamp"]) / 1e3
 print("dominant kernel: %d launches, duration min %.0f / median %.0f / max %.0f us (alone: ~410 us; longer = it shared the chip with the other forward's kernels)" % (
     len(dom), dur.min(), dur.median(), dur.max()))
+
+# per-kernel mean duration inside the two-lane window against the whole run's single-lane launches (outside the window): the profiler's
+# cross-check of bench.py's `roofline_in_flight.dominant_kernel.avg_launch_ms` (event-bracketed) — a kernel that shares the chip lasts longer
+if len(per_q) > 1:
+    import re
+    t["short"] = t["Kernel_Name"].map(lambda n: re.sub(r"\((bsr::|float|unsigned|int|void).*", "", n.replace("void bsr::", "").replace("bsr::", "")))
+    t["dur_us"] = (t["End_Timestamp"] - t["Start_Timestamp"]) / 1e3
+    inside = t[(t["Start_Timestamp"] >= lo) & (t["End_Timestamp"] <= hi)]
+    outside = t[t["Start_Timestamp"] > hi]
+    a = inside.groupby("short")["dur_us"].agg(["count", "mean"])
+    b = outside.groupby("short")["dur_us"].agg(["count", "mean"])
+    j = a.join(b, lsuffix="_two_lanes", rsuffix="_alone", how="inner").sort_values("mean_two_lanes", ascending=False)
+    print("per kernel, mean launch duration in us — two forwards in flight | one at a time (later phases of the same run):")
+    for k, r in j.iterrows():
+        if r["mean_two_lanes"] >= 20:
+            print("  %-75s %7.1f (%4d launches) | %7.1f (%4d)  x%.2f" % (k[:75], r["mean_two_lanes"], r["count_two_lanes"], r["mean_alone"], r["count_alone"], r["mean_two_lanes"] / r["mean_alone"]))

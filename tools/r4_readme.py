@@ -53,7 +53,8 @@ Other round-4 artefacts (this block is written by `tools/r4_readme.py` from the 
   7.56: the attention output no longer makes the round trip); dominant kernel %.0f MB per launch against %.0f MB algorithmic.
 * `r4_kernel_stats*.csv` — `rocprofv3 --kernel-trace --stats` of `bench.py --streams 1` (tables above): **38 launches per forward** (round 3: 44).
 * `r4_lane_overlap.txt` — `tools/lane_overlap.py` over a kernel trace of the default two-lane bench:
-  `%s`; `%s`.
+  `%s`; `%s`; followed by every kernel's mean launch duration with two forwards in flight against one at a time (x1.4-2.8: the profiler's
+  cross-check of `roofline_in_flight.dominant_kernel.avg_launch_ms`).
 * `r4_bench_dist1.json` — `BSR_BENCH_FORCE_DIST=1 python bench.py` (the RCCL path on one rank): all_gather of the 33.5-MB packed payload,
   `verified: %s`, %.3f ms alone, %.3f ms exposed per step; %.0f images/s.
 * `r4_bench_tsm512.json` / `_f32x3` — BASELINE configs[4] per-rank shape (8 frames of 512x512, TSM generator, frame = 2): %.0f frames/s at f32
@@ -88,7 +89,7 @@ Other round-4 artefacts (this block is written by `tools/r4_readme.py` from the 
     100 * row("<3, 3, 1, false")["mfma_busy"], 100 * row("gemm_nloop")["mfma_busy"], 100 * row("<1, 1, 1, false")["mfma_busy"], 100 * row("<3, 3, 2, false, 4, 32, 4, 1, 1, 2")["mfma_busy"],
     100 * mf["forward"]["mfma_busy_time_weighted"],
     tr["all_kernels_hbm_bytes_per_forward"] / 1e9, tr["dominant_kernel_hbm_bytes_per_launch"] / 1e6, tr["dominant_kernel_algorithmic_bytes_per_launch"] / 1e6,
-    lanes[-2].strip(), lanes[-1].strip(),
+    [ln for ln in lanes if ln.startswith("while queue")][0].strip(), [ln for ln in lanes if ln.startswith("dominant kernel")][0].strip(),
     str(d1["config"]["allgather"]["verified"]).lower(), d1["config"]["allgather"]["ms_alone"], d1["config"]["allgather"]["ms_exposed_per_step"], d1["value"],
     t5["value"], t5x["value"], sweep_rows, " / ".join("%.0f" % base_sweep[k] for k in (1, 2, 4, 8, 10, 16)),
     b16.get("value", 0), b16.get("rate_vs_batch32_single_stream", 0),
