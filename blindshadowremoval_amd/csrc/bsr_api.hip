@@ -20,6 +20,7 @@
 #include "glue_kernels.h"
 #include "igemm_conv.h"
 #include "igemm_h16.h"
+#include "igemm_s2p.h"
 #include "prep_kernels.h"
 #include "stem7.h"
 
@@ -147,6 +148,7 @@ struct bsr_handle {
   // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
   unsigned* range_flag = nullptr;
   bool fuse_heads = true;        // env BSR_FUSE_HEADS=0: always the two-launch heads (A/B measurements, bit-identity tests)
+  bool s2_persist = false;       // env BSR_S2_PERSIST=1: down1 / down2 on the persistent stride-2 kernel (igemm_s2p.h) — see profiles/HISTORY.md
   bool tail_stagger = true;      // env BSR_TAIL_STAGGER=0: both wave groups of a fused GEMM tail walk their channel groups in the same order
   bool fuse_c3q = false;         // env BSR_FUSE_C3Q=1: res*.conv2 with the conv3 | theta|phi|g GEMM as its tail (one launch).  Built, bit-identical, and
                                  // OFF: one forward at a time it is 0.2 % faster, with two forwards in flight 0.8 % slower (its 150-KB, 8-wave workgroups
@@ -260,7 +262,10 @@ struct Launcher {
     constexpr bool kTrunk = !TR && S == 1 && NI == 2 && (CC == 32 || (k11 && CC == 24));
     bool half_tile = false;
     if constexpr (kTrunk) half_tile = !h16 && mh % 2 == 0 && (long long)(mh / 4) * (mw / 32) * h->B * nb < bsr::device_cu_count();
-    if (half_tile) {
+    constexpr bool kS2 = k33 && S == 2 && !TR && NI == 2 && CC == 16 && INB == 1;      // down1 / down2
+    if (kS2 && !h16 && h->s2_persist && (a.nchunk & 1) == 0) {
+      if constexpr (kS2) check(bsr::launch_igemm_s2p<2>(a, h->B, s), name);          // persistent workgroups with next-tile prefetch (igemm_s2p.h)
+    } else if (half_tile) {
       if constexpr (kTrunk) check(bsr::launch_igemm_conv<KH, KW, S, TR, 2, 32, 2, 2, 1, 1, CC, INB>(a, h->B, s), name);
     } else if (!h16)
       check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
@@ -458,6 +463,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   if (const char* e_ = getenv("BSR_FUSE_ATTW")) h->fuse_attw = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_FUSE_C3Q")) h->fuse_c3q = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_TAIL_STAGGER")) h->tail_stagger = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_S2_PERSIST")) h->s2_persist = atoi(e_) != 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {

@@ -766,6 +766,30 @@ def test_fused_gemm_tails_are_bit_identical_to_the_separate_launches(monkeypatch
     plain.close()
 
 
+def test_persistent_stride2_kernel_is_bit_identical(monkeypatch):
+    """igemm_s2p_kernel (round 4, opt-in BSR_S2_PERSIST=1): down1 / down2 on persistent workgroups that request the next tile's input
+    during the current tile's last chunk and keep the weight ring running across tiles — the same accumulation order as
+    igemm_conv_kernel<3,3,2>: same bits on x2, x3 and every output, for one and for several tiles per workgroup (B = 1: 128 tiles on 512
+    resident workgroups; B = 32: 8 tiles per workgroup; B = 3: a ragged walk)."""
+    from blindshadowremoval_amd import Generator
+    w = init_weights(1)
+    plain = Generator().load_weights(w)
+    monkeypatch.setenv("BSR_S2_PERSIST", "1")
+    pers = Generator().load_weights(w)
+    monkeypatch.delenv("BSR_S2_PERSIST")
+    g = torch.Generator().manual_seed(73)
+    for (B, H, W) in ((1, 256, 256), (3, 256, 256), (32, 256, 256), (2, 512, 512)):
+        inp, uv = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
+        a = [t.clone() for t in pers(inp, uv)]
+        b = plain(inp, uv)
+        for pr in ("x2", "x3"):
+            assert torch.equal(pers.probe(pr), plain.probe(pr)), (B, H, W, pr)
+        for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
+            assert torch.equal(x, y), (B, H, W, name)
+    pers.close()
+    plain.close()
+
+
 def test_packed_output_is_bit_identical(gen_w):
     """bsr_forward_packed: con_rgb | dif written as one [B,H,W,4] tensor by the tail kernel (the all-gather payload of bench.py /
     dist.py) — the same bits as the two separate outputs."""

@@ -143,13 +143,13 @@ What the round did to the fp32 path (38 launches per forward instead of 44; matr
   +1.4 %% with two in flight, bit-identical.  The same tail behind `res*.conv2` (conv3 | theta|phi|g, 21 channel tiles) was built and is
   bit-identical too, but is off: one at a time 0.797 vs 0.815 ms for the six blocks, with two forwards in flight 6 800 vs 6 857 images/s
   (its 150-KB 8-wave workgroups leave the other lane's kernels no room on the CU).
-* **Why the rest of the review's list was not built** (`profiles/HISTORY.md`, round 4, has the numbers): the `c3q` GEMM with its output stores
+* **The rest of the review's list** (`profiles/HISTORY.md`, round 4, has the numbers): the `c3q` GEMM with its output stores
   compiled out runs in 61.9 instead of 62.4 us — it is not write-bound; its 62 us are 53 us of workgroup lifetime (79 %% matrix-busy inside it)
   plus ~9 us of stragglers in a one-round grid, which fusion removes only for SHORT launches (`w`: 36 us).  Chaining `res{i+1}.conv1` behind
   the `w` tail needs the block output as an LDS tile beside the tail's weight ring: 128 px x 264 ch (135 KB) whole, or per-tile slabs plus a
-  second weight ring for two wave groups (~190 KB) — over the 160-KB CU.  A persistent stride-2 kernel hides ~3-4 k of a 53-k-cycle tile
-  (the loads' latency, not their issue slots — round 3's conservation finding): <= 0.4 %% of the forward against the SGPR-spill cost measured on
-  the persistent up3; a stem + down1 fusion has the MFMA work of both (293 us at peak for 382 now) and one workgroup per CU: no gain.
+  second weight ring for two wave groups (~190 KB) — over the 160-KB CU.  The persistent stride-2 kernel with next-tile prefetch WAS built (`igemm_s2p.h`, opt-in, bit-identical)
+  and is slower — down1 198 -> 220 us, down2 97 -> 108 us: it can only hide the loads' latency (~3-4 k of a 53-k-cycle tile), their ~370
+  instructions now sit inside the matrix loop, and the tile loop spills (round 3's persistent up3 again); a stem + down1 fusion has the MFMA work of both (293 us at peak for 382 now) and one workgroup per CU: no gain.
   2x32-pixel tiles for the trunk at B = 32 and NI = 4 channel groups in `c3q`: measured, both slower or equal.
 * **Small batches** (table in `profiles/README.md`): B = 16 %.0f images/s = %.2f of the B = 32 rate (round-3 kernels: 0.80), B = 10 — the
   reference's literal element — %.0f (3 898), B = 8 %.0f (3 392), B = 1 %.0f (554); all shapes bit-identical to the B = 32 rows.
