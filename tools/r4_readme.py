@@ -129,7 +129,7 @@ design = '''<!-- BEGIN r4 DESIGN -->
 
 | dtype | images/s: two forwards in flight (one at a time) | ms / step | dominant kernel against its roofs | max abs error vs oracle |
 |---|---|---|---|---|
-| **f32** — fp32 matrix cores, the measured path (`value`) | **%.0f** (%.0f; over the boxes of the round 6 780-6 880 and 6 590-6 650; round 3: %.0f / %.0f) | %.3f | transposed 3x3 `igemm_conv_kernel` %.1f TFLOP/s = **%.1f %%** of 157.3 (`bound: mfma`); PMC: matrix pipe busy %.1f %% at %.2f GHz; 3x3-conv path %.1f %%; HBM %.0f MB per launch (%.0f MB algorithmic); whole forward in the two-lane mode %.1f TFLOP/s = %.1f %% | %.1e, %d mask flips |
+| **f32** — fp32 matrix cores, the measured path (`value`) | **%.0f** (%.0f; over the boxes of the round 6 770-6 880 and 6 590-6 650; round 3: %.0f / %.0f) | %.3f | transposed 3x3 `igemm_conv_kernel` %.1f TFLOP/s = **%.1f %%** of 157.3 (`bound: mfma`); PMC: matrix pipe busy %.1f %% at %.2f GHz; 3x3-conv path %.1f %%; HBM %.0f MB per launch (%.0f MB algorithmic); whole forward in the two-lane mode %.1f TFLOP/s = %.1f %% | %.1e, %d mask flips |
 | f32x3 — split precision on the fp16 matrix cores (§4b) | %.0f (%.0f) | %.3f | %s | %.1e, %d mask flips |
 | f16 — fp16 operands + fp16 activation pack (configs[3]) | %.0f (%.0f) | %.3f | %s | 1.4e-03 (tested at 2e-3) |
 
