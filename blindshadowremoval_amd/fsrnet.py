@@ -825,51 +825,91 @@ class FSRNetTSM(object):
         t = torch.as_tensor(np.asarray(img) if not isinstance(img, torch.Tensor) else img, dtype=torch.float32)
         return torch.split(t.reshape(n, s, s, t.shape[-1]), list(split), dim=3)
 
-    def test_step_sfw(self, img, box=None, training: bool = False):
-        """train_with_TSM.py:668-707: element = [2,256,256,17] (image + mirror)."""
-        im, cmap, mask, uv, reg, face = self._prep(img, 2, self.SPLIT_SFW)
+    def _groups(self, elements, n: int, split):
+        """Stack k elements of n coupled frames each into one [k*n, S, S, C] batch, split by channels."""
+        s = self.config.IMG_SIZE
+        ts = [torch.as_tensor(np.asarray(e) if not isinstance(e, torch.Tensor) else e, dtype=torch.float32).reshape(n, s, s, -1) for e in elements]
+        return torch.split(torch.cat(ts, dim=0), list(split), dim=3)
+
+    def test_steps_sfw(self, elements, training: bool = False):
+        """train_with_TSM.py:668-707 for k elements in ONE forward: each element = [2,256,256,17] (image + mirror) is its own
+        frame = 2 group — the ShareLayer couples only the frames of a group (model_with_TSM.py:204-229), so the k groups are independent
+        and each element's outputs are those of its own forward, bit for bit.  -> [(losses, figs)] per element."""
+        k = len(elements)
+        im, cmap, mask, uv, reg, face = self._groups(elements, 2, self.SPLIT_SFW)
         dev = "cuda:%d" % self.gen._device
         _, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg.contiguous().to(dev), frame=2, share=True,
                                             chuck=1, training=training)
         mask_pred = mask_pred * face.to(dev)
         con_rgb = torch.clamp(con_rgb, 0, 1)
-        label = (mask[0] == 2).float()                                              # :685
-        pred0 = mask_pred[0].detach().cpu()
-        mse = float(((mask[0] - pred0) ** 2).mean())
-        losses = {"psnr": float(10 * np.log10(1.0 / mse)) if mse > 0 else float("inf")}
-        lab = np.concatenate([[1, 0], label.numpy().reshape(-1)])                   # :688-692: one forced sample of each class
-        sc = np.concatenate([[1, 0], pred0.numpy().reshape(-1)])
-        losses["auc"] = roc_auc_score(lab, sc)
-        return losses, [im.to(dev), con_rgb, mask_pred * 2, label.reshape(1, *label.shape).to(dev)]
+        im_d = im.to(dev)
+        pred_host = mask_pred.detach().cpu()
+        out = []
+        for j in range(k):
+            g = slice(2 * j, 2 * j + 2)
+            m0 = mask[2 * j]
+            label = (m0 == 2).float()                                               # :685
+            pred0 = pred_host[2 * j]
+            mse = float(((m0 - pred0) ** 2).mean())
+            losses = {"psnr": float(10 * np.log10(1.0 / mse)) if mse > 0 else float("inf")}
+            lab = np.concatenate([[1, 0], label.numpy().reshape(-1)])               # :688-692: one forced sample of each class
+            sc = np.concatenate([[1, 0], pred0.numpy().reshape(-1)])
+            losses["auc"] = roc_auc_score(lab, sc)
+            out.append((losses, [im_d[g], con_rgb[g], mask_pred[g] * 2, label.reshape(1, *label.shape).to(dev)]))
+        return out
 
-    def test_step_sfw_video(self, img, box=None, training: bool = False):
-        """train_with_TSM.py:720-748: element = [10,256,256,13] (10 consecutive frames share features)."""
-        im, uv, reg, face = self._prep(img, 10, self.SPLIT_VIDEO)
+    def test_step_sfw(self, img, box=None, training: bool = False):
+        """train_with_TSM.py:668-707: element = [2,256,256,17] (image + mirror)."""
+        return self.test_steps_sfw([img], training=training)[0]
+
+    def test_steps_sfw_video(self, elements, training: bool = False):
+        """train_with_TSM.py:720-748 for k elements in one forward: each element = [10,256,256,13] is its own frame = 10 group."""
+        k = len(elements)
+        im, uv, reg, face = self._groups(elements, 10, self.SPLIT_VIDEO)
         dev = "cuda:%d" % self.gen._device
         _, con_rgb, _, mask_pred = self.gen(im.contiguous().to(dev), uv.contiguous().to(dev), reg.contiguous().to(dev), frame=10, share=True,
                                             chuck=1, training=training)
-        return {}, [im.to(dev), torch.clamp(con_rgb, 0, 1), mask_pred * face.to(dev) * 2]
+        im_d, con_rgb, shown = im.to(dev), torch.clamp(con_rgb, 0, 1), mask_pred * face.to(dev) * 2
+        return [({}, [im_d[10 * j:10 * j + 10], con_rgb[10 * j:10 * j + 10], shown[10 * j:10 * j + 10]]) for j in range(k)]
 
-    def _loop(self, dataset_val, step_fn):
+    def test_step_sfw_video(self, img, box=None, training: bool = False):
+        """train_with_TSM.py:720-748: element = [10,256,256,13] (10 consecutive frames share features)."""
+        return self.test_steps_sfw_video([img], training=training)[0]
+
+    def _loop(self, dataset_val, steps_fn, batch: int = 1):
+        """The reference's loop (train_with_TSM.py:619-666, 709-718) with `batch` ELEMENTS per forward (1 = the reference's own
+        element-by-element form; config[4]'s "batch = 64 frames" is 32 SFW pairs or 6 ten-frame video groups)."""
         if self.gen._handle is None and self.gen.restore(self.config.CHECKPOINT_DIR) == 0 and self.gen._handle is None:
             raise RuntimeError("no generator weights: checkpoint data shard missing under %s" % self.config.CHECKPOINT_DIR)
+        if batch < 1:
+            raise ValueError("batch must be >= 1 element per forward")
         start = time.time()
         names = list(dataset_val.name_list)
         results = []
+        group: List[Tuple[int, str, object]] = []
+
+        def flush():
+            if not group:
+                return
+            for (step, name, _), (losses, figs) in zip(group, steps_fn([g[2] for g in group], training=False)):
+                self.log.display(losses, 0, step, False, len(names))
+                self.log.save_img(figs, name)
+                results.append((name, losses, figs))
+            group.clear()
         try:
             for step, img_name in enumerate(names):
                 element = next(dataset_val.feed)
-                losses, figs = step_fn(element[0], element[1] if len(element) > 1 else None, training=False)
-                self.log.display(losses, 0, step, False, len(names))
-                self.log.save_img(figs, _name(img_name))
-                results.append((_name(img_name), losses, figs))
+                group.append((step, _name(img_name), element[0]))
+                if len(group) >= batch:
+                    flush()
+            flush()
         finally:
             self.log.flush()
         print('\n*****Time for epoch {} is {} sec*****'.format(1, int(time.time() - start)))
         return results
 
-    def testsfw(self, dataset_val):
-        return self._loop(dataset_val, self.test_step_sfw)
+    def testsfw(self, dataset_val, batch: int = 1):
+        return self._loop(dataset_val, self.test_steps_sfw, batch)
 
-    def testsfw_video(self, dataset_val):
-        return self._loop(dataset_val, self.test_step_sfw_video)
+    def testsfw_video(self, dataset_val, batch: int = 1):
+        return self._loop(dataset_val, self.test_steps_sfw_video, batch)

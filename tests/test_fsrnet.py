@@ -170,6 +170,14 @@ def test_tsm_loops_over_the_sfw_loaders(tmp_path, golden_dir):
     ref = GeneratorTSMOracle(w)(img, uv, reg, 10, True)
     assert float((vid[0][2][1].cpu() - ref[1].clamp(0, 1)).abs().max()) <= 1e-3
     assert len([f for f in os.listdir(os.path.join(str(tmp_path), "test")) if f.endswith("-result.png")]) == 2      # same names for both loops
+    # several elements per forward (round 4; config[4]'s "batch = 64 frames" = 32 pairs / 6 ten-frame groups): each element is its own
+    # ShareLayer group, so its outputs are those of its own forward, bit for bit
+    res2 = fsr.testsfw(D.Dataset(cfg, "test", dset="sfw", workers=2), batch=2)
+    vid2 = fsr.testsfw_video(D.Dataset(cfg, "test", dset="sfw_video", workers=2), batch=2)
+    for one, many in ((res, res2), (vid, vid2)):
+        assert [r[0] for r in one] == [r[0] for r in many] and [r[1] for r in one] == [r[1] for r in many]
+        for a, b in zip(one, many):
+            assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
 
 
 @pytest.mark.gpu
