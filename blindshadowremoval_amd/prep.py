@@ -51,17 +51,27 @@ def _tri_table(tri, zs: Sequence[np.ndarray]) -> np.ndarray:
     return out
 
 
+_REF_TRI: dict = {}      # the Delaunay mesh of the canonical landmarks (one per process: matplotlib / qhull take ~0.4 ms to rebuild it per item)
+
+
 def meshes(lm: np.ndarray) -> List[np.ndarray]:
     """The four triangle tables of one set of normalised landmarks, with the reference's vertex sets and dtype flow
     (dataset.generate_uv_map / generate_offset_map / generate_face_region = warp.py:194-232, utils.py:255-276)."""
     import matplotlib.tri as mtri
     uv, lm_ref = D._face_model()
     tabs = [_tri_table(mtri.Triangulation(lm[:, 0], lm[:, 1]), [uv[:, 1], uv[:, 0], uv[:, 2]])]          # stacked [y, x, z] (warp.py:228-230)
-    for source, target in ((lm, lm_ref), (lm_ref, lm)):                                                    # reg_in, reg_out
+    for k, (source, target) in enumerate(((lm, lm_ref), (lm_ref, lm))):                                   # reg_in, reg_out
         s = np.concatenate([source, D._ANCHORS], axis=0).astype(np.float32)
         t = np.concatenate([target, D._ANCHORS], axis=0).astype(np.float32)
         off = s - t
-        tabs.append(_tri_table(mtri.Triangulation(t[:, 0], t[:, 1]), [off[:, 1], off[:, 0]]))           # [my, mx] (warp.py:210-213)
+        if k == 0:          # reg_in triangulates the TARGET points = the canonical landmarks + anchors: the same mesh for every item
+            tri = _REF_TRI.get("t")
+            if tri is None or not np.array_equal(_REF_TRI["pts"], t):
+                tri = mtri.Triangulation(t[:, 0], t[:, 1])
+                _REF_TRI["t"], _REF_TRI["pts"] = tri, t.copy()
+        else:
+            tri = mtri.Triangulation(t[:, 0], t[:, 1])
+        tabs.append(_tri_table(tri, [off[:, 1], off[:, 0]]))                                              # [my, mx] (warp.py:210-213)
     more = np.copy(lm[0:17, :])
     more[:, 1] = more[0, 1] - (more[:, 1] - more[0, 1]) * 0.8
     src = np.concatenate([lm, more], axis=0)
