@@ -1,4 +1,4 @@
-"""Rewrite the round-3 result table of DESIGN.md §7 (between <!-- BEGIN r3 DESIGN TABLE --> / <!-- END r3 DESIGN TABLE -->) from
+"""(Round 3; its table now lives in profiles/HISTORY.md.)  Rewrite the round-3 result table of DESIGN.md §7 (between <!-- BEGIN r3 DESIGN TABLE --> / <!-- END r3 DESIGN TABLE -->) from
 profiles/r3_bench_n1*.json, so that the numbers quoted there are the tracked ones.  Usage: python tools/r3_design_table.py"""
 import json
 import os

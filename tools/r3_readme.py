@@ -43,9 +43,9 @@ Other round-3 artefacts (this block is written by `tools/r3_readme.py` from the 
   579-us kernel, the rest is workgroup turn-over and the last round's tail.  Matrix-busy inside a wave pair's lifetime: 2 x 73.7 k / 161.7 k
   = 91 %%; over the whole kernel 85 %%.  With ONE workgroup per CU (`_solo`): `%s` —
   a lone wave cannot feed the pipe back to back either (65.8 cycles per MFMA with all staging compiled out).  Before the round's last passes
-  (row-wise staging, one-round-trip prologue, quad-addressed epilogue, buffer-addressed unguarded weight staging — DESIGN.md §7) the same
+  (row-wise staging, one-round-trip prologue, quad-addressed epilogue, buffer-addressed unguarded weight staging — profiles/HISTORY.md) the same
   stamps read 14.5 k / 140.6 k (122 per MFMA) / 14.6 k at 600 us.
-  What was built on these numbers and measured (all dropped): persistent workgroups with an atomic tile counter (no turn-over,
+  What was built on these numbers and measured (all dropped, profiles/HISTORY.md): persistent workgroups with an atomic tile counter (no turn-over,
   but 40-75 spilled SGPRs around the tile loop: 616 vs 600 us), half-period dephasing of the odd wave slot (no change: the residents are not
   in lockstep), 8-wave workgroups with 64 accumulators per wave (4 waves per SIMD: 623 vs 600 us), `v_mfma_f32_16x16x4_f32` instead of
   `32x32x2` (`r3_coexec.txt`: a VALU wave beside EITHER MFMA stream gets no issue slots at equal priority — the issue granularity is not what
