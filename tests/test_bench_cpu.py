@@ -32,6 +32,7 @@ def test_gpus2_launches_two_ranks_over_gloo():
     assert abs(j["value"] - 4 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-3      # whole-job aggregate over both ranks
     assert j["repeats"]["n"] == 2 and j["repeats"]["ms_per_step_min"] > 0
     assert j["config"]["forwards_in_flight"] == 1 and "single_stream" not in j      # the CPU stand-in has no streams: --streams 2 only applies on a GPU
+    assert j["value_mode"] == "one forward at a time" and "single_stream_value" not in j and "roofline_in_flight" not in j      # every line says which mode `value` is in
 
 
 def test_gpus_without_devices_fails_loudly():
@@ -86,3 +87,19 @@ def test_under_torchrun_the_ranks_already_exist():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["stub"] is True and j["config"]["global_batch"] == 2
+
+
+def test_run_loop_refuses_to_run_without_a_gpu():
+    """`python -m blindshadowremoval_amd.run_loop` (the torchrun entry of the data-parallel loops): no GPU -> exit code 2 with a message,
+    never a CPU fallback; --device with several RCCL ranks is refused before anything else happens."""
+    root = os.path.dirname(BENCH)
+    env = dict(os.environ, PYTHONPATH=root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "blindshadowremoval_amd.run_loop", "--loop", "ffhq", "--data", "x", "--checkpoint-dir", "/tmp/none"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 2 and "no CPU path" in r.stderr
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-m", "blindshadowremoval_amd.run_loop", "--loop", "ffhq", "--data", "x", "--checkpoint-dir", "/tmp/none", "--device", "0"],
+                       capture_output=True, text=True, timeout=300, env=env2, cwd=root)
+    assert r.returncode == 2 and "--backend gloo" in r.stderr
