@@ -102,6 +102,58 @@ def layer_bytes(name, dtype):
 
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
+
+def workload_tables(tsm, hw):
+    """(MMAC per image by launch name, activation elements (read, written) per image, executed MMAC of the composed GEMMs) of one
+    hw x hw image, from the layer table itself: GSC (/root/reference/model.py:198-226) or the TSM variant
+    (/root/reference/model_with_TSM.py:231-259, :261-325: res0 sees cat[x 96 | x_share 192 | uv 3] = 291 channels, blocks 3-5
+    cat[x_hole 291 | bmask | x_share 582 | uv 3] = 877; up1 291 -> 96, clr_up1 877 -> 128).  Attention is quadratic in the
+    (hw/8)^2 tokens: two tokens x tokens x 128 contractions per block (model.py:51-53)."""
+    h1, h2, h4, h8 = hw, hw // 2, hw // 4, hw // 8
+    t = h8 * h8
+    c_res = [291, 291, 291, 877, 877, 877] if tsm else [99, 257, 257, 261, 261, 261]      # input channels of each block
+    c_up1, c_clr1 = (291, 877) if tsm else (257, 261)
+    mm = lambda pix, k, cin, cout: pix * k * cin * cout / 1e6
+    m = {"conv1": mm(h1 * h1, 49, 3, 32), "down1": mm(h2 * h2, 9, 32, 64), "down2": mm(h4 * h4, 9, 64, 64), "down3": mm(h8 * h8, 9, 64, 96),
+         "up1": mm(t, 9, c_up1, 96), "up2": mm(h4 * h4, 9, 160, 64), "up3": mm(h2 * h2, 9, 128, 64), "heads": 2 * mm(h1 * h1, 49, 64, 1),
+         "clr_up1": mm(t, 9, c_clr1, 128), "clr_up2": mm(h4 * h4, 9, 128, 96), "clr_up3": mm(h2 * h2, 9, 96, 64),
+         "clr_conv1": mm(h1 * h1, 9, 65, 16) + mm(h1 * h1, 1, 16, 16) + mm(h1 * h1, 1, 16, 3)}
+    io = {"conv1": (h1 * h1 * 3, h1 * h1 * 32), "down1": (h1 * h1 * 32, h2 * h2 * 64), "down2": (h2 * h2 * 64, h4 * h4 * 64), "down3": (h4 * h4 * 64, t * 96),
+          "up1": (t * c_up1, h4 * h4 * 96), "up2": (h4 * h4 * 160, h2 * h2 * 64), "up3": (h2 * h2 * 128, h1 * h1 * 64), "heads": (h1 * h1 * 64, h1 * h1 * 16),
+          "clr_up1": (t * c_clr1, h4 * h4 * 128), "clr_up2": (h4 * h4 * 128, h2 * h2 * 96), "clr_up3": (h2 * h2 * 96, h1 * h1 * 64),
+          "clr_conv1": (h1 * h1 * (64 + 1 + 3), h1 * h1 * 4)}
+    ex = {}
+    for i in range(6):
+        cin = c_res[i]
+        m["res%d.conv1" % i] = mm(t, 1, cin, 128)
+        m["res%d.conv2" % i] = mm(t, 9, 128, 128)
+        m["res%d.c3q" % i] = 4 * mm(t, 1, 128, 257)  # conv3 + theta | phi | g (composed offline into one K = 128 GEMM)
+        m["res%d.attention" % i] = 2 * mm(t, 1, t, 128)
+        m["res%d.w" % i] = mm(t, 1, 128, 257)
+        ex["res%d.c3q" % i] = mm(t, 1, 128, 672)
+        io["res%d.conv1" % i] = (t * cin, t * 128)
+        io["res%d.conv2" % i] = (t * 128, t * 128)
+        io["res%d.c3q" % i] = (t * (128 + min(cin, 288)), t * (288 + 384))          # + the block input (skip folded into y3x)
+        io["res%d.attention" % i] = (t * 384, t * 128)
+        n_out = 288 if tsm else 264                   # channels the `w` GEMM stores: the block output's stride (264), at most its 9 tiles
+        io["res%d.w" % i] = (t * (128 + 288), t * n_out)
+        io["res%d.attw" % i] = (t * (384 + 288), t * n_out)                          # qkv + y3x in, block output out (att never reaches HBM)
+        io["res%d.c2c3q" % i] = (t * (128 + min(cin, 288)), t * (288 + 384))        # t1 + block input in, y3x + qkv out (t2 never reaches HBM)
+    return m, io, ex
+
+
+def set_workload(tsm, hw):
+    """Re-price every launch for another workload (bench.py --workload tsm512): the tables are rebuilt IN PLACE, so every user of
+    LAYER_MMAC / LAYER_IO_ELEMS / EXECUTED_MMAC / GFLOP_PER_IMAGE sees the frames actually run."""
+    global GFLOP_PER_IMAGE, GFLOP_3X3_PER_IMAGE
+    m, io, ex = workload_tables(tsm, hw)
+    LAYER_MMAC.clear(); LAYER_MMAC.update(m)
+    LAYER_IO_ELEMS.clear(); LAYER_IO_ELEMS.update(io)
+    EXECUTED_MMAC.clear(); EXECUTED_MMAC.update(ex)
+    GFLOP_PER_IMAGE = 2e-3 * sum(m.values())
+    px = hw * hw
+    GFLOP_3X3_PER_IMAGE = 2e-3 * (sum(m[n] for n in LAYERS_3X3) - px * (16 * 16 + 16 * 3) / 1e6)
+
 # the "3x3-conv path" of north_star / SURVEY §8d: 3x3, stride-2 3x3 and transposed 3x3 layers (clr_conv1's launch also carries the fused 1x1 tail)
 LAYERS_3X3 = (["down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3", "clr_conv1"] + ["res%d.conv2" % i for i in range(6)])
 # kernel instantiation -> the layers it runs (csrc/bsr_api.hip launch table)
@@ -422,7 +474,7 @@ def roofline_in_flight(gens, lanes, run_on, B, dtype, dom_name, ms_per_step, n_r
     avg = tot / cnt
     gflop = 2e-3 * sum(launch_mmac(n) for n in layers) * B / len(layers)
     whole = GFLOP_PER_IMAGE * B / ms_per_step
-    return {"mode": "two forwards in flight (two handles, two HIP streams) = the mode of `value`",
+    return {"mode": "two forwards in flight (two handles, two HIP streams) = the mode of `two_in_flight`, not of `value`",
             "whole_forward": {"achieved": round(whole, 2), "peak": PEAK_F32_MFMA_TFLOPS if dtype == "f32" else None, "unit": "TFLOP/s",
                               "frac": round(whole / PEAK_F32_MFMA_TFLOPS, 4) if dtype == "f32" else None,
                               "note": "18.104 GFLOP x images / ms_per_step of the timed region: the chip-level figure of this mode"},
@@ -532,9 +584,9 @@ def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_p
     rf, dom = roofline_from_events(gen, lambda: gen(inp, uv, out=out), B, "f32x3")
     attach_traffic(rf, dom, B, "f32x3")
     attach_mfma(rf, dom, B, "f32x3")
-    res = {"dtype": "f32x3", "value": round(B * args.steps / dt, 2), "unit": "images/sec (this GPU, no collective)", "ms_per_step": round(dt / args.steps * 1e3, 4),
-           "steps": args.steps, "forwards_in_flight": 2 if two else 1,
-           "single_stream": {"value": round(B * args.steps / dt_serial, 2), "ms_per_step": round(dt_serial / args.steps * 1e3, 4)}, "roofline": rf,
+    res = {"dtype": "f32x3", "value": round(B * args.steps / dt_serial, 2), "unit": "images/sec (this GPU, no collective)", "ms_per_step": round(dt_serial / args.steps * 1e3, 4),
+           "steps": args.steps, "forwards_in_flight": 1, "value_mode": "one forward at a time",
+           "two_in_flight": ({"value": round(B * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4)} if two else None), "roofline": rf,
            "note": "3x3 / stride-2 / transposed 3x3 layers on v_mfma_f32_32x32x16_f16 with operands split into hi + lo fp16 planes at LDS staging "
                    "(three instructions per K group, fp32 accumulate); every other kernel is the fp32 one; activations stay fp32 in HBM"}
     if with_parity:
@@ -714,16 +766,25 @@ def run_rank(args):
             mx = float(t.item())
         return mx, own
 
+    # `value` is the configuration BASELINE names, literally: ONE batch of B images per GPU resident at a time — every step is one whole
+    # forward on ONE handle and ONE stream, the next step starts when the stream reaches it (round 5; rounds 3-4 took `value` with two
+    # forwards in flight, which keeps 2 x B images resident: that figure is now the side measurement `two_in_flight`)
+    serial = (lambda i: step(i, lane=0))
     for i in range(args.warmup):
-        step(i)
+        serial(i)
     drain()
-    elapsed, own = timed(args.steps, step)                  # THE timed region: exactly K steps
-    reps = [elapsed] + [timed(args.steps, step)[0] for _ in range(max(0, args.repeats - 1))]
+    elapsed, own = timed(args.steps, serial)                # THE timed region: exactly K steps
+    reps = [elapsed] + [timed(args.steps, serial)[0] for _ in range(max(0, args.repeats - 1))]
     extra = {}
-    if nlanes > 1:                                      # the same K steps strictly one after the other on one handle / one stream
-        t_serial, _ = timed(args.steps, lambda i: step(i, lane=0))
-        extra["single_stream"] = {"value": round(world * B * args.steps / t_serial, 2), "ms_per_step": round(t_serial / args.steps * 1e3, 4),
-                                  "note": "the same K steps on ONE handle and ONE stream (no two forwards in flight)"}
+    if nlanes > 1:                                      # side measurement: consecutive steps alternate between two handles on two HIP streams
+        for i in range(max(2, args.warmup)):
+            step(i)
+        drain()
+        t_two = min(timed(args.steps, step)[0] for _ in range(2))
+        extra["two_in_flight"] = {"value": round(world * B * args.steps / t_two, 2), "ms_per_step": round(t_two / args.steps * 1e3, 4),
+                                  "streams_seen_to_overlap": lanes_verified,
+                                  "note": "NOT `value`: the same K steps alternating between two handles on two HIP streams (two forwards in flight, 2 x B images "
+                                          "resident; ms_per_step is an inverse throughput there); every output is bit-identical to the forward running alone"}
     if distributed and not args.no_gather:
         t_nog, _ = timed(args.steps, lambda i: step(i, gather=False))
 
@@ -761,7 +822,7 @@ def run_rank(args):
         value = world * B * args.steps / elapsed
         rs = sorted(r / args.steps * 1e3 for r in reps)
         cfg = {"workload": None, "images_per_gpu_per_step": B, "global_batch": world * B, "height": HW, "width": HW,
-               "parallelism": "dp%d" % world, "forwards_in_flight": nlanes, "streams_seen_to_overlap": lanes_verified,
+               "parallelism": "dp%d" % world, "forwards_in_flight": 1,
                "collective": ("all_gather(con_rgb|dif) per step, async, double-buffered" if distributed and not args.no_gather else "none")}
         if tsm:
             cfg["workload"] = ("BASELINE configs[4] per-rank shape: TSM generator (model_with_TSM.py), %d frames of 512x512 per GPU per step, "
@@ -775,9 +836,7 @@ def run_rank(args):
         else:
             cfg["workload"] = ("BASELINE configs[3]: batch=32 synthetic 256x256x3 per GPU, fp16 MFMA (fp32 accumulate/storage) on the "
                                "3x3-conv path, fp32 elsewhere; NOT the headline configuration")
-        if nlanes > 1:
-            cfg["workload"] += "; steps alternate between two handles on two HIP streams (two forwards in flight, `single_stream` = one at a time)"
-        single = extra.pop("single_stream", None)
+        two = extra.pop("two_in_flight", None)
         cfg.update(extra)
         result = {
             "metric": "images/sec at 256x256 batch inference (GSC generator forward)" if not tsm else "images/sec at 512x512 (TSM generator forward)",
@@ -787,27 +846,37 @@ def run_rank(args):
             "repeats": {"n": len(rs), "ms_per_step_min": round(rs[0], 4), "ms_per_step_median": round(rs[len(rs) // 2], 4),
                         "ms_per_step_all": [round(r, 4) for r in rs], "note": "`value` is the FIRST timed region of exactly K steps; the others repeat it"},
         }
-        result["value_mode"] = ("two forwards in flight (steps alternate between two handles on two HIP streams; every step is one whole B-image forward)"
-                                if nlanes > 1 else "one forward at a time")
-        if single is not None:
-            result["single_stream_value"] = single["value"]        # the strictly serial figure of the same process, comparable with rounds 1-2
-            result["single_stream"] = single
+        result["value_mode"] = "one forward at a time"
+        result["single_stream_value"] = result["value"]            # the key rounds 3-4 carried the serial figure under: now `value` itself
+        if two is not None:
+            result["two_in_flight_value"] = two["value"]
+            result["two_in_flight"] = two
+        if not args.stub:
+            from blindshadowremoval_amd import _lib
+            result["library_source_sha16"] = _lib.source_sha()      # the hash compiled INTO libbsr_hip.so (== the tree's, or the load had refused it)
         if args.stub:
             result["stub"] = True
             result["roofline"] = None
             result["cpu_baseline"] = None
         else:
             if tsm:
-                result["roofline"] = None
+                # configs[4]'s per-rank shape priced with ITS work: 512x512 frames, the TSM channel plan, attention over 4096 tokens
+                set_workload(True, HW)
+                rf, dom_name = roofline_from_events(gen, lambda: forward(0, lane=0), B, args.dtype)
+                rf["work_per_frame"] = {"gflop": round(GFLOP_PER_IMAGE, 3), "gflop_attention": round(2e-3 * sum(LAYER_MMAC["res%d.attention" % i] for i in range(6)), 3),
+                                        "note": "TSM generator at %dx%d: model_with_TSM.py channel plan (291 / 877-wide trunk), attention over %d tokens "
+                                                "(quadratic: 2 x tokens^2 x 128 MACs per block); ShareLayer warp / reduce / unwarp kernels are glue (no matrix work)" % (HW, HW, (HW // 8) ** 2)}
+                rf["traffic_note"] = "no counter pass for this workload: see profiles/r5_kernel_stats_tsm512.csv for the kernel durations"
+                result["roofline"] = rf
             else:
-                rf, dom_name = pre_rf if pre_rf is not None else roofline_from_events(gen, lambda: forward(0), B, args.dtype)
+                rf, dom_name = pre_rf if pre_rf is not None else roofline_from_events(gen, lambda: forward(0, lane=0), B, args.dtype)
                 attach_traffic(rf, dom_name, B, args.dtype)
                 attach_mfma(rf, dom_name, B, args.dtype)
                 result["roofline"] = rf
-                if nlanes > 1 and not distributed:
-                    result["roofline_in_flight"] = roofline_in_flight(gens, lanes, lambda k: forward(k, lane=k), B, args.dtype, dom_name, ms_per_step)
+                if two is not None and not distributed:
+                    result["roofline_in_flight"] = roofline_in_flight(gens, lanes, lambda k: forward(k, lane=k), B, args.dtype, dom_name, two["ms_per_step"])
                 if args.dtype == "f32" and world == 1 and not args.no_secondary:
-                    result["batch16"] = secondary_batch16(gen, dev, value if nlanes == 1 else (single or {}).get("value"))
+                    result["batch16"] = secondary_batch16(gen, dev, value)
             if not args.no_cpu_baseline and world == 1 and not tsm:
                 result["cpu_baseline"] = cpu_baseline(weights, gen=gen, device=dev)
             else:
@@ -851,7 +920,8 @@ def parse_args(argv=None):
                     help="gsc256 = BASELINE configs[1]/[3]; tsm512 = the per-rank shape of configs[4] (TSM generator, 512x512 frames)")
     ap.add_argument("--streams", type=int, choices=(1, 2), default=2,
                     help="forwards in flight per GPU: 2 = consecutive steps alternate between two handles on two HIP streams, so one step's kernels "
-                         "fill the tails and ramps of the other's one-round launches (the serial figure is reported beside it as `single_stream`)")
+                         "fill the tails and ramps of the other's one-round launches — reported as `two_in_flight` BESIDE `value`, which is always one forward at a time; "
+                         "1 = skip that side measurement")
     ap.add_argument("--no-gather", action="store_true", help="skip the output all-gather (N>1)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo only with --stub (CPU test of the rank logic)")
     ap.add_argument("--stub", action="store_true", help="CPU stand-in generator: tests the launcher / sharding / JSON contract, measures nothing")

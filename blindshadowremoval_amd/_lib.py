@@ -6,9 +6,10 @@ import ctypes
 import os
 from typing import Optional
 
+from . import build as _build
 from .build import LIB_PATH
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_CLASSES = 7
 CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue", "convT3x3_ni2")
 
@@ -16,7 +17,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed")
+           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed", "bsr_source_sha")
 
 
 def load() -> ctypes.CDLL:
@@ -24,14 +25,26 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(LIB_PATH):
+    if not os.path.isfile(_build.LIB_PATH):
         raise RuntimeError("libbsr_hip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "— the HIP path has no fallback" % LIB_PATH)
+                           "— the HIP path has no fallback" % _build.LIB_PATH)
     try:
         import torch  # noqa: F401  (loads libamdhip64 first; our DT_NEEDED then resolves to the same runtime)
     except ImportError:
         pass
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(_build.LIB_PATH)
+    # The binary is bound to its sources: build.py compiles the hash of csrc/* + include/bsr_hip.h into it.  A library built from
+    # other sources than this tree holds (the .so is git-ignored and travels as a built artefact) is refused — tests and bench lines
+    # can then only ever describe the kernels that are in the tree.
+    try:
+        lib.bsr_source_sha.restype = ctypes.c_char_p
+        built = (lib.bsr_source_sha() or b"").decode()
+    except AttributeError:
+        built = "<none: built before the hash was embedded>"
+    want = _build.source_sha16()
+    if built != want:
+        raise RuntimeError("libbsr_hip.so is STALE: it was compiled from kernel sources %s, the tree holds %s — rebuild "
+                           "(`python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback" % (built, want))
     c_f, c_i, c_v, c_sz = ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
     lib.bsr_abi_version.restype = c_i
     lib.bsr_last_error.restype = ctypes.c_char_p
@@ -75,6 +88,11 @@ def load() -> ctypes.CDLL:
         raise RuntimeError("libbsr_hip.so ABI %d != binding ABI %d: rebuild" % (lib.bsr_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def source_sha() -> str:
+    """The source hash the LOADED library carries (== build.source_sha16(), or load() would have refused it)."""
+    return (load().bsr_source_sha() or b"").decode()
 
 
 class RangeError(RuntimeError):

@@ -34,11 +34,28 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+def library_sha16(path: str = None) -> str:
+    """The source hash compiled into a built library (its bsr_source_sha() export), read without touching the GPU; '' if the
+    file is not a library of this ABI generation."""
+    import ctypes
+    try:
+        lib = ctypes.CDLL(path or LIB_PATH)
+        fn = lib.bsr_source_sha
+    except (OSError, AttributeError):
+        return ""
+    fn.restype = ctypes.c_char_p
+    return (fn() or b"").decode()
+
+
 def is_stale() -> bool:
+    """True when the library is missing or was compiled from other sources than the tree holds now.  The embedded hash decides
+    (a checkout or a copy resets mtimes); the mtime test only saves loading the library when it is obviously fresh."""
     if not os.path.isfile(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(f) > t for f in _deps())
+    if any(os.path.getmtime(f) > t for f in _deps()):
+        return True
+    return library_sha16() != source_sha16()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -54,8 +71,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             if not force and not is_stale():
                 return LIB_PATH
             tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+            # the hash of everything the library is compiled from goes INTO the binary (bsr_source_sha()): _lib.load() refuses a
+            # library whose hash is not the tree's, so a stale .so can neither pass the tests nor produce a bench line
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-                   "-o", tmp] + [os.path.join(PKG_DIR, s) for s in SOURCES]
+                   '-DBSR_SRC_SHA="%s"' % source_sha16(), "-o", tmp] + [os.path.join(PKG_DIR, s) for s in SOURCES]
             res = subprocess.run(cmd, cwd=PKG_DIR, capture_output=True, text=True)
             if verbose or res.returncode != 0:
                 print(" ".join(cmd))

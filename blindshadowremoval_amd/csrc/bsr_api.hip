@@ -432,7 +432,12 @@ int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
 
 extern "C" {
 
-int bsr_abi_version(void) { return 4; }
+int bsr_abi_version(void) { return 5; }
+
+#ifndef BSR_SRC_SHA
+#define BSR_SRC_SHA "unhashed"
+#endif
+const char* bsr_source_sha(void) { return BSR_SRC_SHA; }
 
 const char* bsr_last_error(void) { return g_last_error.c_str(); }
 

@@ -140,6 +140,11 @@ const char* bsr_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
 int bsr_abi_version(void);
 
+/* The hash (first 16 hex digits of SHA-256) of the sources this binary was compiled from: every file under csrc/ plus this header,
+ * as blindshadowremoval_amd.build.source_sha16() computes it.  The Python binding refuses to load a library whose hash differs from
+ * the tree's (a stale built artefact), and bench.py prints it; "unhashed" when compiled outside build.py.  ABI 5. */
+const char* bsr_source_sha(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,8 +31,9 @@ def test_gpus2_launches_two_ranks_over_gloo():
     assert len(j["config"]["per_rank_images_per_sec"]) == 2
     assert abs(j["value"] - 4 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-3      # whole-job aggregate over both ranks
     assert j["repeats"]["n"] == 2 and j["repeats"]["ms_per_step_min"] > 0
-    assert j["config"]["forwards_in_flight"] == 1 and "single_stream" not in j      # the CPU stand-in has no streams: --streams 2 only applies on a GPU
-    assert j["value_mode"] == "one forward at a time" and "single_stream_value" not in j and "roofline_in_flight" not in j      # every line says which mode `value` is in
+    assert j["config"]["forwards_in_flight"] == 1 and "two_in_flight" not in j      # the CPU stand-in has no streams: the two-lane side measurement only exists on a GPU
+    # `value` is always one forward at a time (BASELINE configs[1]: ONE batch of 32 resident), and every line says so
+    assert j["value_mode"] == "one forward at a time" and j["single_stream_value"] == j["value"] and "roofline_in_flight" not in j
 
 
 def test_gpus_without_devices_fails_loudly():
@@ -68,6 +69,17 @@ def test_roofline_tables_are_consistent():
         assert abs(bench.launch_mmac(name) - sum(bench.LAYER_MMAC[p] for p in parts)) < 1e-9 and name in bench.LAYER_IO_ELEMS
     assert abs(2e-3 * sum(bench.LAYER_MMAC[n] for n in bench.LAYERS_3X3) - 2e-3 * (16.78 + 3.15) - bench.GFLOP_3X3_PER_IMAGE) < 0.01
     assert bench.physical_cores() >= 1
+    # the same tables derived from the layer list (workload_tables) reproduce Appendix C, and re-pricing for configs[4]'s frames works in place
+    m, io, ex = bench.workload_tables(False, 256)
+    assert all(abs(m[k] - v) < 0.02 for k, v in bench.LAYER_MMAC.items()) and io == bench.LAYER_IO_ELEMS and set(m) == set(bench.LAYER_MMAC)
+    bench.set_workload(True, 512)
+    try:
+        assert abs(bench.LAYER_MMAC["res0.attention"] - 2 * 4096 * 4096 * 128 / 1e6) < 1e-6          # quadratic in the 4096 tokens
+        assert abs(bench.LAYER_MMAC["res3.conv1"] - 4096 * 877 * 128 / 1e6) < 1e-6 and abs(bench.LAYER_MMAC["up1"] - 4096 * 9 * 291 * 96 / 1e6) < 1e-6
+        assert abs(bench.GFLOP_PER_IMAGE - 2e-3 * sum(bench.LAYER_MMAC.values())) < 1e-9 and 110 < bench.GFLOP_PER_IMAGE < 125
+    finally:
+        bench.set_workload(False, 256)
+    assert abs(bench.GFLOP_PER_IMAGE - 18.104) < 1e-3 and abs(bench.GFLOP_3X3_PER_IMAGE - 11.017) < 1e-3
 
 
 def test_under_torchrun_the_ranks_already_exist():

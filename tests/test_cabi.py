@@ -63,3 +63,37 @@ def test_header_is_plain_c():
     res = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "bsr_hip.h")],
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_a_stale_library_is_refused(lib, tmp_path):
+    """The binary is bound to its sources: build.py compiles source_sha16() into the library, _lib.load() compares it with the tree's.
+    A deliberately stale .so — the real library with the embedded hash overwritten, as if it had been built from other kernel sources
+    and shipped as an artefact — must raise, not load."""
+    import subprocess
+    import sys
+    from blindshadowremoval_amd.build import library_sha16, source_sha16
+    sha = source_sha16()
+    assert _lib.source_sha() == sha == library_sha16() and len(sha) == 16          # the fresh build carries the tree's hash
+    blob = open(LIB_PATH, "rb").read()
+    assert blob.count(sha.encode()) >= 1
+    stale = tmp_path / "libbsr_hip.so"
+    stale.write_bytes(blob.replace(sha.encode(), b"0123456789abcdef"))
+    assert library_sha16(str(stale)) == "0123456789abcdef"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from blindshadowremoval_amd import build, _lib\n"
+            "build.LIB_PATH = %r\n"
+            "try:\n"
+            "    _lib.load()\n"
+            "except RuntimeError as e:\n"
+            "    print('REFUSED', e)\n"
+            "else:\n"
+            "    print('LOADED')\n" % (ROOT, str(stale)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in r.stdout and "STALE" in r.stdout and "0123456789abcdef" in r.stdout, r.stdout + r.stderr
+    # and is_stale() sees it too (so build_library() would recompile), whatever the file times say
+    code2 = ("import sys; sys.path.insert(0, %r)\n"
+             "from blindshadowremoval_amd import build\n"
+             "build.LIB_PATH = %r\n"
+             "print('STALE' if build.is_stale() else 'FRESH')\n" % (ROOT, str(stale)))
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
+    assert r.stdout.strip() == "STALE", r.stdout + r.stderr
