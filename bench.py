@@ -434,7 +434,8 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
                               "region; the rocprofv3 --kernel-trace average of the same kernel is in profiles/ (3-4 %% longer: profiler overhead); event-timed "
                               "launches carry ~1-2 us of event overhead each, so all_kernels_ms slightly exceeds ms_per_step" % n_rep),
           "algorithmic_gflop_per_launch": round(dom["gflop"] / dom["launches"], 2),
-          "path_3x3": {"achieved": round(path, 2), "peak": round(peak33, 1), "frac": round(path / peak33, 4), "unit": "TFLOP/s", "launches": len(LAYERS_3X3), "ms": round(t33, 4),
+          "path_3x3": {"achieved": round(path, 2), "peak": round(peak33, 1), "frac": round(path / peak33, 4), "unit": "TFLOP/s",
+                       "launches": sum(1 for n in LAYERS_3X3 if n in layer_ms) + len(fused33), "ms": round(t33, 4),
                        "algorithmic_gflop": round(gflop33, 2),
                        "note": ("%d of the launches are res*.conv2 fused with the conv3 | theta|phi|g GEMM: counted with their whole time and the GEMM's work "
                                 "(%.1f GFLOP beyond the path's %.1f)" % (len(fused33), gflop33 - GFLOP_3X3_PER_IMAGE * B, GFLOP_3X3_PER_IMAGE * B)) if fused33 else None},

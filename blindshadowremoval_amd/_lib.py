@@ -17,7 +17,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed", "bsr_source_sha")
+           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed", "bsr_source_sha", "bsr_peek_range")
 
 
 def load() -> ctypes.CDLL:
@@ -82,6 +82,8 @@ def load() -> ctypes.CDLL:
     lib.bsr_prep_rows.restype = c_i
     lib.bsr_check_range.argtypes = [c_v, c_v]
     lib.bsr_check_range.restype = c_i
+    lib.bsr_peek_range.argtypes = [c_v]
+    lib.bsr_peek_range.restype = c_i
     lib.bsr_destroy.argtypes = [c_v]
     lib.bsr_destroy.restype = None
     if lib.bsr_abi_version() != ABI_VERSION:

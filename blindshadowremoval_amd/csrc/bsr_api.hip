@@ -144,6 +144,7 @@ struct bsr_handle {
   Plan plan{};
   int B = 0, H = 0, W = 0;       // shape of the last forward
   bool ran = false;
+  bool att_in_lds = false;       // the last forward ran attention + `w` as ONE launch: the attention output never reached the att<i> workspace slots
   // Range guard of the 16-bit modes (igemm_h16.h): one word of pinned, device-mapped host memory; a kernel that stages an activation
   // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
   unsigned* range_flag = nullptr;
@@ -566,6 +567,15 @@ int bsr_check_range(bsr_handle* h, void* stream) {
   return fail(BSR_ERR_RANGE, kRangeMsg);
 }
 
+int bsr_peek_range(bsr_handle* h) {
+  if (h == nullptr) return fail(BSR_ERR_ARG, "bsr_peek_range: null handle");
+  if (h->range_flag == nullptr) return BSR_OK;
+  // no synchronisation, no clear: the word lives in host memory the kernels write over PCIe; what it says covers every forward that
+  // has COMPLETED so far (the caller waited for an event of the one it asks about)
+  if (__atomic_load_n(h->range_flag, __ATOMIC_SEQ_CST) == 0u) return BSR_OK;
+  return fail(BSR_ERR_RANGE, kRangeMsg);
+}
+
 int bsr_set_timing(bsr_handle* h, int enable) {
   if (h == nullptr) return fail(BSR_ERR_ARG, "bsr_set_timing: null handle");
   h->timing = enable != 0;
@@ -710,6 +720,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     // (attention.h, FUSEW; the attention output never goes to HBM).  Small batches (the 4- / 2-wave attention shapes) and the 16-bit
     // modes keep the two launches; both forms give the same bits (tests/test_gpu_parity.py).
     const bool fuse_w = h->dtype == BSR_DTYPE_F32 && h->fuse_attw && bsr::attention_auto_qw(B, H8 * W8) == 4;
+    h->att_in_lds = fuse_w;
     if (fuse_w && L.rc == BSR_OK) {
       LayerW l;
       snprintf(nm, sizeof nm, "res%d.w", i);
@@ -864,7 +875,14 @@ int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, in
   else if (nm == "x3") src = {p.c2, H / 4, W / 4, 160, 96, 64, p16};
   else if (nm == "x0") src = {p.xa, H / 8, W / 8, h->var.cs_a, 0, h->var.c_a};
   else if ((i = res_idx("res")) >= 0) src = {p.r[i], H / 8, W / 8, i < 3 ? h->var.cs_r : h->var.cs_h, 0, i < 3 ? h->var.c_r : h->var.c_h};
-  else if ((i = res_idx("att")) >= 0) src = {p.att[i], H / 8, W / 8, 128, 0, 128};
+  else if ((i = res_idx("att")) >= 0) {
+    // fused attention + w (fp32, full batches): the attention output stays in LDS, the att<i> slots hold whatever an earlier
+    // forward left there — refuse rather than hand out stale data
+    if (h->att_in_lds)
+      return fail(BSR_ERR_STATE, "bsr_probe: att<i> does not exist for the last forward — attention and the `w` GEMM ran as one launch and the "
+                                 "attention output never left LDS (create the handle with BSR_FUSE_ATTW=0 in the environment to probe it)");
+    src = {p.att[i], H / 8, W / 8, 128, 0, 128};
+  }
   else if ((i = res_idx("y3x")) >= 0) src = {p.y3[i], H / 8, W / 8, CS_Y3X, 0, CS_Y3X};
   else if (nm == "up1") src = {p.c2, H / 4, W / 4, 160, 0, 96, p16};
   else if (nm == "up2") src = {p.c3, H / 2, W / 2, 128, 0, 64, p16};

@@ -642,7 +642,14 @@ class FSRNet(object):
             if ev is not None:
                 ev.synchronize()
             if getattr(self.gen, "dtype", "f32") != "f32":
-                self.gen.check_range()                              # 16-bit modes: an out-of-range activation is an error here, never a silent inf
+                # 16-bit modes: an out-of-range activation is an error here, never a silent inf.  The batch's own event has completed, so
+                # the host-visible flag already covers it: read it WITHOUT synchronising the stream (check_range would wait for the up to
+                # gpu_inflight batches submitted after this one and drain the pipeline on every batch) and without clearing it (a later
+                # batch's report must not be lost): a raised flag means this batch or one of those behind it — the loop stops either way
+                try:
+                    self.gen.peek_range()
+                except RuntimeError as e:
+                    raise type(e)("batch of items %s (or one of the <= %d batches submitted after it): %s" % ([it[1] for it in items][:4], depth, e)) from None
             tm["forward_s"] += time.perf_counter() - t0
             tm.setdefault("first_batch_done_s", time.time() - start)
             poll()
@@ -714,6 +721,11 @@ class FSRNet(object):
                 complete(gpu_q.pop(0))
             drain(keep=0)
         except BaseException:
+            if on_gpu:
+                try:
+                    torch.cuda.synchronize()        # device-to-host copies of still-queued batches may be writing into ring slots / pinned buffers
+                except BaseException:       # noqa: BLE001
+                    pass
             self.close_pools()              # outstanding jobs of a failed loop are dropped with their workers
             for _, _, shm, slot_ in inflight:
                 if slot_ is None:

@@ -190,6 +190,13 @@ class Generator:
             rc = self._lib.bsr_check_range(self._handle, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "bsr_check_range")
 
+    def peek_range(self) -> None:
+        """``check_range`` for a pipelined caller: no stream synchronisation and the condition is not cleared — raises
+        ``_lib.RangeError`` if any forward that has COMPLETED so far overflowed fp16 (bsr_peek_range).  No-op for "f32"."""
+        if self._handle is None:
+            raise RuntimeError("Generator has no weights: call load_weights() or restore() first")
+        _lib.check(self._lib.bsr_peek_range(self._handle), "bsr_peek_range")
+
     # -- test / measurement hooks -----------------------------------------------------------
     def probe(self, name: str) -> torch.Tensor:
         """Intermediate of the last forward as a dense NHWC tensor (see bsr_probe in include/bsr_hip.h)."""

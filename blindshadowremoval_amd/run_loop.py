@@ -35,6 +35,12 @@ def main(argv=None) -> int:
                                                               "GPU — how the world-2 loop is exercised on a one-GPU box (tests/test_fsrnet.py)")
     args = ap.parse_args(argv)
 
+    # Before ANYTHING initialises the HIP / HSA runtime (torch.cuda.is_available() below already does): the runtime reads this at
+    # start-up — the host driver only supports dmabuf IPC, and RCCL's buffer registration fails without it.  Set here, not after the
+    # device probe; never by re-exec'ing the process.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29641")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -54,9 +60,6 @@ def main(argv=None) -> int:
     grouped = world > 1 or os.environ.get("BSR_LOOP_FORCE_DIST") == "1"      # the latter: a ONE-rank process group (exercises the collective path on one GPU)
     if grouped:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29641")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:

@@ -83,6 +83,10 @@ int bsr_forward_tsm(bsr_handle* h, const float* inputs, const float* uv, const f
  * bsr_forward / bsr_forward_tsm refuse with BSR_ERR_RANGE once a completed forward has raised the flag.  Always BSR_OK on a
  * BSR_DTYPE_F32 handle.  (NaN inputs are not a range error; they propagate to the outputs.) */
 int bsr_check_range(bsr_handle* h, void* stream);
+/* The same condition WITHOUT synchronising and WITHOUT clearing it: BSR_ERR_RANGE if any forward that has completed so far raised the
+ * flag.  For pipelined callers that keep several forwards in flight and wait on their own events (FSRNet's loops): after the event of
+ * forward k, a set flag means forward k — or one submitted after it that has already finished — overflowed.  ABI 5. */
+int bsr_peek_range(bsr_handle* h);
 
 /* Bytes of activation workspace the library holds for a batch of B HxW images (grown lazily by
  * bsr_forward; growth synchronises the stream — call bsr_reserve first to keep forwards allocation-free). */
@@ -92,7 +96,9 @@ int bsr_reserve(bsr_handle* h, int B, int H, int W);
 
 /* Test hook: copy a named intermediate of the LAST forward (dense NHWC, real channel count) into dst
  * (device pointer, capacity cap_floats).  shape4 receives [B,H,W,C].  Names: x1 x2 x3 x0 res0..res5 up1 up2
- * y d32 bmask xh f1 f2 f att<i> y3x<i>.  shape4 is filled even when cap_floats is too small (BSR_ERR_ARG), so a caller can
+ * y d32 bmask xh f1 f2 f y3x<i> att<i> — att<i> (the attention output of block i) only exists when the last forward ran attention and the
+ * `w` GEMM as separate launches (small batches, the 16-bit modes, BSR_FUSE_ATTW=0); after a fused forward it never left LDS and the
+ * probe returns BSR_ERR_STATE.  shape4 is filled even when cap_floats is too small (BSR_ERR_ARG), so a caller can
  * size its buffer with a first call of capacity 0. */
 int bsr_probe(bsr_handle* h, const char* name, float* dst, size_t cap_floats, int shape4[4], void* stream);
 

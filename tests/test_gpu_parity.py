@@ -664,8 +664,13 @@ def test_range_guard_large_activations_and_overflow(dtype):
     big = [t.clone() for t in g32(inp * (4 * k), uv * (4 * k))]
     assert _max_activation(g32) > 7.0e4 and all(bool(torch.isfinite(t).all()) for t in big)     # the fp32 path stays finite
     g32.check_range()
+    g16.peek_range()                                   # the pipelined loops' form (no stream sync, no clear): nothing raised so far
     g16(inp * (4 * k), uv * (4 * k))
     torch.cuda.synchronize()
+    for _ in range(2):                                 # peek reports and does NOT clear
+        with pytest.raises(RangeError, match="fp16 range"):
+            g16.peek_range()
+    g32.peek_range()                                   # an fp32 handle never reports
     with pytest.raises(RangeError, match="fp16 range"):
         g16(inp, uv)                                   # the completed overflowing forward is not silent: the next call refuses
     with pytest.raises(RangeError):
@@ -841,3 +846,29 @@ def test_two_handles_on_two_streams_give_the_serial_result():
                 assert torch.equal(a, b)
     for g in gens:
         g.close()
+
+
+def test_att_probe_refuses_after_a_fused_forward(monkeypatch):
+    """At full fp32 batches attention and the `w` GEMM are ONE launch and the attention output never leaves LDS: bsr_probe("att<i>")
+    must say so (BSR_ERR_STATE) instead of copying whatever an earlier forward left in the workspace slot.  Forms that do write it
+    (small batches -> the 2-wave attention shape; BSR_FUSE_ATTW=0) still serve the probe, and both agree on the block outputs."""
+    from blindshadowremoval_amd import Generator
+    w = init_weights(1)
+    torch.manual_seed(63)
+    inp, uv = torch.rand(32, 256, 256, 3).cuda(), torch.rand(32, 256, 256, 3).cuda()
+    g = Generator(dtype="f32").load_weights(w)
+    g(inp[:2], uv[:2])                                 # B = 2: separate launches, the slot is written
+    att_small = g.probe("att0").clone()
+    assert att_small.shape == (2, 32, 32, 128) and float(att_small.abs().max()) > 0
+    g(inp, uv)                                         # B = 32: fused
+    with pytest.raises(RuntimeError, match="never left LDS"):
+        g.probe("att0")
+    res0 = g.probe("res0").clone()
+    g.close()
+    monkeypatch.setenv("BSR_FUSE_ATTW", "0")
+    g2 = Generator(dtype="f32").load_weights(w)
+    g2(inp, uv)
+    att = g2.probe("att0")
+    assert att.shape == (32, 32, 32, 128) and torch.equal(att[:2], att_small)
+    assert torch.equal(g2.probe("res0"), res0)
+    g2.close()

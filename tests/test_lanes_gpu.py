@@ -25,9 +25,9 @@ def test_streams_seen_to_overlap_do_overlap():
         return time.perf_counter() - t0
     if not ok:
         pytest.skip("concurrent_streams found no pair of streams it had seen overlapping on this box: nothing to check")
-    # overlapping spin kernels take ~0.5x, serialised ones 1.0x of one stream's time.  This is a WALL-CLOCK ratio on a shared box: it is
-    # measured up to three times, and a box too noisy to show the overlap skips the check (with the numbers) instead of failing the suite —
-    # the functional guarantee (two handles on two streams give the serial results) is test_gpu_parity's, not this one's.
+    # overlapping spin kernels take ~0.5x, serialised ones 1.0x of one stream's time.  A WALL-CLOCK ratio on a shared box, measured up
+    # to three times: clearly overlapping (< 0.85) passes; FULLY serialised in every attempt (>= 0.95: streams that were reported as
+    # overlapping share a hardware queue — the regression this test exists for) FAILS; only the ambiguous band in between skips.
     seen = []
     for _ in range(3):
         serial = min(spin(lanes[0], lanes[0]) for _ in range(5))
@@ -35,4 +35,6 @@ def test_streams_seen_to_overlap_do_overlap():
         seen.append((round(both * 1e3, 3), round(serial * 1e3, 3)))
         if both < 0.85 * serial:
             return
-    pytest.skip("the two streams did not show their overlap in three attempts (both vs serial, ms): %s" % seen)
+    assert not all(b >= 0.95 * s_ for b, s_ in seen), \
+        "streams reported as overlapping ran fully serialised in three attempts (both vs serial, ms): %s" % seen
+    pytest.skip("ambiguous: the two streams showed neither a clear overlap nor serialisation in three attempts (both vs serial, ms): %s" % seen)

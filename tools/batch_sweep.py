@@ -3,7 +3,7 @@
 B in {1, 2, 4, 8, 10, 16, 32} (fp32, one forward at a time on one stream; B = 10 is the reference's literal element,
 /root/reference/train_test_GSC.py:866-871, B = 16 BASELINE configs[2]).  Writes one JSON object.
 
-    python tools/batch_sweep.py [--out gpurun_out/r4_batch_sweep.json] [--dtype f32] [--graph]
+    python tools/batch_sweep.py [--out gpurun_out/r4_batch_sweep.json] [--dtype f32] [--batches 1,2,4,8,10,16,32] [--seconds 0.5]
 """
 import argparse
 import json
