@@ -34,9 +34,16 @@ constexpr int kAx3StageWords = kAttKT * kAx3LdK + kAttKT * kAx3LdV;    // one 32
 constexpr int kAx3SmemBytes = 4 * kAx3StageWords * 4;                  // two tile PAIRS (double buffer)
 static_assert(kAx3SmemBytes <= 160 * 1024, "LDS budget");
 static_assert(66 * 64 * 4 <= 4 * kAx3StageWords, "merge scratch fits the staging buffers");
+// FUSEW (round 5): the NonLocalBlock's `w` conv + BN + block residual + LeakyReLU as the TAIL of this kernel, as in attention.h — the
+// workgroup's 128 normalised query rows go through LDS (fp32, over the merge scratch) into the split A fragments of
+// gemm_tail_run<5, 4, 2>, the two key-stream wave groups take the channel tiles [0,5) / [5,9) of N = 288.  Same split, same
+// matrix-instruction order per output element as gemm_nloop_kernel<3, 4, 2> reading the attention output from HBM: bit-identical.
+constexpr int kAx3WSmemBytes = AttWCfg::SMEM_FLOATS * 4;
+static_assert(kAx3WSmemBytes <= 160 * 1024 && kAx3WSmemBytes >= kAx3SmemBytes, "LDS budget of the fused tail");
 
+template <bool FUSEW = false>
 __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens,
-                                                                       unsigned* __restrict__ range_flag) {
+                                                                       unsigned* __restrict__ range_flag, AttWArgs wa) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,6 +201,12 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
 
   // merge the two key streams: waves 4-7 hand (m, l, O^T) to waves 0-3 through LDS ([wq][66 values][64 lanes])
   __syncthreads();
+  // FUSEW: the staging buffers are dead from here on; the weight images of GEMM steps 0 and 1 and the bias are requested now, by all
+  // eight waves, so that their latency hides behind the merge (ring and bias live ABOVE the merge scratch / attention tile)
+  [[maybe_unused]] float* s_ring = smem + kTailAFloats;
+  [[maybe_unused]] float* s_bias = s_ring + 3 * kTailSlot;
+  [[maybe_unused]] GemmTailState<5, 4> tail;
+  if constexpr (FUSEW) gemm_tail_prefetch(tail, wa, s_bias, tid);
   float* sx = smem + (size_t)wq * 66 * 64 + lane;
   if (grp == 1) {
     sx[0] = m_run;
@@ -204,8 +217,11 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
       for (int i = 0; i < 16; ++i) sx[(2 + dt * 16 + i) * 64] = o[dt][i];
   }
   __syncthreads();
-  if (grp == 1) return;
-  {
+  if constexpr (!FUSEW) {
+    if (grp == 1) return;
+  }
+  float inv = 0.f;
+  if (grp == 0) {
     const float m1 = sx[0], l1 = sx[64];
     const float m = fmaxf(m_run, m1);
     const float s0 = __builtin_amdgcn_exp2f(m_run - m), s1 = __builtin_amdgcn_exp2f(m1 - m);
@@ -214,19 +230,37 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[dt][i] = o[dt][i] * s0 + sx[(2 + dt * 16 + i) * 64] * s1;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    inv = 1.f / l_tot;
   }
 
   // y[q][d], d = 32 dt + (i & 3) + 8 (i >> 2) + 4h: four consecutive channels per register quad
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_tot;
-  float* orow = out + ((size_t)img * tokens + q) * kAttD;
+  if constexpr (!FUSEW) {
+    float* orow = out + ((size_t)img * tokens + q) * kAttD;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 v = {o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv};
-      *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g4 + 4 * h) = v;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 v = {o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g4 + 4 * h) = v;
+      }
+  } else {
+    // ---- the `w` GEMM tail (gemm_tail.h, H = 2: gemm_nloop_kernel<3, 4, 2> with the activation tile coming through LDS instead of HBM) ----
+    __syncthreads();                                           // every read of the merge scratch is done: the attention tile may overwrite it
+    float* s_att = smem;                                       // [128 queries][kTailLdA] fp32: the values the unfused kernel stores as att
+    if (grp == 0) {
+      float* arow = s_att + (wq * 32 + r) * kTailLdA;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = {o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv};
+          *reinterpret_cast<f32x4*>(arow + 32 * dt + 8 * g4 + 4 * h) = v;
+        }
     }
+    const size_t tile_pix = (size_t)img * tokens + (size_t)qb * 128 + (size_t)__builtin_amdgcn_readfirstlane(wq) * 32;
+    gemm_tail_run<5, 4, 2>(tail, wa, s_att, s_ring, s_bias, grp, wq, tile_pix, lane);
+  }
 }
 
 inline hipError_t launch_nonlocal_attention_x3(const float* qkv, float* out, int batch, int tokens, hipStream_t stream, unsigned* range_flag = nullptr) {
@@ -234,12 +268,29 @@ inline hipError_t launch_nonlocal_attention_x3(const float* qkv, float* out, int
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nonlocal_attention_x3_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nonlocal_attention_x3_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kAx3SmemBytes);
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
-  hipLaunchKernelGGL(nonlocal_attention_x3_kernel, dim3(batch * (tokens / 128)), dim3(512), kAx3SmemBytes, stream, qkv, out, tokens, range_flag);
+  hipLaunchKernelGGL(nonlocal_attention_x3_kernel<false>, dim3(batch * (tokens / 128)), dim3(512), kAx3SmemBytes, stream, qkv, out, tokens, range_flag, AttWArgs{});
+  return hipGetLastError();
+}
+
+// attention + `w` GEMM tail in one launch, split precision (the 16-bit modes at any batch: this kernel has one workgroup shape)
+inline hipError_t launch_nonlocal_attention_x3_w(const float* qkv, int batch, int tokens, const AttWArgs& wa, hipStream_t stream, unsigned* range_flag = nullptr) {
+  if (tokens % (2 * kAttKT) != 0 || tokens % 128 != 0 || wa.n_pad < 12 * 32 || wa.n_store > 288 || wa.res_c > 288 || wa.out2 != nullptr) return hipErrorInvalidValue;
+  auto kern = nonlocal_attention_x3_kernel<true>;
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (dev < 0 || !once.done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kAx3WSmemBytes);
+    if (e != hipSuccess) return e;
+    if (dev >= 0) once.done[dev] = true;
+  }
+  AttWArgs w2 = wa;
+  w2.range_flag = range_flag;
+  hipLaunchKernelGGL(kern, dim3(batch * (tokens / 128)), dim3(512), kAx3WSmemBytes, stream, qkv, static_cast<float*>(nullptr), tokens, range_flag, w2);
   return hipGetLastError();
 }
 

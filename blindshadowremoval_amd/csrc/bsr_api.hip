@@ -716,10 +716,12 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
       L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
     }
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att))).
-    // fp32, full batches: ONE launch — the `w` GEMM runs as the tail of the attention kernel on the workgroup's own 128 pixels
-    // (attention.h, FUSEW; the attention output never goes to HBM).  Small batches (the 4- / 2-wave attention shapes) and the 16-bit
-    // modes keep the two launches; both forms give the same bits (tests/test_gpu_parity.py).
-    const bool fuse_w = h->dtype == BSR_DTYPE_F32 && h->fuse_attw && bsr::attention_auto_qw(B, H8 * W8) == 4;
+    // ONE launch — the `w` GEMM runs as the tail of the attention kernel on the workgroup's own 128 pixels (attention.h /
+    // attention_x3.h, FUSEW; the attention output never goes to HBM).  fp32 small batches (the 4- / 2-wave attention shapes) keep the
+    // two launches; both forms give the same bits (tests/test_gpu_parity.py).
+    // 16-bit modes (round 5): the same fusion on the split-precision kernels (attention_x3.h FUSEW + gemm_tail_run<.., H = 2>), at every batch
+    // (that kernel has one workgroup shape).
+    const bool fuse_w = h->fuse_attw && (h->dtype != BSR_DTYPE_F32 || bsr::attention_auto_qw(B, H8 * W8) == 4);
     h->att_in_lds = fuse_w;
     if (fuse_w && L.rc == BSR_OK) {
       LayerW l;
@@ -732,7 +734,10 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
         wa.out = r_out; wa.out_cs = o_cs; wa.n_store = o_cs < 288 ? o_cs : 288; wa.n_store1 = wa.n_store; wa.act = 1; wa.stagger = h->tail_stagger ? 1 : 0;
         snprintf(nm, sizeof nm, "res%d.attw", i);
         L.begin(K_ATT, nm);
-        L.check(bsr::launch_nonlocal_attention_w(ws + p.qkv, B, H8 * W8, wa, s), "attention+w");
+        if (h->dtype == BSR_DTYPE_F32)
+          L.check(bsr::launch_nonlocal_attention_w(ws + p.qkv, B, H8 * W8, wa, s), "attention+w");
+        else
+          L.check(bsr::launch_nonlocal_attention_x3_w(ws + p.qkv, B, H8 * W8, wa, s, h->range_flag), "attention_x3+w");
         L.end();
       }
     } else {

@@ -28,6 +28,7 @@ struct GemmTailArgs {
   int out2_cs, n_split, n_store;
   int act;               // 1: LeakyReLU(0.3)
   int stagger;           // 1: wave group 1 runs its SHORT channel group first, so that its epilogues fall into group 0's matrix phases
+  unsigned* range_flag;  // H = 2 (16-bit modes): the handle's sticky range flag (mfma_common.h range_report); may be null
 };
 
 constexpr int kTailLdA = 128 + 4;                   // floats per pixel row of the activation tile in LDS
@@ -108,28 +109,54 @@ __device__ __forceinline__ void gemm_tail_prefetch(GemmTailState<TA, TB>& st, co
 // The GEMM itself.  Preconditions: the activation tile is complete in s_a as far as THIS thread's own writes go (the function's
 // first barrier publishes it together with ring steps 0 and 1); gemm_tail_prefetch has run.  grp = wave group (0 / 1), wq = the
 // wave's 32-pixel row of the tile, tile_pix = flattened NHWC pixel index of that row's first pixel (its 32 pixels are consecutive).
-template <int TA, int TB>
+// H = 0: fp32 matrix cores.  H = 2 (round 5): the split-precision form of gemm_nloop_kernel<3, 4, 2> — the weight image is the fp16 one
+// of pack_taps_h16 (the same 36-word rows: 32 halves hi | 32 halves lo | pad, so the ring machinery above is shared), the A fragments
+// are read from the fp32 tile and split into hi / lo planes exactly as that kernel splits what it loads from HBM, and a 16-channel K
+// group costs three v_mfma_f32_32x32x16_f16 in its order (lo.hi, hi.lo, hi.hi): bit-identical to the separate launch.
+template <int TA, int TB, int H = 0>
 __device__ __forceinline__ void gemm_tail_run(GemmTailState<TA, TB>& st, const GemmTailArgs& a, const float* s_a, float* s_ring, const float* s_bias,
                                               int grp, int wq, size_t tile_pix, int lane) {
   using C = GemmTailCfg<TA, TB>;
-  constexpr int NI = C::NI, NCH = C::NCH, G = C::G, LDP = C::LDP, NSTEPS = C::NSTEPS;
+  constexpr int NI = C::NI, NCH = C::NCH, G = H ? 2 : C::G, LDP = C::LDP, NSTEPS = C::NSTEPS;
+  static_assert(H == 0 || H == 2, "fp32, or split precision on the fp16 matrix cores");
   const int h = lane >> 5, r = lane & 31;
   gemm_tail_store(st.loff, s_ring, 0, st.r0);
   gemm_tail_store(st.loff, s_ring, kTailSlot, st.r1);
   __syncthreads();
-  f32x4 afr[NCH * G];                                          // this lane's pixel, channels 8g + 4h .. +3
+  f32x4 afr[H ? 1 : NCH * G];                                  // this lane's pixel, channels 8g + 4h .. +3
+  f16x8 ahi[H ? NCH * G : 1], alo[H ? NCH * G : 1];            // H = 2: channels 16g + 8h .. +7, split
+  if constexpr (H == 0) {
 #pragma unroll
-  for (int g = 0; g < NCH * G; ++g) afr[g] = *reinterpret_cast<const f32x4*>(s_a + (wq * 32 + r) * kTailLdA + g * 8 + 4 * h);
+    for (int g = 0; g < NCH * G; ++g) afr[g] = *reinterpret_cast<const f32x4*>(s_a + (wq * 32 + r) * kTailLdA + g * 8 + 4 * h);
+  } else {
+    float amax = 0.f;
+#pragma unroll
+    for (int g = 0; g < NCH * G; ++g) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(s_a + (wq * 32 + r) * kTailLdA + g * 16 + 8 * h);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(s_a + (wq * 32 + r) * kTailLdA + g * 16 + 8 * h + 4);
+      split8(x0, x1, ahi[g], alo[g]);
+      amax = amax8(x0, x1, amax);
+    }
+    range_report(amax, a.range_flag);
+  }
   const int t0 = grp ? TA : 0, nt = grp ? TB : TA;             // this wave group's channel tiles [t0, t0 + nt)
   const bool short_first = grp && a.stagger;
   int b_base[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) b_base[ni] = grp * (96 * LDP) + (ni * 32 + r) * LDP + 4 * h;
   int w_cur = 0, w_n1 = kTailSlot, w_n2 = 2 * kTailSlot;
-  f32x4 bf[2][NI];
+  f32x4 bf[2][H ? 1 : NI];
+  f16x8 bh[2][H ? NI : 1], bl[2][H ? NI : 1];
   auto read_frags = [&](int slot, int b_off) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_ring + b_base[ni] + b_off);
+    for (int ni = 0; ni < NI; ++ni) {
+      if constexpr (H == 0) {
+        bf[slot][ni] = *reinterpret_cast<const f32x4*>(s_ring + b_base[ni] + b_off);
+      } else {
+        bh[slot][ni] = *reinterpret_cast<const f16x8*>(s_ring + b_base[ni] + b_off);
+        bl[slot][ni] = *reinterpret_cast<const f16x8*>(s_ring + b_base[ni] + b_off + 16);      // lo plane: 32 halves further
+      }
+    }
   };
   read_frags(0, w_cur);
   const bool has_res = a.res != nullptr;
@@ -163,12 +190,23 @@ __device__ __forceinline__ void gemm_tail_run(GemmTailState<TA, TB>& st, const G
         }
         if (g == G - 1 && has2) gemm_tail_store(st.loff, s_ring, w_n2, st.r0);
         __builtin_amdgcn_sched_barrier(0);
-        const f32x4 av = afr[ch * G + g];
+        if constexpr (H == 0) {
+          const f32x4 av = afr[ch * G + g];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          if (ni < nvalid) {
+          for (int ni = 0; ni < NI; ++ni) {
+            if (ni < nvalid) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bf[cur][ni][j], acc[ni], 0, 0, 0);
+              for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bf[cur][ni][j], acc[ni], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if (ni < nvalid) {
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ch * G + g], bh[cur][ni], acc[ni], 0, 0, 0);
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ch * G + g], bl[cur][ni], acc[ni], 0, 0, 0);
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ch * G + g], bh[cur][ni], acc[ni], 0, 0, 0);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -83,6 +83,53 @@ inline int device_cu_count() {
   return cus;
 }
 
+// ---- 16-bit matrix-core modes: operand split and range guard (used by igemm_h16.h, gemm_nloop.h, gemm_tail.h, attention_x3.h, conv_n16.h, stem7.h) ----
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+
+// hi = fp16(x) (round to nearest even), lo = fp16(x - hi).  Written on 2-wide vectors so that gfx950 selects its packed
+// conversions: v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32 = 5 VALU instructions per pair of values
+// (9 element by element).  The split runs beside the fp16 matrix stream and is what the 16-bit kernels are bound by once the
+// matrix work has shrunk by 16/3, so it is kept as lean as the ISA allows.
+__device__ __forceinline__ void split2(const f32x2 x, f16x2& hi, f16x2& lo) {
+  hi = __builtin_convertvector(x, f16x2);
+  lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), f16x2);
+}
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+  f16x2 h[4], l[4];
+  split2(f32x2{a[0], a[1]}, h[0], l[0]);
+  split2(f32x2{a[2], a[3]}, h[1], l[1]);
+  split2(f32x2{b[0], b[1]}, h[2], l[2]);
+  split2(f32x2{b[2], b[3]}, h[3], l[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[2 * i] = h[i][0]; hi[2 * i + 1] = h[i][1];
+    lo[2 * i] = l[i][0]; lo[2 * i + 1] = l[i][1];
+  }
+}
+
+// Range guard of the 16-bit modes.  fp16(x) is inf for |x| >= 65520 (round to nearest even; 65504 is the largest finite value), where
+// the fp32 path stays finite.  Every kernel that converts fp32 activations keeps the running maximum of their magnitudes — one
+// v_max3_f32 with |.| source modifiers per PAIR of values, beside the 5 instructions per pair of the split itself — and a thread that
+// saw an overflowing value stores 1 to the handle's sticky flag (host-visible memory: bsr_check_range / the next bsr_forward report
+// BSR_ERR_RANGE).  NaN inputs are not flagged (v_max drops them); they propagate to the outputs visibly.
+constexpr float kF16Overflow = 65520.f;
+__device__ __forceinline__ float amax8(const f32x4& a, const f32x4& b, float m) {
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1])), m);
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[2]), __builtin_fabsf(a[3])), m);
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(b[0]), __builtin_fabsf(b[1])), m);
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(b[2]), __builtin_fabsf(b[3])), m);
+  return m;
+}
+__device__ __forceinline__ float amax4(const f32x4& a, float m) {
+  m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[0]), __builtin_fabsf(a[1])), m);
+  return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a[2]), __builtin_fabsf(a[3])), m);
+}
+__device__ __forceinline__ void range_report(float m, unsigned* flag) {
+  if (m >= kF16Overflow && flag != nullptr) *flag = 1u;
+}
+
 struct ConvArgs {
   const float* in;      // NHWC activations, channel stride in_cs, first channel in_coff
   int in_cs, in_coff;

@@ -375,7 +375,11 @@ def test_per_launch_timing_names_every_layer(gen_w):
     entries = gen.get_launch_timing()
     gen.set_timing(False)
     names = [n for n, _, _ in entries]
-    assert set(bench.LAYER_MMAC) <= set(names), sorted(set(bench.LAYER_MMAC) - set(names))
+    covered1 = []
+    for n in names:                      # 16-bit modes: attention + w are one launch at every batch (round 5), fp32 only at full batches
+        covered1 += list(bench.FUSED_LAUNCHES.get(n, (n,) if n in bench.LAYER_MMAC else ()))
+    assert sorted(covered1) == sorted(bench.LAYER_MMAC), sorted(set(bench.LAYER_MMAC) ^ set(covered1))
+    assert ("res0.attw" in names) == (gen.dtype != "f32")
     assert all(ms > 0 for _, ms, _ in entries)
     assert abs(sum(bench.LAYER_MMAC.values()) - 9052.06) < 1.0          # SURVEY Appendix C total
     grouped = [n for layers in bench.KERNEL_GROUPS.values() for n in layers]
@@ -392,8 +396,7 @@ def test_per_launch_timing_names_every_layer(gen_w):
     for n in names32:
         covered += list(bench.FUSED_LAUNCHES.get(n, (n,) if n in bench.LAYER_MMAC else ()))
     assert sorted(covered) == sorted(bench.LAYER_MMAC), sorted(set(bench.LAYER_MMAC) ^ set(covered))
-    if gen.dtype == "f32":
-        assert "res0.attw" in names32
+    assert "res0.attw" in names32
 
 
 def test_handle_lifecycle_returns_its_memory():
@@ -820,6 +823,61 @@ def test_smallest_accepted_image(gen_w):
     inp, uv = torch.rand(3, 32, 256, 3), torch.rand(3, 32, 256, 3)
     out, ref, errs, nflip = run_and_compare(gen, w, inp, uv, want_probes=("x0", "res2", "res5"))
     assert out[0].shape == (3, 32, 256, 1)
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f16"])
+def test_fused_attention_w_tail_is_bit_identical_in_the_16_bit_modes(dtype, monkeypatch):
+    """Round 5: the split-precision attention kernel runs the `w` GEMM as its tail too (attention_x3.h FUSEW, gemm_tail_run<.., H = 2>):
+    the normalised attention tile goes through LDS in fp32 and is split into hi / lo fp16 planes exactly as gemm_nloop_kernel<3,4,2>
+    splits what it loads from HBM, same matrix-instruction order per output element => the same bits as the two-launch form on every
+    output and probe — at every batch (this kernel has one workgroup shape), GSC and the wider TSM trunk alike."""
+    from blindshadowremoval_amd import Generator, GeneratorTSM
+    w = init_weights(1)
+    fused = Generator(dtype=dtype).load_weights(w)
+    monkeypatch.setenv("BSR_FUSE_ATTW", "0")
+    plain = Generator(dtype=dtype).load_weights(w)
+    monkeypatch.delenv("BSR_FUSE_ATTW")
+    g = torch.Generator().manual_seed(73)
+    for (B, H, W) in ((32, 256, 256), (3, 256, 256), (2, 512, 512)):
+        inp, uv = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
+        fused.set_timing(True)
+        a = [t.clone() for t in fused(inp, uv)]
+        torch.cuda.synchronize()
+        names = [n for n, _, _ in fused.get_launch_timing()]
+        fused.set_timing(False)
+        assert "res0.attw" in names and "res5.attw" in names and "res0.w" not in names and "res0.attention" not in names, (B, H, W)
+        plain.set_timing(True)
+        b = plain(inp, uv)
+        torch.cuda.synchronize()
+        names_p = [n for n, _, _ in plain.get_launch_timing()]
+        plain.set_timing(False)
+        assert "res0.attention" in names_p and "res0.w" in names_p and "res0.attw" not in names_p
+        fused.check_range()
+        for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
+            assert torch.equal(x, y), (dtype, B, H, W, name)
+        for pr in ("res0", "res2", "res3", "res5"):
+            assert torch.equal(fused.probe(pr), plain.probe(pr)), (dtype, B, H, W, pr)
+        with pytest.raises(RuntimeError, match="never left LDS"):
+            fused.probe("att0")
+        assert plain.probe("att0").shape == (B, H // 8, W // 8, 128)
+    fused.close()
+    plain.close()
+    if dtype == "f32x3":
+        wt = init_weights(1, variant="tsm")
+        ft = GeneratorTSM(dtype=dtype).load_weights(wt)
+        monkeypatch.setenv("BSR_FUSE_ATTW", "0")
+        pt = GeneratorTSM(dtype=dtype).load_weights(wt)
+        monkeypatch.delenv("BSR_FUSE_ATTW")
+        inp, uv = torch.rand(4, 256, 256, 3, generator=g).cuda(), torch.rand(4, 256, 256, 3, generator=g).cuda()
+        reg = ((torch.rand(4, 256, 256, 6, generator=g) - 0.5) * 0.2).cuda()
+        a = [t.clone() for t in ft(inp, uv, reg, 2, True)]
+        b = pt(inp, uv, reg, 2, True)
+        for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
+            assert torch.equal(x, y), ("tsm", name)
+        for pr in ("res2", "res5"):
+            assert torch.equal(ft.probe(pr), pt.probe(pr)), ("tsm", pr)
+        ft.close()
+        pt.close()
 
 
 @pytest.mark.gpu
