@@ -17,7 +17,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed", "bsr_source_sha", "bsr_peek_range")
+           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed", "bsr_source_sha", "bsr_peek_range", "bsr_png_file_bytes", "bsr_png_scratch_bytes", "bsr_png_encode")
 
 
 def load() -> ctypes.CDLL:
@@ -25,14 +25,14 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(_build.LIB_PATH):
+    if not os.path.isfile(LIB_PATH):
         raise RuntimeError("libbsr_hip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "— the HIP path has no fallback" % _build.LIB_PATH)
+                           "— the HIP path has no fallback" % LIB_PATH)
     try:
         import torch  # noqa: F401  (loads libamdhip64 first; our DT_NEEDED then resolves to the same runtime)
     except ImportError:
         pass
-    lib = ctypes.CDLL(_build.LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
     # The binary is bound to its sources: build.py compiles the hash of csrc/* + include/bsr_hip.h into it.  A library built from
     # other sources than this tree holds (the .so is git-ignored and travels as a built artefact) is refused — tests and bench lines
     # can then only ever describe the kernels that are in the tree.
@@ -82,6 +82,12 @@ def load() -> ctypes.CDLL:
     lib.bsr_prep_rows.restype = c_i
     lib.bsr_check_range.argtypes = [c_v, c_v]
     lib.bsr_check_range.restype = c_i
+    lib.bsr_png_file_bytes.argtypes = [c_i, c_i]
+    lib.bsr_png_file_bytes.restype = c_sz
+    lib.bsr_png_scratch_bytes.argtypes = [c_i]
+    lib.bsr_png_scratch_bytes.restype = c_sz
+    lib.bsr_png_encode.argtypes = [c_i, c_v, c_i, c_i, c_i, c_v, c_sz, c_v, c_v]
+    lib.bsr_png_encode.restype = c_i
     lib.bsr_peek_range.argtypes = [c_v]
     lib.bsr_peek_range.restype = c_i
     lib.bsr_destroy.argtypes = [c_v]

@@ -21,6 +21,7 @@
 #include "igemm_conv.h"
 #include "igemm_h16.h"
 #include "igemm_s2p.h"
+#include "png_kernels.h"
 #include "prep_kernels.h"
 #include "stem7.h"
 
@@ -154,6 +155,7 @@ struct bsr_handle {
   bool fuse_c3q = false;         // env BSR_FUSE_C3Q=1: res*.conv2 with the conv3 | theta|phi|g GEMM as its tail (one launch).  Built, bit-identical, and
                                  // OFF: one forward at a time it is 0.2 % faster, with two forwards in flight 0.8 % slower (its 150-KB, 8-wave workgroups
                                  // leave the other lane's kernels no room on the CU) — profiles/HISTORY.md, round 4
+  bool conv1_gemm = true;        // env BSR_CONV1_GEMM=0: res*.conv1 of the 16-bit modes on the implicit-GEMM kernel at every batch (A/B measurements, bit-identity tests)
   bool fuse_attw = true;         // env BSR_FUSE_ATTW=0: attention and the `w` GEMM as two launches (A/B measurements, bit-identity tests)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
@@ -467,6 +469,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   h->dtype = dtype;
   if (const char* e_ = getenv("BSR_FUSE_HEADS")) h->fuse_heads = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_FUSE_ATTW")) h->fuse_attw = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_CONV1_GEMM")) h->conv1_gemm = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_FUSE_C3Q")) h->fuse_c3q = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_TAIL_STAGGER")) h->tail_stagger = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_S2_PERSIST")) h->s2_persist = atoi(e_) != 0;
@@ -688,6 +691,26 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     share_layer(ws + p.xa, V.cs_a, 96, ws + p.xa, V.cs_a, 96);
   }
 
+  // res*.conv1 (1x1, 99|257|261 -> 128, + BN + LeakyReLU) in the 16-bit modes at full batches: the resident-activation GEMM with ONE
+  // workgroup per CU and all of N per workgroup (gemm_nloop.h, MINW = 1) — same split, same matrix-instruction order per output
+  // element as igemm_h16_kernel<1,1,1,..,NSPLIT = 2>: the same bits
+  auto conv1_gemm = [&](const char* nm, const float* x, int x_cs) -> bool {
+    if (h->dtype == BSR_DTYPE_F32 || V.tsm || !h->conv1_gemm || L.rc != BSR_OK) return false;
+    if (ncell % 128 != 0 || (long long)(ncell / 128) * 2 < bsr::device_cu_count() || (x_cs != 128 && x_cs != 288)) return false;
+    LayerW l;
+    L.rc = find_layer(h, nm, x_cs / 32, 1, 36, 128, &l);
+    if (L.rc != BSR_OK) return true;
+    bsr::ConvArgs a{};
+    a.in = x; a.in_cs = x_cs; a.in_coff = 0; a.out = ws + p.t1; a.out_cs = 128; a.out_coff = 0;
+    a.w = l.w; a.bias = l.b; a.nchunk = l.nchunk; a.n_pad = l.n_pad; a.n_store = 128; a.act = 1;
+    a.range_flag = h->range_flag;
+    L.begin(K_CONV1, nm);
+    if (x_cs == 128) L.check(bsr::launch_gemm_nloop<4, 4, 2, 1>(a, ncell, 1, s), nm);
+    else L.check(bsr::launch_gemm_nloop<4, 9, 2, 1>(a, ncell, 1, s), nm);
+    L.end();
+    return true;
+  };
+
   // ResBottleneck + NonLocalBlock (model.py:98-113, 23-61)
   auto res_block = [&](int i, const float* x, int x_cs, int x_c) {
     float* r_out = ws + p.r[i];
@@ -695,7 +718,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     char nm[32];
     float* y3 = ws + p.y3[i];
     snprintf(nm, sizeof nm, "res%d.conv1", i);
-    L.conv<1, 1, 1, false, 2, 24, 3>(K_CONV1, nm, x, x_cs, 0, x_cs, H8, W8, ws + p.t1, 128, 0, 128, 1);
+    if (!conv1_gemm(nm, x, x_cs)) L.conv<1, 1, 1, false, 2, 24, 3>(K_CONV1, nm, x, x_cs, 0, x_cs, H8, W8, ws + p.t1, 128, 0, 128, 1);
     // conv3+BN (128 -> 257 = y3) and theta|phi|g (257 -> 3x128, no activation in between: model.py:101,33-46) are ONE
     // K = 128 GEMM: the qkv weights are composed offline with conv3's (pack.py), N = [y3 288 | qkv 384].  The y3 output also absorbs
     // the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
@@ -830,6 +853,25 @@ int bsr_prep_rows(int device, const void* d_blob, size_t blob_bytes, size_t rows
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(bsr::prep_blur_kernel, grid, dim3(256), 0, s, hull_tmp, S, out);
   HIP_TRY(hipGetLastError());
+  return BSR_OK;
+}
+
+size_t bsr_png_file_bytes(int H, int W) {
+  bsr::PngGeom g;
+  return bsr::png_geometry(H, W, &g) ? (size_t)g.file_bytes : 0;
+}
+
+size_t bsr_png_scratch_bytes(int B) { return B > 0 ? (size_t)B * 4 * sizeof(unsigned long long) : 0; }
+
+int bsr_png_encode(int device, const unsigned char* pixels, int B, int H, int W, unsigned char* out, size_t out_stride, void* scratch, void* stream) {
+  if (pixels == nullptr || out == nullptr || scratch == nullptr) return fail(BSR_ERR_ARG, "bsr_png_encode: null argument");
+  bsr::PngGeom g;
+  if (B <= 0 || !bsr::png_geometry(H, W, &g)) return fail(BSR_ERR_ARG, "bsr_png_encode: B, H, W must be positive, W <= 5461 and H <= 65535");
+  if (out_stride < g.file_bytes) return fail(BSR_ERR_ARG, "bsr_png_encode: out_stride is smaller than bsr_png_file_bytes(H, W)");
+  if (reinterpret_cast<uintptr_t>(scratch) % 8 != 0) return fail(BSR_ERR_ARG, "bsr_png_encode: scratch must be 8-byte aligned");
+  DeviceGuard guard(device);
+  HIP_TRY(guard.err);
+  HIP_TRY(bsr::launch_png_encode(pixels, B, g, out, out_stride, static_cast<unsigned long long*>(scratch), static_cast<hipStream_t>(stream)));
   return BSR_OK;
 }
 

@@ -31,8 +31,13 @@ struct GemmNLoopCfg {
 // ConvArgs use: in/in_cs/in_coff (K = NCH*32 channels), pixels flattened (multiple of 128),
 // w packed [NCH][1][n_pad][36] with n_pad >= 32 * (tiles + NI - 1), bias[n_pad], out/out_cs/out_coff/n_store
 // (+ out2/n_split/n_store1), act, res1 (one residual, channels [0, res1_c)).  tiles_x = tiles per blockIdx.y range.
-template <int NI, int NCH, int H = 0>
-__global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
+// MINW = waves per SIMD the register budget is sized for.  2 (default): two workgroups share a CU.  1 (round 5, res*.conv1 in the 16-bit
+// modes: K = 288, N = 128): ONE workgroup per CU keeps 32 pixels x 288 channels per wave resident — 36 16-byte loads per lane, all in
+// flight at once (147 KB per CU: the input is read exactly once, at full memory-level parallelism) — and computes all of N from them.
+// The implicit-GEMM form of that layer took its input through a 3-slot LDS ring two 0.16-us steps ahead of an L2 / HBM round trip, in
+// two N blocks that each fetched and split the tile: 27 us against ~11 of HBM time.
+template <int NI, int NCH, int H = 0, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
   using C = GemmNLoopCfg<NI, NCH, H>;
   constexpr int LDP = C::LDP, G = C::G;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -267,10 +272,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nloop_kernel(ConvArgs p) {
 #endif
 }
 
-template <int NI, int NCH, int H = 0>
+template <int NI, int NCH, int H = 0, int MINW = 2>
 inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, int nsplit, hipStream_t stream) {
   using C = GemmNLoopCfg<NI, NCH, H>;
-  auto kern = gemm_nloop_kernel<NI, NCH, H>;
+  auto kern = gemm_nloop_kernel<NI, NCH, H, MINW>;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {

@@ -1,0 +1,232 @@
+// PNG files of the test loops' figure strips, built ON THE DEVICE (round 5).
+//
+// The reference's loops end every item with `cv2.imwrite` of an 8-bit RGB strip (/root/reference/utils.py:196-204, called from
+// train_test_GSC.py:744-746, :889-890).  Rounds 2-4 encoded those strips on the host (pngio.py: Sub filter + zlib RLE, ~4 ms of CPU
+// per 256x768 strip, ~9 ms per 256x1792 UCB strip): with the forward at 6 000+ images/s that encoder, not the GPU, set the loops'
+// rate.  PNG is lossless, so any conforming file gives the reference's pixels back; this writer produces the simplest conforming
+// file — filter type 0 on every scanline, the zlib stream as STORED deflate blocks — whose byte layout is a pure function of
+// (H, W): every pixel byte has a fixed position, and the only data-dependent bytes are the zlib Adler-32 and the IDAT CRC-32, both
+// of which reduce in parallel.  The host's share becomes one write() per file.
+//
+//   file = signature(8) | IHDR chunk(25) | IDAT length(4) "IDAT"(4) | zlib: 78 01 | blocks | adler32(4) | crc32(4) | IEND chunk(12)
+//   block b = 5-byte header (BFINAL, LEN, ~LEN) + R whole scanlines (R = 65535 / (1 + 3W)), scanline = 00 | W x RGB
+//
+// png_rows_kernel: one wave per scanline.  The wave assembles the scanline's bytes of the FILE (with the block header / the chunk
+// head in front of it where one starts there) in LDS, copies them out, and reduces its part of the two checksums:
+//   * CRC-32 (reflected, poly 0xEDB88320): the register after a message is linear in (initial register, message), so
+//     crc(A | B) = shift(crc(A), |B|) ^ crc_0(B) with shift(c, n) = c * x^(8n) mod P — zlib's crc32_combine, restated: multmodp / x2nmodp
+//     below.  Every lane runs the table-driven byte loop over its piece (the stream's first piece starts from 0xFFFFFFFF, all others
+//     from 0), shifts the result to the END of the checksummed stream and the pieces are XORed together: a wave reduction, then one
+//     atomicXor per scanline — XOR is order-independent, so the result is deterministic.
+//   * Adler-32 over the n raw bytes d_0 .. d_{n-1}: A = 1 + sum d_j, B = n + sum (n - j) d_j (mod 65521): two integer sums, 64-bit atomics.
+// png_finish_kernel: one thread per file folds the accumulators, runs the 4 Adler bytes through the CRC and writes the fixed bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bsr {
+
+constexpr unsigned kCrcPoly = 0xEDB88320u;
+
+// a(x) * b(x) mod P(x), bit-reflected representation (bit 31 = x^0): zlib crc32.c's multmodp
+__host__ __device__ inline unsigned crc_multmodp(unsigned a, unsigned b) {
+  unsigned m = 1u << 31, p = 0u;
+  for (;;) {
+    if (a & m) {
+      p ^= b;
+      if ((a & (m - 1u)) == 0u) break;
+    }
+    m >>= 1;
+    b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+  }
+  return p;
+}
+
+struct PngGeom {
+  int H, W;                 // pixels
+  int RB;                   // raw bytes per scanline: 1 + 3 W
+  int R;                    // scanlines per stored block
+  int nblocks;
+  unsigned zlen;            // bytes of the zlib stream (IDAT data)
+  unsigned file_bytes;
+  unsigned ihdr_crc;
+  unsigned x2n[32];         // x^(2^k) mod P
+};
+
+__host__ __device__ inline unsigned crc_update_byte(unsigned c, unsigned byte) {     // bitwise form (host, and the finish kernel's few bytes)
+  c ^= byte;
+  for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+  return c;
+}
+
+inline bool png_geometry(int H, int W, PngGeom* g) {
+  if (H <= 0 || W <= 0 || (long long)3 * W + 1 > 16384 || H > 65535) return false;      // a scanline must fit the per-wave LDS segment
+  g->H = H; g->W = W;
+  g->RB = 1 + 3 * W;
+  g->R = 65535 / g->RB;
+  g->nblocks = (H + g->R - 1) / g->R;
+  g->zlen = 2u + 5u * (unsigned)g->nblocks + (unsigned)H * (unsigned)g->RB + 4u;
+  g->file_bytes = 8u + 25u + 8u + g->zlen + 4u + 12u;
+  const unsigned char ihdr[17] = {'I', 'H', 'D', 'R', (unsigned char)(W >> 24), (unsigned char)(W >> 16), (unsigned char)(W >> 8), (unsigned char)W,
+                                  (unsigned char)(H >> 24), (unsigned char)(H >> 16), (unsigned char)(H >> 8), (unsigned char)H, 8, 2, 0, 0, 0};
+  unsigned c = 0xFFFFFFFFu;
+  for (int i = 0; i < 17; ++i) c = crc_update_byte(c, ihdr[i]);
+  g->ihdr_crc = c ^ 0xFFFFFFFFu;
+  unsigned p = 1u << 30;                                     // x^1
+  g->x2n[0] = p;
+  for (int k = 1; k < 32; ++k) g->x2n[k] = p = crc_multmodp(p, p);
+  return true;
+}
+
+// c * x^(8 n) mod P: the CRC register c moved past n further (zero) bytes — zlib's x2nmodp(n, 3) folded into the product
+__device__ inline unsigned crc_shift_bytes(const PngGeom& g, unsigned c, unsigned n) {
+  unsigned k = 3;
+  while (n) {
+    if (n & 1u) c = crc_multmodp(g.x2n[k & 31], c);
+    n >>= 1;
+    ++k;
+  }
+  return c;
+}
+
+constexpr int kPngSegMax = 16384 + 16;                        // LDS bytes per wave: a scanline + the headers that may precede it
+constexpr int kPngWaves = 4;
+
+// pixels: [B][H][W][3] uint8 (device).  out: B files, `stride` bytes apart.  acc: [B][4] 64-bit words, zeroed: {sum d, sum (n - j) d, crc xor, -}
+__global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __restrict__ pixels, unsigned char* __restrict__ out, size_t stride,
+                                                       unsigned long long* __restrict__ acc, PngGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char png_smem[];
+  unsigned* s_tab = reinterpret_cast<unsigned*>(png_smem);                       // 256-entry CRC table
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* seg = png_smem + 1024 + (size_t)wave * kPngSegMax;
+  {
+    unsigned c = (unsigned)tid;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+    s_tab[tid] = c;
+  }
+  const int item = blockIdx.y;
+  const int y = blockIdx.x * kPngWaves + wave;
+  const bool live = y < g.H;
+  // the scanline's place in the file, and what precedes it inside this wave's segment
+  int hdr = 0;                                               // bytes of the segment in front of the scanline
+  unsigned file_off = 0;                                     // file offset of the segment's first byte
+  if (live) {
+    const int blk = y / g.R;
+    const unsigned row_off = 8u + 25u + 8u + 2u + 5u * (unsigned)(blk + 1) + (unsigned)y * (unsigned)g.RB;
+    if (y % g.R == 0) hdr = 5;
+    if (y == 0) hdr = 5 + 2 + 4;                             // "IDAT" | 78 01 | block header
+    file_off = row_off - (unsigned)hdr;
+    if (lane == 0) {
+      int o = 0;
+      if (y == 0) {
+        seg[0] = 'I'; seg[1] = 'D'; seg[2] = 'A'; seg[3] = 'T'; seg[4] = 0x78; seg[5] = 0x01;
+        o = 6;
+      }
+      if (hdr) {
+        const int rows = min(g.R, g.H - blk * g.R);
+        const unsigned len = (unsigned)rows * (unsigned)g.RB;
+        seg[o] = (blk == g.nblocks - 1) ? 1 : 0;             // BFINAL, BTYPE = 00 (stored)
+        seg[o + 1] = (unsigned char)len; seg[o + 2] = (unsigned char)(len >> 8);
+        seg[o + 3] = (unsigned char)~len; seg[o + 4] = (unsigned char)(~len >> 8);
+      }
+      seg[hdr] = 0;                                          // filter type 0 (None)
+    }
+    const unsigned char* src = pixels + ((size_t)item * g.H + y) * (size_t)(3 * g.W);
+    const int nb = 3 * g.W;
+    if (((3 * g.W) & 3) == 0 && (reinterpret_cast<uintptr_t>(pixels) & 3) == 0) {
+      const unsigned* src4 = reinterpret_cast<const unsigned*>(src);
+      for (int i = lane; i < nb / 4; i += 64) {
+        const unsigned v = src4[i];
+        unsigned char* d = seg + hdr + 1 + 4 * i;
+        d[0] = (unsigned char)v; d[1] = (unsigned char)(v >> 8); d[2] = (unsigned char)(v >> 16); d[3] = (unsigned char)(v >> 24);
+      }
+    } else {
+      for (int i = lane; i < nb; i += 64) seg[hdr + 1 + i] = src[i];
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const int seg_len = hdr + g.RB;
+  // copy the segment to the file image
+  unsigned char* dst = out + (size_t)item * stride + file_off;
+  for (int i = lane; i < seg_len; i += 64) dst[i] = seg[i];
+  // checksums: lane l owns bytes [l * chunk, (l + 1) * chunk) of the segment
+  const int chunk = (seg_len + 63) / 64;
+  const int b0 = min(lane * chunk, seg_len), b1 = min(b0 + chunk, seg_len);
+  unsigned c = (y == 0 && lane == 0) ? 0xFFFFFFFFu : 0u;     // the checksummed stream starts with "IDAT"
+  unsigned long long sa = 0, sb = 0;
+  const unsigned long long n_raw = (unsigned long long)g.H * (unsigned long long)g.RB;
+  const long long raw0 = (long long)y * g.RB - hdr;         // raw index of segment byte 0 (header bytes are not raw data)
+  for (int i = b0; i < b1; ++i) {
+    const unsigned d = seg[i];
+    c = s_tab[(c ^ d) & 0xFFu] ^ (c >> 8);
+    if (i >= hdr) {
+      sa += d;
+      sb += (n_raw - (unsigned long long)(raw0 + i)) * d;
+    }
+  }
+  // shift this piece to the end of the checksummed stream (just before the Adler bytes): stream = "IDAT" + zlib stream - adler
+  const unsigned stream_pos = file_off - 37u + (unsigned)b1;                     // bytes of the stream up to and including this piece ("IDAT" sits at file offset 37)
+  const unsigned stream_end = 4u + g.zlen - 4u;
+  unsigned contrib = (b1 > b0) ? crc_shift_bytes(g, c, stream_end - stream_pos) : 0u;
+  for (int o = 32; o >= 1; o >>= 1) {
+    contrib ^= __shfl_xor(contrib, o);
+    sa += __shfl_xor(sa, o);
+    sb += __shfl_xor(sb, o);
+  }
+  if (lane == 0) {
+    unsigned long long* a = acc + (size_t)item * 4;
+    atomicAdd(a, sa);
+    atomicAdd(a + 1, sb);
+    atomicXor(reinterpret_cast<unsigned*>(a + 2), contrib);
+  }
+}
+
+__global__ void png_finish_kernel(unsigned char* __restrict__ out, size_t stride, const unsigned long long* __restrict__ acc, PngGeom g, int B) {
+  const int item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= B) return;
+  unsigned char* f = out + (size_t)item * stride;
+  const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  for (int i = 0; i < 8; ++i) f[i] = sig[i];
+  auto be32 = [&](unsigned off, unsigned v) { f[off] = (unsigned char)(v >> 24); f[off + 1] = (unsigned char)(v >> 16); f[off + 2] = (unsigned char)(v >> 8); f[off + 3] = (unsigned char)v; };
+  be32(8, 13u);
+  f[12] = 'I'; f[13] = 'H'; f[14] = 'D'; f[15] = 'R';
+  be32(16, (unsigned)g.W);
+  be32(20, (unsigned)g.H);
+  f[24] = 8; f[25] = 2; f[26] = 0; f[27] = 0; f[28] = 0;     // 8 bits, truecolour, deflate, adaptive filtering, no interlace
+  be32(29, g.ihdr_crc);
+  be32(33, g.zlen);
+  const unsigned long long* a = acc + (size_t)item * 4;
+  const unsigned long long n_raw = (unsigned long long)g.H * (unsigned long long)g.RB;
+  const unsigned A = (unsigned)((1ull + a[0]) % 65521ull), Bv = (unsigned)((n_raw + a[1]) % 65521ull);
+  const unsigned adler = (Bv << 16) | A;
+  const unsigned tail = 41u + g.zlen - 4u;                   // file offset of the Adler-32
+  be32(tail, adler);
+  unsigned c = (unsigned)a[2];
+  for (int i = 0; i < 4; ++i) c = crc_update_byte(c, f[tail + i]);
+  be32(tail + 4, c ^ 0xFFFFFFFFu);
+  be32(tail + 8, 0u);
+  f[tail + 12] = 'I'; f[tail + 13] = 'E'; f[tail + 14] = 'N'; f[tail + 15] = 'D';
+  be32(tail + 16, 0xAE426082u);
+}
+
+inline hipError_t launch_png_encode(const unsigned char* pixels, int B, const PngGeom& g, unsigned char* out, size_t stride,
+                                    unsigned long long* acc, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * 4 * sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  const int smem = 1024 + kPngWaves * kPngSegMax;
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (dev < 0 || !once.done[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    if (dev >= 0) once.done[dev] = true;
+  }
+  hipLaunchKernelGGL(png_rows_kernel, dim3((unsigned)((g.H + kPngWaves - 1) / kPngWaves), (unsigned)B), dim3(256), smem, stream, pixels, out, stride, acc, g);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(png_finish_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, out, stride, acc, g, B);
+  return hipGetLastError();
+}
+
+}  // namespace bsr

@@ -71,6 +71,13 @@ class Logging(object):
         self._png_threads = png_threads
         self._pool = None
         self._pending: List = []
+        # gpu_png (round 5): the strips become complete PNG FILES on the device (gpu_png.py / csrc/png_kernels.h: stored deflate, checksums
+        # computed there) and come over as bytes; the host only write()s them, from `file_threads` threads (write releases the GIL).  The
+        # pipelined loops switch it on when the generator lives on a GPU; png_threads / png_workers are the host encoders it replaces.
+        self.gpu_png = False
+        self.file_threads = 4
+        self._encoders: Dict[int, object] = {}
+        self._file_pool = None
 
     @staticmethod
     def accumulate(acc: Dict[str, List[float]], losses: Dict[str, float]) -> None:
@@ -119,6 +126,41 @@ class Logging(object):
             a = torch.clamp(f.detach().float(), 0.0, 1.0) * 255.0
             cols.append(a.expand(-1, -1, -1, 3) if a.shape[3] == 1 else a[..., :3])
         return torch.round(torch.cat(cols, dim=2)).to(torch.uint8)
+
+    def files_on_device(self, figs: Sequence[torch.Tensor]) -> torch.Tensor:
+        """strips_on_device + the PNG encoding itself on the device: uint8 [B, file_bytes] — row j is the complete PNG file of item j's
+        strip (decodes to exactly get_imgs' pixels)."""
+        strips = self.strips_on_device(figs)
+        dev = strips.device.index
+        if dev not in self._encoders:
+            from .gpu_png import StripEncoder
+            self._encoders[dev] = StripEncoder(dev)
+        return self._encoders[dev].encode(strips)
+
+    def save_files(self, files: np.ndarray, names: Sequence[str]) -> List:
+        """Write the PNG files of one batch (`files`: uint8 [B, file_bytes], e.g. a view of pinned memory the device copy landed in) under
+        the names save_img would give them.  Returns the write futures: the caller must not reuse the memory behind `files` before they
+        are done (flush() waits for all of them too)."""
+        if self._file_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._file_pool = ThreadPoolExecutor(max_workers=max(1, self.file_threads), thread_name_prefix="bsr-file")
+            os.makedirs(os.path.join(self.config.CHECKPOINT_DIR, 'test'), exist_ok=True)
+
+        def put(path, row):
+            with open(path, "wb", buffering=0) as f:
+                f.write(memoryview(row))
+        futs = []
+        for j, name in enumerate(names):
+            out = self._png_path(name)
+            self.saved.append(out)
+            futs.append(self._file_pool.submit(put, out, files[j]))
+        self._pending.extend(futs)
+        if len(self._pending) > 4096:            # keep the list of finished futures short (exceptions surface here or in flush())
+            done = [f for f in self._pending if f.done()]
+            for f in done:
+                f.result()
+            self._pending = [f for f in self._pending if not f.done()]
+        return futs
 
     def _png_path(self, fname: str) -> str:
         parts = fname.replace('\\', '/').split('/')
@@ -261,6 +303,9 @@ class Logging(object):
             if self._pool is not None:
                 self._pool.shutdown(wait=True)
                 self._pool = None
+            if self._file_pool is not None:
+                self._file_pool.shutdown(wait=True)
+                self._file_pool = None
             if self._png_pool is not None:
                 self._png_pool.shutdown()
                 self._png_pool = None
@@ -374,6 +419,9 @@ class FSRNet(object):
             if weights is not None:
                 self.gen.load_weights(weights)
         self.log = Logging(config, png_threads=4)
+        # PNG strips are built as complete files ON THE DEVICE when the generator lives on one (gpu_png.py); False: the host encoders
+        # (png_threads / png_workers) of rounds 2-4 — same pixels either way
+        self.log.gpu_png = getattr(self.gen, "_device", None) is not None and torch.cuda.is_available()
         self.shm_ring = True                     # device-to-host copies of pool-bound batches land in pinned shared-memory slots (_ShmPinnedRing); False: private pinned buffers + a file copy
         self.gpu_inflight = 2                    # batches whose forward + device-to-host copy may be outstanding while the loop feeds the next one
         self.all_losses: List[Tuple[str, Dict[str, float]]] = []      # (name, losses) of EVERY item in list order — on every rank after a data-parallel loop
@@ -511,6 +559,8 @@ class FSRNet(object):
         on_gpu = dev != "cpu"
         depth = max(0, int(self.gpu_inflight)) if on_gpu else 0
         pins: List[Optional[torch.Tensor]] = [None] * (depth + 1)      # pinned staging buffers, one per batch that may be outstanding (+ the one being filled)
+        pin_busy: List[List] = [[] for _ in range(depth + 1)]          # file writes still reading a pinned buffer (gpu_png): waited for before its turn comes again
+        gpu_png = on_gpu and self.log.gpu_png
         gpu_q: List[Tuple] = []             # submitted batches whose device-to-host copy may still be running, oldest first
         turn = [0]
         # batches bound for a worker pool (PNG strips, UCB post-processing) are copied device -> a pinned SHARED-MEMORY slot the workers
@@ -578,7 +628,7 @@ class FSRNet(object):
                 slot = ring.acquire()
             return slot
 
-        def to_host_async(payload: torch.Tensor, to_pool: bool = False):
+        def to_host_async(payload: torch.Tensor, to_pool: bool = False, pin_id: bool = False):
             """-> (numpy view of the payload on the host, event | None, ring slot | None).  GPU: an asynchronous copy into this batch's
             pinned buffer; the view is valid once the event has completed and until the buffer's turn comes again (depth + 1
             submissions later) — or, in a ring slot, until the slot is released."""
@@ -594,13 +644,16 @@ class FSRNet(object):
                 return view.numpy(), ev, slot
             k = turn[0]
             turn[0] = (k + 1) % len(pins)
+            for fu in pin_busy[k]:                # the file writes of the batch that used this buffer depth + 1 submissions ago
+                fu.result()
+            pin_busy[k] = []
             if pins[k] is None or pins[k].numel() < nbytes:
                 pins[k] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
             view = pins[k][:nbytes].view(payload.dtype).reshape(payload.shape)
             view.copy_(payload, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            return view.numpy(), ev, None
+            return view.numpy(), ev, (-1 - k if pin_id else None)       # pin_id: the "slot" names the private pinned buffer (negative), for pin_busy
 
         def submit():
             """one batch: rows -> device -> generator -> what the host needs, on its way to pinned memory; nothing here waits for the GPU"""
@@ -626,7 +679,10 @@ class FSRNet(object):
                 else:
                     figs_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]        # train_test_GSC.py:872-873,889
                     shown_b = figs_b
-                host, ev, slot = to_host_async(self.log.strips_on_device(shown_b), to_pool=self.log.png_workers > 0)
+                if gpu_png:                       # complete PNG files built on the device; the host only writes them
+                    host, ev, slot = to_host_async(self.log.files_on_device(shown_b), to_pool=False, pin_id=True)
+                else:
+                    host, ev, slot = to_host_async(self.log.strips_on_device(shown_b), to_pool=self.log.png_workers > 0)
             gpu_q.append((items, host, ev, figs_b, slot))
             tm["forward_s"] += time.perf_counter() - t0
             tm["forwards"] += 1
@@ -691,7 +747,9 @@ class FSRNet(object):
                 tm["post_s"] += time.perf_counter() - t1
                 finish(items, post)
                 return
-            if slot is not None:                    # the strips already sit in a shared-memory slot: the PNG workers read them there
+            if gpu_png and slot is not None and slot < 0:
+                pin_busy[-1 - slot] = self.log.save_files(host, [it[1] for it in items])
+            elif slot is not None:                  # the strips already sit in a shared-memory slot: the PNG workers read them there
                 self.log.save_strips(host, [it[1] for it in items], parked=(ring.path(slot), lambda k=slot: ring.release(k)))
             else:
                 strips = host if self.log.png_workers > 0 else np.array(host)      # the worker path copies into shared memory at once; writer threads keep the array

@@ -41,6 +41,43 @@ def encode_png(a: np.ndarray) -> bytes:
                      _chunk(b"IEND", b"")))
 
 
+def stored_layout(h: int, w: int):
+    """(scanline bytes, scanlines per stored block, blocks, zlib-stream bytes, file bytes) of the STORED-deflate RGB file the device
+    encoder writes (csrc/png_kernels.h: its layout is a pure function of H and W)."""
+    rb = 1 + 3 * w
+    r = 65535 // rb
+    if r < 1:
+        raise ValueError("a %d-pixel scanline does not fit one stored deflate block" % w)
+    nblocks = (h + r - 1) // r
+    zlen = 2 + 5 * nblocks + h * rb + 4
+    return rb, r, nblocks, zlen, 8 + 25 + 8 + zlen + 4 + 12
+
+
+def encode_png_stored(a: np.ndarray) -> bytes:
+    """uint8 [H,W,3] -> the bytes of the PNG file csrc/png_kernels.h builds on the device, byte for byte: filter type 0 on every
+    scanline, the zlib stream as stored deflate blocks of whole scanlines.  The host statement of that format: tests compare the
+    device encoder with it, and it is itself checked against an independent decoder (PIL)."""
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("encode_png_stored takes a uint8 [H,W,3] array, got %s %s" % (a.dtype, a.shape))
+    h, w, _ = a.shape
+    rb, r, nblocks, zlen, total = stored_layout(h, w)
+    raw = np.zeros((h, rb), np.uint8)
+    raw[:, 1:] = a.reshape(h, 3 * w)
+    parts = [b"\x78\x01"]
+    for b in range(nblocks):
+        rows = raw[b * r:(b + 1) * r]
+        n = rows.size
+        parts.append(struct.pack("<BHH", 1 if b == nblocks - 1 else 0, n, n ^ 0xFFFF))
+        parts.append(rows.tobytes())
+    parts.append(struct.pack(">I", zlib.adler32(raw.tobytes()) & 0xFFFFFFFF))
+    data = b"".join(parts)
+    assert len(data) == zlen
+    out = b"".join((_SIGNATURE, _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)), _chunk(b"IDAT", data), _chunk(b"IEND", b"")))
+    assert len(out) == total
+    return out
+
+
 def write_png(path: str, a: np.ndarray) -> None:
     """Write `a` to `path` (the directory is created when missing)."""
     d = os.path.dirname(path)

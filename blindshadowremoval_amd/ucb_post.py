@@ -15,7 +15,6 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from .metrics import psnr as _psnr, ssim as _ssim
 
@@ -30,11 +29,37 @@ MASK_DIRS = {          # train_test_GSC.py:386-392, relative to Config.UCB_MASK_
 }
 
 
+def resize_weights(out_size: int, in_size: int):
+    """Per output index: (lower, upper, lerp) of TensorFlow's bilinear kernel with half-pixel centres — compute_interpolation_weights
+    + HalfPixelScaler of tensorflow/core/kernels/image/resize_bilinear_op.cc / image_resizer_state.h (TF 2.3), float32 throughout:
+    in = (i + 0.5f) * (in_size / out_size) - 0.5f;  lower = max(floor(in), 0);  upper = min(ceil(in), in_size - 1);  lerp = in - floor(in)."""
+    scale = np.float32(in_size) / np.float32(out_size)
+    src = (np.arange(out_size, dtype=np.float32) + np.float32(0.5)) * scale - np.float32(0.5)
+    fl = np.floor(src)
+    lower = np.maximum(fl.astype(np.int64), 0)
+    upper = np.minimum(np.ceil(src).astype(np.int64), in_size - 1)
+    return lower, upper, (src - fl).astype(np.float32)
+
+
 def resize_bilinear(x: np.ndarray, size: int) -> np.ndarray:
-    """tf.image.resize(x, [size, size]) for an [H,W,C] array: bilinear, half-pixel centres, no antialiasing -> float32."""
-    t = torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).permute(2, 0, 1)[None]
-    y = F.interpolate(t, size=(size, size), mode="bilinear", align_corners=False, antialias=False)
-    return y[0].permute(1, 2, 0).contiguous().numpy()
+    """tf.image.resize(x, [size, size]) for an [H,W,C] array (the reference's calls: train_test_GSC.py:437-471) -> float32.
+    Bilinear, half-pixel centres, no antialiasing, in the ARITHMETIC of TensorFlow's CPU kernel (compute_lerp of
+    resize_bilinear_op.cc): top = tl + (tr - tl) * x_lerp; bottom = bl + (br - bl) * x_lerp; out = top + (bottom - top) * y_lerp,
+    every operation a rounded float32 operation, no fused multiply-add.  Round 5: plain numpy instead of torch's F.interpolate,
+    whose rounding depended on the thread count and the channel count (different vector kernels) — the rounded masks
+    (round(resize(mask)), :439-471) sit on exact .5 ties for some crop sizes, so the operation order decides pixels; this form is
+    deterministic, and the device kernel (csrc/ucb_kernels.h) executes the same operations, bit for bit."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    h, w = x.shape[0], x.shape[1]
+    ylo, yhi, yl = resize_weights(size, h)
+    xlo, xhi, xl = resize_weights(size, w)
+    top_rows, bot_rows = x[ylo], x[yhi]                                      # [size, W, C]
+    xl_ = xl[None, :, None]
+    tl, tr = top_rows[:, xlo], top_rows[:, xhi]
+    top = tl + (tr - tl) * xl_
+    bl, br = bot_rows[:, xlo], bot_rows[:, xhi]
+    bottom = bl + (br - bl) * xl_
+    return (top + (bottom - top) * yl[:, None, None]).astype(np.float32)
 
 
 def _pad(x: np.ndarray, size: int, full: int) -> np.ndarray:

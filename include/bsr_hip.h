@@ -129,6 +129,18 @@ int bsr_timing_entry(bsr_handle* h, int i, char* name, size_t name_cap, float* m
 int bsr_prep_rows(int device, const void* d_blob, size_t blob_bytes, size_t rows_off, size_t grid_off, int B, int S, float* out, float* hull_tmp,
                   void* stream);
 
+/* The output sink of the reference's loops on the device: replaces `cv2.imwrite(fname, strip)` of Logging.save_img
+ * (/root/reference/utils.py:196-204; called per item from train_test_GSC.py:744-746 and :889-890) up to the write() itself.
+ * pixels: [B,H,W,3] uint8 RGB strips (device).  out: B complete PNG FILE images, out_stride bytes apart (device or device-mapped
+ * pinned memory), each exactly bsr_png_file_bytes(H, W) long: 8-bit truecolour, filter type 0, the zlib stream as stored deflate
+ * blocks (lossless: any decoder returns `pixels`; size = raw size + 0.3 %), Adler-32 and chunk CRC-32s computed on the device.
+ * scratch: bsr_png_scratch_bytes(B) bytes of device memory, 8-byte aligned (the per-file checksum accumulators).  W <= 5461.
+ * Asynchronous on `stream`.  ABI 5. */
+size_t bsr_png_file_bytes(int H, int W);
+size_t bsr_png_scratch_bytes(int B);
+int bsr_png_encode(int device, const unsigned char* pixels, int B, int H, int W, unsigned char* out, size_t out_stride, void* scratch,
+                   void* stream);
+
 /* Test hook: the fused NonLocalBlock attention kernel alone (/root/reference/model.py:51-53).
  * qkv [B,tokens,384] (theta | phi | g, 128 channels each) -> y [B,tokens,128]; tokens % 128 == 0. */
 int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream);

@@ -81,7 +81,7 @@ def test_a_stale_library_is_refused(lib, tmp_path):
     assert library_sha16(str(stale)) == "0123456789abcdef"
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from blindshadowremoval_amd import build, _lib\n"
-            "build.LIB_PATH = %r\n"
+            "build.LIB_PATH = _lib.LIB_PATH = %r\n"
             "try:\n"
             "    _lib.load()\n"
             "except RuntimeError as e:\n"

@@ -367,6 +367,7 @@ def test_pipelined_loop_with_and_without_the_shared_pinned_ring(golden_dir, tmp_
             ds.name_list = ds.name_list[:20]
             fsr = FSRNet(cfg, weights=w)
             fsr.shm_ring, fsr.gpu_inflight = ring, depth
+            fsr.log.gpu_png = False                                        # this test is about the HOST encoder pool and its ring (round 5's device writer: next test)
             fsr.log.png_workers = 0 if ucb else 2
             fsr.post_workers, fsr.return_figs = (3 if ucb else 0), False
             res = fsr.test(ds, batch=8) if ucb else fsr.testFFHQ(ds, batch=8)
@@ -381,6 +382,39 @@ def test_pipelined_loop_with_and_without_the_shared_pinned_ring(golden_dir, tmp_
             got = runs[(ucb, label)]
             assert got[0] == base[0] and got[1] == base[1], (ucb, label)
             assert got[2] == base[2], (ucb, label)                         # PNG strips byte for byte
+
+
+@pytest.mark.gpu
+def test_device_png_writer_in_the_loops_gives_the_host_encoders_pixels(golden_dir, tmp_path):
+    """Round 5: with the generator on a GPU the loops build the PNG FILES of a batch on the device (gpu_png.StripEncoder, stored deflate,
+    checksums computed there) and the host only writes them.  Every file must decode (PIL checks chunk CRCs, zlib the Adler-32) to
+    exactly the pixels the host encoder's file decodes to — synchronous and pipelined, full and ragged last batch."""
+    import io
+    from PIL import Image
+    from blindshadowremoval_amd import dataset as D
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    from blindshadowremoval_amd.gpu_png import file_bytes
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    w = init_weights(1)
+    runs = {}
+    for label, gpu_png, depth in (("host", False, 2), ("device_sync", True, 0), ("device", True, 3)):
+        cfg.CHECKPOINT_DIR = str(tmp_path / label)
+        ds = D.Dataset(cfg, "test", ucb=True, workers=2, device_prep=0, device_batch=8)
+        ds.name_list = ds.name_list[:20]                                   # 8 + 8 + 4
+        fsr = FSRNet(cfg, weights=w)
+        assert fsr.log.gpu_png is True                                     # the default on a GPU
+        fsr.log.gpu_png, fsr.gpu_inflight, fsr.return_figs = gpu_png, depth, False
+        res = fsr.testFFHQ(ds, batch=8)
+        ds.close()
+        assert len(res) == 20 and len(fsr.log.saved) == 20
+        runs[label] = [open(f, "rb").read() for f in fsr.log.saved]
+        fsr.close()
+    assert all(len(b) == file_bytes(256, 768) for b in runs["device"])     # the layout is a pure function of the strip's shape
+    assert runs["device"] == runs["device_sync"]
+    for a, b in zip(runs["device"], runs["host"]):
+        A, B = np.asarray(Image.open(io.BytesIO(a)).convert("RGB")), np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))
+        assert A.shape == (256, 768, 3) and np.array_equal(A, B)
 
 
 @pytest.mark.gpu

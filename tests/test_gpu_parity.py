@@ -880,6 +880,30 @@ def test_fused_attention_w_tail_is_bit_identical_in_the_16_bit_modes(dtype, monk
         pt.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32x3", "f16"])
+def test_conv1_resident_gemm_is_bit_identical_to_the_implicit_gemm_form(dtype, monkeypatch):
+    """Round 5: at full batches the 16-bit modes run res*.conv1 (1x1, K = 128 | 288 -> 128) as gemm_nloop_kernel<4, NCH, 2, MINW = 1> — one
+    workgroup per CU, the whole input tile resident in registers, all of N per workgroup — instead of igemm_h16_kernel<1,1,1>.  Same
+    operand split and matrix-instruction order per output element => the same bits; small batches keep the implicit-GEMM form."""
+    from blindshadowremoval_amd import Generator
+    w = init_weights(1)
+    new = Generator(dtype=dtype).load_weights(w)
+    monkeypatch.setenv("BSR_CONV1_GEMM", "0")
+    old = Generator(dtype=dtype).load_weights(w)
+    monkeypatch.delenv("BSR_CONV1_GEMM")
+    g = torch.Generator().manual_seed(74)
+    for (B, H, W) in ((32, 256, 256), (16, 256, 256), (8, 512, 512), (3, 256, 256)):
+        inp, uv = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
+        a = [t.clone() for t in new(inp, uv)]
+        b = old(inp, uv)
+        for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
+            assert torch.equal(x, y), (dtype, B, H, W, name)
+        for pr in ("res0", "res1", "res3", "res5"):
+            assert torch.equal(new.probe(pr), old.probe(pr)), (dtype, B, H, W, pr)
+    new.close()
+    old.close()
+
+
 @pytest.mark.gpu
 def test_two_handles_on_two_streams_give_the_serial_result():
     """bench.py --streams 2 (and any serving loop) keeps two forwards in flight on two handles / two HIP streams: the kernels of one
