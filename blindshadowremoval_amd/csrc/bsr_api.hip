@@ -24,6 +24,7 @@
 #include "png_kernels.h"
 #include "prep_kernels.h"
 #include "stem7.h"
+#include "ucb_kernels.h"
 
 namespace {
 
@@ -872,6 +873,24 @@ int bsr_png_encode(int device, const unsigned char* pixels, int B, int H, int W,
   DeviceGuard guard(device);
   HIP_TRY(guard.err);
   HIP_TRY(bsr::launch_png_encode(pixels, B, g, out, out_stride, static_cast<unsigned long long*>(scratch), static_cast<hipStream_t>(stream)));
+  return BSR_OK;
+}
+
+size_t bsr_ucb_post_scratch_bytes(int B, int S) {
+  if (B <= 0 || (S != 32 && S != 64 && S != 128 && S != 256)) return 0;
+  return (size_t)B * bsr::ucb_item_scratch_bytes(S);
+}
+
+int bsr_ucb_post(int device, const float* rows10, const unsigned char* masks, const float* boxes, int B, int S, float* losses,
+                 unsigned char* strips, float* figs, int* status, void* scratch, void* stream) {
+  if (rows10 == nullptr || masks == nullptr || boxes == nullptr || losses == nullptr || strips == nullptr || status == nullptr || scratch == nullptr)
+    return fail(BSR_ERR_ARG, "bsr_ucb_post: null argument");
+  if (B <= 0 || (S != 32 && S != 64 && S != 128 && S != 256))
+    return fail(BSR_ERR_ARG, "bsr_ucb_post: B must be positive and S one of 32, 64, 128, 256 (reference: 256)");
+  if (reinterpret_cast<uintptr_t>(scratch) % 256 != 0) return fail(BSR_ERR_ARG, "bsr_ucb_post: scratch must be 256-byte aligned");
+  DeviceGuard guard(device);
+  HIP_TRY(guard.err);
+  HIP_TRY(bsr::launch_ucb_post(rows10, masks, boxes, B, S, losses, strips, figs, status, scratch, static_cast<hipStream_t>(stream)));
   return BSR_OK;
 }
 

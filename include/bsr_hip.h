@@ -141,6 +141,21 @@ size_t bsr_png_scratch_bytes(int B);
 int bsr_png_encode(int device, const unsigned char* pixels, int B, int H, int W, unsigned char* out, size_t out_stride, void* scratch,
                    void* stream);
 
+/* The per-item post-processing of FSRNet.test_step on the device: replaces /root/reference/train_test_GSC.py:424-748 (resize to the crop
+ * box + zero pad :437-477, region thresholds :479-590, 4-connected components :594-615, nose rule :650-666, composite :711-722, SSIM /
+ * PSNR :724-725, the seven figures of :744 as one strip) for a batch of B items.
+ * rows10: [B,S,S,10] float32 = input 3 | ground truth 3 | con_rgb 3 | dif 1 (row 0 of each item's generator call, :419-422);
+ * masks: [B,7,S,S] uint8 grey levels of the seven segmentation masks in the order of :386-392 (face+hair, face, mouth, nose, eyebrow,
+ * eye, glasses — what cv2.imread returns, before the / 255.0); boxes: [B,4] float32 crop boxes.  All device pointers.
+ * losses: [B,2] float32 = ssim, psnr; strips: [B,S,7*S,3] uint8 RGB (the figure strip Logging.save_img writes — feed it to
+ * bsr_png_encode); figs: optional [B,7,S,S,3] float32 (the figures themselves; may be NULL); status: [B] int32 — 0 = done,
+ * 1 = a mask the reference takes a bounding box of is empty (the reference raises there), 2 = the crop box does not fit S.
+ * scratch: bsr_ucb_post_scratch_bytes(B, S) bytes, 256-byte aligned.  S in {32, 64, 128, 256} (reference: 256).  Every decision
+ * (rounded masks, thresholds, components, rules) is bit-identical to blindshadowremoval_amd/ucb_post.py, the host statement.  ABI 5. */
+size_t bsr_ucb_post_scratch_bytes(int B, int S);
+int bsr_ucb_post(int device, const float* rows10, const unsigned char* masks, const float* boxes, int B, int S, float* losses,
+                 unsigned char* strips, float* figs, int* status, void* scratch, void* stream);
+
 /* Test hook: the fused NonLocalBlock attention kernel alone (/root/reference/model.py:51-53).
  * qkv [B,tokens,384] (theta | phi | g, 128 channels each) -> y [B,tokens,128]; tokens % 128 == 0. */
 int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* stream);
