@@ -23,7 +23,7 @@ import glob
 import os
 import random
 import re
-from typing import Iterator, List, Optional, Tuple
+from typing import Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
 
@@ -32,9 +32,19 @@ _ANCHORS = np.asarray([[0, 0], [0, 255], [255, 0], [255, 255], [0, 127], [127, 0
                        [0, 63], [0, 191], [255, 63], [255, 191], [63, 0], [191, 0], [63, 255], [191, 255]]) / 255   # warp.py:195-198
 
 
+_FACE_MODEL: list = []
+
+
 def _face_model():
-    z = np.load(_DATA)
-    return z["uv"], z["lm_ref"]
+    """(uv, lm_ref) of the canonical face (data/face_model.npz), read once per process — the loaders' workers called it per item
+    (0.5 ms of npz parsing each); the arrays are read-only."""
+    if not _FACE_MODEL:
+        z = np.load(_DATA)
+        uv, lm_ref = z["uv"], z["lm_ref"]
+        uv.setflags(write=False)
+        lm_ref.setflags(write=False)
+        _FACE_MODEL.append((uv, lm_ref))
+    return _FACE_MODEL[0]
 
 
 def usable_cpus() -> int:
@@ -280,7 +290,7 @@ def build_element(job) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     lm_path, gt_path, siblings, size = job
     if isinstance(gt_path, tuple) and gt_path[0] == "<device>":            # the host half of a device-prepared row (prep.py)
         from .prep import host_part
-        return host_part((lm_path, gt_path[1], size))
+        return host_part((lm_path, gt_path[1], size) + ((gt_path[2],) if len(gt_path) > 2 else ()))
     if gt_path == "<sfw>":
         return build_sfw_pair(lm_path, size)
     if gt_path == "<sfw_video>":
@@ -324,6 +334,7 @@ class Dataset:
         self.device_prep, self.device_batch = device_prep, int(device_batch)
         if device_prep is not None and (rows != 1 or dset is not None):
             raise NotImplementedError("device_prep prepares row 0 of the GSC loaders (rows=1, dset=None)")
+        self.ucb_mask_files: Optional[List[Dict[str, str]]] = None       # per item of name_list: the seven mask paths (FSRNet.test sets it; device_prep only)
         self.name_list: List[str] = []
         pattern = "*.npy" if dset is None else "*_label.png"               # dataset.py:55-61 | dataset_with_TSM.py:63
         for d in config.DATA_DIR_TEST:
@@ -367,7 +378,13 @@ class Dataset:
             if i < lo:
                 continue                                                   # another rank's item: only its RNG draws are consumed
             gt = self._gt_path(lm_path)
-            yield (lm_path, ("<device>", gt) if self.device_prep is not None else gt, sibs, size)
+            if self.device_prep is not None:
+                # ucb_mask_files (set by FSRNet.test for its device post-processing): the item's seven mask PNGs are decoded by the same
+                # worker that decodes its image, and travel bit-packed
+                masks = self.ucb_mask_files[i] if self.ucb_mask_files is not None else None
+                yield (lm_path, ("<device>", gt) + ((masks,) if masks is not None else ()), sibs, size)
+            else:
+                yield (lm_path, gt, sibs, size)
 
     def close(self) -> None:
         pool, self._pool = self._pool, None
@@ -403,7 +420,10 @@ class Dataset:
         def emit():
             out, boxes = dp.rows(group)
             for i, part in enumerate(group):
-                yield out[i:i + 1][None], boxes[i][None], np.array([part[4]])
+                if len(part) > 5 and part[5] is not None:      # + the item's seven segmentation masks (host, bit-packed or grey levels: prep.pack_masks)
+                    yield out[i:i + 1][None], boxes[i][None], np.array([part[4]]), part[5]
+                else:
+                    yield out[i:i + 1][None], boxes[i][None], np.array([part[4]])
         for part in self._iterate_host():
             group.append(part)
             if len(group) >= self.device_batch:

@@ -130,7 +130,10 @@ class Logging(object):
     def files_on_device(self, figs: Sequence[torch.Tensor]) -> torch.Tensor:
         """strips_on_device + the PNG encoding itself on the device: uint8 [B, file_bytes] — row j is the complete PNG file of item j's
         strip (decodes to exactly get_imgs' pixels)."""
-        strips = self.strips_on_device(figs)
+        return self.encode_strips(self.strips_on_device(figs))
+
+    def encode_strips(self, strips: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,S,W,3] strips on a GPU -> their PNG files [B, file_bytes] on that GPU (gpu_png.StripEncoder, one per device)."""
         dev = strips.device.index
         if dev not in self._encoders:
             from .gpu_png import StripEncoder
@@ -426,6 +429,7 @@ class FSRNet(object):
         self.gpu_inflight = 2                    # batches whose forward + device-to-host copy may be outstanding while the loop feeds the next one
         self.all_losses: List[Tuple[str, Dict[str, float]]] = []      # (name, losses) of EVERY item in list order — on every rank after a data-parallel loop
         self.timings: Dict[str, float] = {}      # wall-clock split of the last test / testFFHQ loop (see _loop)
+        self.post_device = True                  # FSRNet.test's post-processing on the GPU when the generator lives on one (ucb_post_gpu); False: the host forms below
         self.post_threads = 8                    # threads that post-process the items of one UCB batch (post_workers == 0)
         self.post_workers = 0                    # > 0: UCB post-processing in that many worker PROCESSES, pipelined one batch behind the GPU
         self.post_inflight = 2                   # batches whose post-processing may be outstanding
@@ -442,8 +446,23 @@ class FSRNet(object):
         return self._post_pool
 
     def warm_pools(self) -> None:
-        """Start the post-processing workers (post_workers > 0) and let them import torch / scipy now, not inside the timed loop."""
-        if self.post_workers > 0:
+        """Start the post-processing workers (post_workers > 0) and let them import torch / scipy now, not inside the timed loop; with the
+        device post-processing (post_device on a GPU) run its kernels and the PNG encoder once on a dummy item — the first launch of a
+        kernel family loads its code object, the first use of a torch operator its module: ~1 s in all on a fresh process."""
+        dev = getattr(self.gen, "_device", None)
+        if self.post_device and dev is not None and torch.cuda.is_available():
+            from .prep import unpack_masks
+            from .ucb_post_gpu import UcbPostDevice
+            s = self.config.IMG_SIZE
+            d = torch.device("cuda", dev)
+            bits = np.zeros((7, s * s // 8), np.uint8)
+            bits[:, : s * s // 16] = 255
+            masks = unpack_masks([("bits", bits, s)], d)
+            rows = torch.rand((1, s, s, 10), device=d)
+            _, strips, _, status = UcbPostDevice(dev).run(rows, masks, torch.tensor([[0, 0, s - 16, s - 16]], dtype=torch.float32, device=d))
+            self.log.encode_strips(strips)
+            torch.cat([strips.reshape(-1)[:8], status.view(torch.uint8)]).cpu()
+        elif self.post_workers > 0:
             self._get_post_pool().warm("post")
 
     def close_pools(self) -> None:
@@ -567,7 +586,16 @@ class FSRNet(object):
         # read in place (_ShmPinnedRing); [ring | None, already tried]
         ring_state = [None, not (on_gpu and self.shm_ring)]
 
-        post_pool = self._get_post_pool() if ucb and postprocess and self.post_workers > 0 else None
+        # round 5: the per-item post-processing of test_step runs ON THE DEVICE (ucb_post_gpu / csrc/ucb_kernels.h), the figure strips become
+        # PNG files there too, and what comes back per item is its file + two losses; post_workers / post_threads are the host forms
+        post_dev = None
+        pend_masks: Dict[int, object] = {}
+        if ucb and postprocess and on_gpu and self.post_device:
+            from .ucb_post_gpu import UcbPostDevice
+            post_dev = UcbPostDevice(self.gen._device)
+            if hasattr(dataset, "ucb_mask_files") and getattr(dataset, "device_prep", None) is not None and not getattr(dataset, "_started", False):
+                dataset.ucb_mask_files = mask_files      # the loader's workers decode the masks next to the images (bit-packed through the pipe)
+        post_pool = self._get_post_pool() if ucb and postprocess and self.post_workers > 0 and post_dev is None else None
         inflight: List[Tuple] = []          # UCB batches whose post-processing runs in the worker pool: (pending items, futures)
 
         poll = getattr(dataset, "poll", lambda: None)      # lets the loader's workers hand over finished elements while this thread is busy elsewhere
@@ -666,7 +694,19 @@ class FSRNet(object):
             gs, con_rgb, _, mask_pred = self.gen(im_d, uv_d, None, chuck=4 if ucb else 1, training=False)
             items = list(pending)
             pending.clear()
-            if ucb and postprocess:
+            if post_dev is not None:
+                # train_test_GSC.py:424-748 for the whole batch on the device; the seven figures leave as PNG files
+                from .prep import pack_masks, unpack_masks
+                packed = [pend_masks.pop(it[0], None) or pack_masks(mask_files[it[0]]) for it in items]      # a feed without masks: read here
+                boxes = torch.from_numpy(np.stack([np.asarray(it[3], np.float32).reshape(-1)[:4] for it in items])).to(dev, non_blocking=True)
+                losses_d, strips_d, figs_d, status_d = post_dev.run(torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3), unpack_masks(packed, dev), boxes,
+                                                                    want_figs=self.return_figs)
+                files_d = self.log.encode_strips(strips_d)
+                nfile = files_d.shape[1]
+                payload = torch.cat([losses_d.view(torch.uint8).reshape(-1), status_d.view(torch.uint8).reshape(-1), files_d.reshape(-1)])      # 12 bytes per item, then the files
+                host, ev, slot = to_host_async(payload, to_pool=False, pin_id=True)
+                figs_b = ("post_dev", nfile, figs_d)
+            elif ucb and postprocess:
                 # train_test_GSC.py:424-748 runs on the host, one independent item per call: what it reads comes over in ONE copy
                 host, ev, slot = to_host_async(torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3), to_pool=post_pool is not None)      # [B,S,S,10]
                 figs_b = None
@@ -710,6 +750,28 @@ class FSRNet(object):
             tm.setdefault("first_batch_done_s", time.time() - start)
             poll()
             t1 = time.perf_counter()
+            if post_dev is not None:
+                from .ucb_post_gpu import raise_for_status
+                _, nfile, figs_d = figs_b
+                nb = len(items)
+                losses = host[:nb * 8].view(np.float32).reshape(nb, 2)
+                status = host[nb * 8:nb * 12].view(np.int32)
+                files = host[nb * 12:nb * 12 + nb * nfile].reshape(nb, nfile)
+                raise_for_status(status, [it[1] for it in items])
+                futs = self.log.save_files(files, [it[1] for it in items])
+                if slot is not None and slot < 0:
+                    pin_busy[-1 - slot] = futs
+                else:
+                    for fu in futs:
+                        fu.result()
+                figs_h = figs_d.cpu() if figs_d is not None else None
+                for j, it in enumerate(items):
+                    lo_ = {"ssim": float(losses[j, 0]), "psnr": float(losses[j, 1])}
+                    self.log.display(lo_, 0, it[0], False, num_list)
+                    tm["items"] += 1
+                    results.append((it[1], [figs_h[j, k][None] for k in range(7)] if figs_h is not None else None, lo_))
+                tm["post_s"] += time.perf_counter() - t1
+                return
             if ucb and postprocess:
                 if post_pool is not None:
                     post_pool._pump(block=False)
@@ -772,6 +834,8 @@ class FSRNet(object):
                     continue
                 img = element[0]
                 pending.append((step, _name(img_name), img, element[1] if len(element) > 1 else None))
+                if post_dev is not None:
+                    pend_masks[step] = element[3] if len(element) > 3 else None      # the item's packed masks when the loader decoded them
                 if len(pending) >= batch:
                     submit()
             submit()

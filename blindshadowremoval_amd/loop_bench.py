@@ -48,6 +48,12 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
                  # post-processing workers write the strips themselves)
                  ("device_prep", dict(workers=max(2, ncpu * 5 // 8) if ucb else max(2, ncpu * 7 // 8), device_prep=fsr.gen._device, device_batch=batch),
                   dict(post_workers=max(2, ncpu), png_workers=0 if ucb else max(2, ncpu * 7 // 8), post_inflight=3, gpu_png=False))]
+        if ucb:
+            # round 5: test_step's post-processing + the PNG encoding run on the device (ucb_post_gpu / gpu_png); the loader's workers also
+            # decode the seven masks of every item
+            modes[-1][2]["post_device"] = False
+            modes.append(("device_post", dict(workers=max(2, ncpu), device_prep=fsr.gen._device, device_batch=batch),
+                          dict(post_workers=0, png_workers=0, post_inflight=3, gpu_png=True, post_device=True)))
         if not ucb:
             # round 5: the PNG files themselves are built on the device (gpu_png.py): no encoder pool, every usable CPU decodes / triangulates
             modes.append(("device_png", dict(workers=max(2, ncpu), device_prep=fsr.gen._device, device_batch=batch),
@@ -59,6 +65,7 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
             fsr.return_figs = not fsr_kw                                 # the device_prep mode measures the loop as a user who wants the PNGs + metrics runs it
             fsr.log.png_workers = fsr_kw.get("png_workers", 0)
             fsr.log.gpu_png = bool(fsr_kw.get("gpu_png", False))        # the earlier modes keep the host encoders they were measured with
+            fsr.post_device = bool(fsr_kw.get("post_device", False))
             base = list(ds.name_list)
             n_items = items * ((10 if ucb else 20) if fsr_kw else 1)     # the fast mode needs a longer list for a steady-state rate (~2-4 s of loop)
             reps = (n_items + len(base) - 1) // len(base)
@@ -79,7 +86,7 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
                           "split_s": {k: round(v, 3) for k, v in tm.items() if k.endswith("_s")}, "forwards": tm.get("forwards")}
             if fsr_kw:
                 t_first = tm.get("first_batch_done_s", 0.0)
-                res[label].update(post_workers=fsr.post_workers if ucb else 0, png_workers=fsr.log.png_workers, gpu_png=fsr.log.gpu_png,
+                res[label].update(post_workers=fsr.post_workers if ucb else 0, png_workers=fsr.log.png_workers, gpu_png=fsr.log.gpu_png, post_device=fsr.post_device,
                                   steady_images_per_sec=round((len(out) - batch) / max(dt - t_first, 1e-9), 2),
                                   note="worker processes started and warmed before the clock; steady_images_per_sec = items after the first batch / time after it")
             ds.close()

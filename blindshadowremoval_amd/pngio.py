@@ -41,6 +41,50 @@ def encode_png(a: np.ndarray) -> bytes:
                      _chunk(b"IEND", b"")))
 
 
+def read_grey_u8(path: str) -> np.ndarray:
+    """An image file as 8-bit grey levels [H,W] (= PIL's open(path).convert("L")).  Fast path for what the UCB segmentation masks are
+    (cv2.imwrite output: 8-bit greyscale, non-interlaced, filter type 0 / 1 / 2 on every scanline): inflate + one cumulative sum —
+    0.06 ms instead of PIL's 0.45 ms per 256x256 mask, seven masks per item in the loaders' workers.  Anything else goes to PIL."""
+    with open(path, "rb") as f:
+        b = f.read()
+    try:
+        if b[:8] != _SIGNATURE:
+            raise ValueError
+        o, idat, hdr = 8, [], None
+        while o + 12 <= len(b):
+            n, = struct.unpack(">I", b[o:o + 4])
+            tag = b[o + 4:o + 8]
+            if tag == b"IHDR":
+                hdr = struct.unpack(">IIBBBBB", b[o + 8:o + 8 + n])
+            elif tag == b"IDAT":
+                idat.append(b[o + 8:o + 8 + n])
+            elif tag == b"IEND":
+                break
+            elif tag in (b"PLTE", b"tRNS", b"gAMA"):          # palette / transparency / gamma: PIL's business
+                raise ValueError
+            o += 12 + n
+        w, h, depth, ctype, _, _, interlace = hdr
+        if depth != 8 or ctype != 0 or interlace != 0:
+            raise ValueError
+        raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, 1 + w)
+        ft = raw[:, 0]
+        if ft.max() > 2:
+            raise ValueError
+        out = raw[:, 1:].copy()
+        sub = ft == 1
+        if sub.all():
+            return np.cumsum(out, axis=1, dtype=np.uint8)      # Sub: x[i] = f[i] + x[i-1] (mod 256)
+        if sub.any():
+            out[sub] = np.cumsum(out[sub], axis=1, dtype=np.uint8)
+        for y in np.nonzero(ft == 2)[0]:                       # Up: x[y] = f[y] + x[y-1] (mod 256), top row: + 0
+            if y > 0:
+                out[y] += out[y - 1]
+        return out
+    except (ValueError, TypeError, struct.error, zlib.error):
+        from PIL import Image
+        return np.asarray(Image.open(path).convert("L"), np.uint8)
+
+
 def stored_layout(h: int, w: int):
     """(scanline bytes, scanlines per stored block, blocks, zlib-stream bytes, file bytes) of the STORED-deflate RGB file the device
     encoder writes (csrc/png_kernels.h: its layout is a pure function of H and W)."""

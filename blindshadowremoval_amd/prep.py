@@ -29,7 +29,10 @@ assert ROW_DTYPE.itemsize == 88
 
 def _imread_u8(path: str) -> np.ndarray:
     from PIL import Image
-    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), np.uint8))
+    im = Image.open(path)
+    if im.mode != "RGB":                      # an RGB file is decoded straight into the array (convert() would copy it once more)
+        im = im.convert("RGB")
+    return np.ascontiguousarray(np.asarray(im, np.uint8))
 
 
 def _tri_table(tri, zs: Sequence[np.ndarray]) -> np.ndarray:
@@ -92,8 +95,35 @@ def crop_box(lm0: np.ndarray) -> Tuple[List[int], np.ndarray]:
     return box, lm / np.float32(length * 2)
 
 
+def pack_masks(paths) -> tuple:
+    """The seven UCB segmentation masks of one item (dict in ucb_post.MASK_DIRS order -> path) as grey levels, for the device
+    post-processing (ucb_post_gpu): ("bits", [7, S*S/8] uint8) when every level is 0 or 255 — what the reference's masks are; an eighth
+    of the bytes through the worker's pipe — else ("u8", [7,S,S] uint8)."""
+    from .ucb_post_gpu import read_masks_u8
+    m = read_masks_u8(paths)
+    if m.shape[1] * m.shape[2] % 8 == 0 and bool(np.all((m == 0) | (m == 255))):
+        return ("bits", np.packbits((m != 0).reshape(7, -1), axis=1), m.shape[1])
+    return ("u8", m, m.shape[1])
+
+
+def unpack_masks(packed: Sequence[tuple], device):
+    """[pack_masks(...)] of a batch -> uint8 [B,7,S,S] grey levels on `device` (bit-packed items are expanded there)."""
+    import torch
+    S = packed[0][2]
+    if all(p[0] == "bits" for p in packed):
+        bits = torch.from_numpy(np.stack([p[1] for p in packed], axis=0)).to(device, non_blocking=True)          # [B,7,S*S/8]
+        shifts = torch.arange(7, -1, -1, device=bits.device, dtype=torch.uint8)
+        return (((bits[..., None] >> shifts) & 1) * 255).to(torch.uint8).reshape(len(packed), 7, S, S)
+    full = [np.unpackbits(p[1], axis=1).reshape(7, S, S) * np.uint8(255) if p[0] == "bits" else p[1] for p in packed]
+    return torch.from_numpy(np.stack(full, axis=0)).to(device, non_blocking=True)
+
+
 def host_part(job):
-    """(lm_path, gt_path, size) -> the host half of one row: (img u8, gt u8 | None, box, [4 triangle tables], name)."""
+    """(lm_path, gt_path, size[, mask paths]) -> the host half of one row: (img u8, gt u8 | None, box, [4 triangle tables], name[, packed masks])."""
+    masks = None
+    if len(job) > 3:
+        masks = pack_masks(job[3])
+        job = job[:3]
     lm_path, gt_path, size = job
     img_path = os.path.splitext(lm_path)[0] + ".png"
     img = _imread_u8(img_path)
@@ -101,7 +131,8 @@ def host_part(job):
     if gt is not None and gt.shape != img.shape:
         raise ValueError("ground truth %s and image %s differ in size" % (gt_path, img_path))
     box, lm = crop_box(np.load(lm_path))
-    return img, gt, np.asarray(box, np.int32), meshes(lm), (gt_path or img_path).encode()
+    out = (img, gt, np.asarray(box, np.int32), meshes(lm), (gt_path or img_path).encode())
+    return out + (masks,) if masks is not None else out
 
 
 def _layout(parts, size: int):
@@ -119,7 +150,8 @@ def _layout(parts, size: int):
     rows_off = take(B * ROW_DTYPE.itemsize)
     grid_off = take(size * 8)
     pieces.append((grid_off, np.linspace(0, 1, size).astype("<f8")))
-    for i, (img, gt, box, tabs, _) in enumerate(parts):
+    for i, part in enumerate(parts):
+        img, gt, box, tabs = part[:4]
         r = rows[i]
         r["h"], r["w"] = img.shape[0], img.shape[1]
         r["img_off"] = take(img.nbytes)

@@ -20,8 +20,8 @@ STATUS_TEXT = {1: "a segmentation mask the reference takes a bounding box of (no
 def read_masks_u8(paths: Dict[str, str]) -> np.ndarray:
     """The seven mask images of one item as grey levels, [7,S,S] uint8 in MASK_ORDER: cv2.imread(...) of the reference (:386-393) returns
     three equal channels of exactly these values; the / 255.0 happens on the device."""
-    from PIL import Image
-    return np.stack([np.asarray(Image.open(paths[k]).convert("L"), np.uint8) for k in MASK_ORDER], axis=0)
+    from .pngio import read_grey_u8
+    return np.stack([read_grey_u8(paths[k]) for k in MASK_ORDER], axis=0)
 
 
 class UcbPostDevice:

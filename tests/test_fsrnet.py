@@ -277,6 +277,7 @@ def test_ucb_post_processing_in_worker_processes_equals_the_in_process_form(gold
         ds = D.Dataset(cfg, "test", ucb=True, workers=2)
         ds.name_list = ds.name_list[:20]
         fsr = FSRNet(cfg, weights=w)
+        fsr.post_device = False                                 # this test is about the HOST forms (in-process / worker pool); the device form: its own test below
         fsr.post_workers, fsr.return_figs = pw, figs
         res = fsr.test(ds, batch=8)
         ds.close()
@@ -369,6 +370,7 @@ def test_pipelined_loop_with_and_without_the_shared_pinned_ring(golden_dir, tmp_
             fsr.shm_ring, fsr.gpu_inflight = ring, depth
             fsr.log.gpu_png = False                                        # this test is about the HOST encoder pool and its ring (round 5's device writer: next test)
             fsr.log.png_workers = 0 if ucb else 2
+            fsr.post_device = False
             fsr.post_workers, fsr.return_figs = (3 if ucb else 0), False
             res = fsr.test(ds, batch=8) if ucb else fsr.testFFHQ(ds, batch=8)
             ds.close()
@@ -415,6 +417,57 @@ def test_device_png_writer_in_the_loops_gives_the_host_encoders_pixels(golden_di
     for a, b in zip(runs["device"], runs["host"]):
         A, B = np.asarray(Image.open(io.BytesIO(a)).convert("RGB")), np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))
         assert A.shape == (256, 768, 3) and np.array_equal(A, B)
+
+
+@pytest.mark.gpu
+def test_ucb_post_processing_on_the_device_equals_the_host_form(golden_dir, tmp_path):
+    """Round 5: FSRNet.test runs test_step's per-item post-processing on the GPU (ucb_post_gpu / csrc/ucb_kernels.h; masks decoded by the
+    loader's workers, strips encoded to PNG files on the device).  Against the host form on the same forwards: the seven figures of
+    every item bit for bit, SSIM / PSNR to 1e-4, the PNG files pixel for pixel — with and without the figures coming back, pipelined
+    and synchronous, masks through the device-preparing loader and read in the loop."""
+    import io
+    from PIL import Image
+    from blindshadowremoval_amd import dataset as D
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    w = init_weights(1)
+    runs = {}
+    for label, post_device, figs, depth, ds_kw in (("host", False, True, 0, dict(workers=2, device_prep=0, device_batch=8)),
+                                                   ("device", True, True, 2, dict(workers=2, device_prep=0, device_batch=8)),
+                                                   ("device_nofigs_sync", True, False, 0, dict(workers=2, device_prep=0, device_batch=8)),
+                                                   ("device_host_rows", True, False, 2, dict(workers=0))):
+        cfg.CHECKPOINT_DIR = str(tmp_path / label)
+        ds = D.Dataset(cfg, "test", ucb=True, **ds_kw)
+        ds.name_list = ds.name_list[:20]
+        fsr = FSRNet(cfg, weights=w)
+        assert fsr.post_device is True
+        fsr.post_device, fsr.return_figs, fsr.gpu_inflight = post_device, figs, depth
+        res = fsr.test(ds, batch=8)
+        ds.close()
+        assert len(res) == 20 and len(fsr.log.saved) == 20
+        runs[label] = (res, [open(f, "rb").read() for f in fsr.log.saved], dict(fsr.log.losses))
+        fsr.close()
+    base_res, base_png, base_means = runs["host"]
+    for label in ("device", "device_nofigs_sync", "device_host_rows"):
+        res, png, means = runs[label]
+        assert [r[0] for r in res] == [r[0] for r in base_res]
+        for r, b in zip(res, base_res):
+            tol = 5e-3 if label == "device_host_rows" else 1e-4          # host-prepared rows are not bit-identical inputs (1e-6)
+            assert abs(r[2]["ssim"] - b[2]["ssim"]) < tol and abs(r[2]["psnr"] - b[2]["psnr"]) < 10 * tol, (label, r[0], r[2], b[2])
+            if label == "device":
+                assert len(r[1]) == 7
+                for k in range(7):
+                    assert torch.equal(r[1][k].cpu(), b[1][k].cpu()), (r[0], k)
+            else:
+                assert r[1] is None
+        if label != "device_host_rows":                      # (host-prepared rows differ from device-prepared ones by ~1e-6: not the same forward)
+            for a, b in zip(png, base_png):
+                A, B = np.asarray(Image.open(io.BytesIO(a)).convert("RGB")), np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))
+                assert A.shape == (256, 7 * 256, 3) and np.array_equal(A, B)
+        for k in ("ssim", "psnr"):
+            assert abs(means[k][0] / means[k][1] - base_means[k][0] / base_means[k][1]) < (5e-2 if label == "device_host_rows" else 1e-4)
 
 
 @pytest.mark.gpu
