@@ -711,6 +711,12 @@ def run_rank(args):
             torch.cuda.synchronize()
             pre_rf = roofline_from_events(gen, lambda: gen(inp, uv, out=outs[0]), B, args.dtype)
         init_group()
+    peer = None
+    if distributed and args.gather == "peer" and not args.no_gather:
+        from blindshadowremoval_amd.peer_gather import PeerGather
+        ctl = dist.new_group(backend="gloo") if args.backend == "nccl" else None
+        peer = PeerGather((B, HW, HW, 4), torch.float32, dev, control_group=ctl)
+        gathered = [peer.gathered(0), peer.gathered(1)]
 
     def on_lane(k):
         return torch.cuda.stream(lanes[k]) if lanes[k] is not None else contextlib.nullcontext()
@@ -738,13 +744,26 @@ def run_rank(args):
             if gathering:
                 if tsm:
                     torch.cat((o[1], o[3]), dim=3, out=packed[slot])
-                pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
+                if peer is not None:
+                    # finish(step i-1) BEFORE push(step i): its barrier also orders everyone's use of this slot's previous contents (step
+                    # i-2) before anyone overwrites them; the copies of step i then run beside the forward of step i+1
+                    if peer_open[0]:
+                        peer.finish()
+                    peer.push(slot, packed[slot])
+                    peer_open[0] = True
+                else:
+                    pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
+
+    peer_open = [False]
 
     def drain():
         for s in (0, 1):
             if pending[s] is not None:
                 pending[s].wait()
                 pending[s] = None
+        if peer is not None and peer_open[0]:
+            peer.finish()
+            peer_open[0] = False
 
     def timed(nsteps, fn):
         """barrier + synchronize on both sides, MAX over ranks (the contract's timed region)"""
@@ -792,6 +811,12 @@ def run_rank(args):
         def gather_only(i):
             slot = i & 1
             with on_lane(slot % nlanes):
+                if peer is not None:
+                    if peer_open[0]:
+                        peer.finish()
+                    peer.push(slot, packed[slot])
+                    peer_open[0] = True
+                    return
                 if pending[slot] is not None:
                     pending[slot].wait()
                 pending[slot] = dist.all_gather_into_tensor(gathered[slot], packed[slot], async_op=True)
@@ -812,6 +837,8 @@ def run_rank(args):
         oks = [None] * world
         dist.all_gather_object(oks, ok)
         extra.update({"allgather": {"bytes_per_rank": packed[0].numel() * 4, "backend": args.backend, "verified": all(oks),
+                               "form": ("peer: full-mesh direct peer-to-peer copies on a copy stream + gloo control barrier (peer_gather.py)" if peer is not None
+                                        else "rccl: all_gather_into_tensor, asynchronous, double-buffered"),
                                "ms_alone": round(t_g / args.steps * 1e3, 4),
                                "ms_per_step_without_gather": round(t_nog / args.steps * 1e3, 4),
                                "ms_exposed_per_step": round((elapsed - t_nog) / args.steps * 1e3, 4)},
@@ -895,6 +922,8 @@ def run_rank(args):
         else:
             sys.stdout.write(line)
             sys.stdout.flush()
+    if peer is not None:
+        peer.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -924,6 +953,10 @@ def parse_args(argv=None):
                          "fill the tails and ramps of the other's one-round launches — reported as `two_in_flight` BESIDE `value`, which is always one forward at a time; "
                          "1 = skip that side measurement")
     ap.add_argument("--no-gather", action="store_true", help="skip the output all-gather (N>1)")
+    ap.add_argument("--gather", choices=("rccl", "peer"), default="rccl",
+                    help="N>1: how the outputs are re-assembled on every rank.  rccl = one asynchronous all_gather_into_tensor per step (RCCL kernels over "
+                         "xGMI); peer = full-mesh direct peer-to-peer copies of the shard into every rank's buffer (copy engines, no compute units; "
+                         "blindshadowremoval_amd/peer_gather.py) — the fallback should RCCL's kernels contend with the forward's one-round launches")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo only with --stub (CPU test of the rank logic)")
     ap.add_argument("--stub", action="store_true", help="CPU stand-in generator: tests the launcher / sharding / JSON contract, measures nothing")
     ap.add_argument("--loop", choices=("ffhq", "ucb"), default=None,

@@ -30,6 +30,8 @@ def main(argv=None) -> int:
     ap.add_argument("--dtype", choices=("f32", "f32x3", "f16"), default="f32")
     ap.add_argument("--random-weights", type=int, default=None, metavar="SEED", help="seeded random-init weights in the checkpoint layout instead of a restore")
     ap.add_argument("--host-prep", action="store_true", help="prepare the rows on the host (default: on the device, prep.py)")
+    ap.add_argument("--host-post", action="store_true", help="rounds 2-4 forms: UCB post-processing in worker processes and PNG encoding on the host "
+                                                             "(default: both on the device — ucb_post_gpu.py, gpu_png.py)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl")
     ap.add_argument("--device", type=int, default=None, help="GPU index of this rank (default: LOCAL_RANK).  With --backend gloo several ranks may share one "
                                                               "GPU — how the world-2 loop is exercised on a one-GPU box (tests/test_fsrnet.py)")
@@ -75,15 +77,18 @@ def main(argv=None) -> int:
     os.makedirs(os.path.join(cfg.CHECKPOINT_DIR, "test"), exist_ok=True)
     ucb = args.loop == "ucb"
     ncpu = cpu_share()                      # this rank's share of the node's usable CPUs
-    ds_kw = dict(workers=max(1, ncpu * 5 // 8 if ucb else ncpu * 7 // 8))      # worker counts: sweeps on the 16-CPU GPU box (loop_bench.py)
+    # worker counts: sweeps on the 16-CPU GPU box (loop_bench.py).  With post-processing and PNG encoding on the device (the default) the
+    # loader's workers — PNG decode, Delaunay meshes, the UCB masks — are the only host stage: one per CPU of this rank's share
+    ds_kw = dict(workers=max(1, (ncpu * 5 // 8 if ucb else ncpu * 7 // 8) if args.host_post else ncpu))
     if not args.host_prep:
         ds_kw.update(device_prep=local_rank, device_batch=args.batch)
     ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
     fsr = FSRNet(cfg, weights=init_weights(args.random_weights) if args.random_weights is not None else None, dtype=args.dtype)
-    fsr.post_workers = max(2, ncpu) if ucb else 0
+    fsr.post_device = fsr.log.gpu_png = not args.host_post
+    fsr.post_workers = max(2, ncpu) if ucb and args.host_post else 0
     fsr.post_inflight = 3
     fsr.return_figs = False
-    fsr.log.png_workers = 0 if ucb else max(1, ncpu * 7 // 8)
+    fsr.log.png_workers = max(1, ncpu * 7 // 8) if args.host_post and not ucb else 0
     rc = 0
     try:
         ds.warm()
@@ -104,7 +109,7 @@ def main(argv=None) -> int:
             means = {k: s / max(c, 1) for k, (s, c) in fsr.log.losses.items()}
             print("\n" + json.dumps({"loop": "FSRNet.test" if ucb else "FSRNet.testFFHQ", "items": n, "ranks": world, "process_group": (args.backend if grouped else None), "items_this_rank": len(res),
                                      "images_per_sec": round(n / dt, 2), "seconds": round(dt, 3), "batch": args.batch, "dtype": args.dtype,
-                                     "cpus_per_rank": ncpu, "means": means}))
+                                     "cpus_per_rank": ncpu, "post_and_png": "host" if args.host_post else "device", "means": means}))
     finally:
         ds.close()
         fsr.close()

@@ -620,6 +620,40 @@ def test_bench_rccl_allgather_world1():
     assert ag["verified"] is True and ag["backend"] == "nccl"
 
 
+def test_peer_gather_world2_on_one_gpu_and_in_bench():
+    """Round 5: the copy-engine alternative to the RCCL all-gather (blindshadowremoval_amd/peer_gather.py: every rank writes its shard into
+    every peer's IPC-mapped gather buffer, a gloo barrier completes the step).  (1) its self-test with TWO ranks sharing GPU 0: handles
+    exchanged, buffers mapped across processes, six double-buffered steps, every shard checked on every rank; (2) bench.py --gather
+    peer on one rank (forced process group): the same `allgather.verified` bookkeeping as the RCCL path."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def free_port():
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        return port
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                        "-m", "blindshadowremoval_amd.peer_gather", "--device", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j == {"peer_gather_selftest": True, "world": 2, "steps": 6, "device_of_every_rank": 0}
+    env.update(BSR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--repeats", "1", "--gather", "peer",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    ag = j["config"]["allgather"]
+    assert ag["verified"] is True and ag["form"].startswith("peer") and ag["bytes_per_rank"] == 33554432 and j["value"] > 0
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Range guard of the 16-bit modes (include/bsr_hip.h: BSR_ERR_RANGE, bsr_check_range)
 
