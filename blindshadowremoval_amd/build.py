@@ -24,7 +24,15 @@ def source_sha16() -> str:
     for f in _deps():
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    if extra_flags():
+        h.update(b"flags\0" + " ".join(extra_flags()).encode())
     return h.hexdigest()[:16]
+
+
+def extra_flags():
+    """Extra hipcc flags of an EXPERIMENT build (env BSR_EXTRA_FLAGS, e.g. "-DBSR_AX3_PRIO=1"): part of the source hash, so a library
+    built with them only loads while the variable still says so (scratch/ab_build.sh); empty for every product build."""
+    return os.environ.get("BSR_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:
@@ -74,7 +82,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             # the hash of everything the library is compiled from goes INTO the binary (bsr_source_sha()): _lib.load() refuses a
             # library whose hash is not the tree's, so a stale .so can neither pass the tests nor produce a bench line
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-                   '-DBSR_SRC_SHA="%s"' % source_sha16(), "-o", tmp] + [os.path.join(PKG_DIR, s) for s in SOURCES]
+                   '-DBSR_SRC_SHA="%s"' % source_sha16()] + extra_flags() + ["-o", tmp] + [os.path.join(PKG_DIR, s) for s in SOURCES]
             res = subprocess.run(cmd, cwd=PKG_DIR, capture_output=True, text=True)
             if verbose or res.returncode != 0:
                 print(" ".join(cmd))

@@ -23,6 +23,10 @@
 #include "igemm_conv.h"
 #include "gemm_tail.h"
 
+#ifndef BSR_ATT_PRIO
+#define BSR_ATT_PRIO 0      // 0: equal priorities; 1 / 2: key-stream wave group 0 / 1 at s_setprio 2
+#endif
+
 namespace bsr {
 
 constexpr int kAttD = 128;        // C/2 of the 257-channel NonLocalBlock (/root/reference/model.py:10-12)
@@ -79,6 +83,9 @@ __global__ __launch_bounds__(QW * 128, QW == 4 ? 2 : 1) void nonlocal_attention_
   }
   const float* base = qkv + (size_t)img * tokens * (3 * kAttD);
   const int q = qb * (QW * 32) + wq * 32 + r;
+#if BSR_ATT_PRIO
+  if (grp == (BSR_ATT_PRIO - 1)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);      // see attention_x3.h
+#endif
 
   // theta fragment of this lane's query: element j of group g is channel 8g + 4h + j
   f32x4 qf[kAttD / 8];

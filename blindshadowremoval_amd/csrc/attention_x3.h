@@ -26,6 +26,10 @@
 #include "attention.h"
 #include "igemm_h16.h"
 
+#ifndef BSR_AX3_PRIO
+#define BSR_AX3_PRIO 0      // 0: equal priorities; 1 / 2: wave group 0 / 1 at s_setprio 2 (measured: profiles/HISTORY.md round 5)
+#endif
+
 namespace bsr {
 
 constexpr int kAx3LdK = 132;                                   // words per phi row: 64 (hi) + 64 (lo) + 4 pad
@@ -65,6 +69,13 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
   }
   const float* base = qkv + (size_t)img * tokens * (3 * kAttD);
   const int q = qb * 128 + wq * 32 + r;
+#if BSR_AX3_PRIO
+  // The two key-stream wave groups share every SIMD and run the same program between the same barriers: left alone they stay in
+  // lock-step — both in their matrix phase, then both in their softmax / split / staging phase — and nothing overlaps.  A static
+  // priority makes one group win every arbitration: it runs ahead until it needs the other pipe, and the groups settle half a phase
+  // apart (MI355X_MICROARCH.md, "Two waves per SIMD", items 4 and 9).
+  if (grp == (BSR_AX3_PRIO - 1)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
 
   // theta of this lane's query, pre-scaled by log2(e) (softmax in base 2), split: K step s covers channels 16s + 8h .. +7
   f16x8 qh[kAttD / 16], ql[kAttD / 16];

@@ -39,6 +39,9 @@
 #ifndef BSR_H16_RING
 #define BSR_H16_RING 4      // slots of the LDS-DMA weight ring: the image of step s + RING - 1 is requested at the top of step s
 #endif
+#ifndef BSR_H16_FETCH_TAP_F16
+#define BSR_H16_FETCH_TAP_F16 5   // = T - 4 of the transposed 3x3 layers
+#endif
 #ifndef BSR_H16_RING_F16
 #define BSR_H16_RING_F16 8  // the same for NSPLIT = 1 (f16 mode): its steps are a third as long, so the same latency spans more of them
 #endif
@@ -397,7 +400,11 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
       for (int q = 0; q < T; ++q) {
         const int t = tap_at(q);
         const int s = ch * T + q;
-        constexpr int kInFetchTap = T - 4;
+        // the step of a chunk at which the NEXT chunk's input tile is requested.  vmcnt retires in order, so the request may stay in
+        // flight for R - 3 steps at most (after that it is older than the weight image the step's barrier waits for).  fp32 input: 24-48
+        // staging registers, requested 4 steps ahead; fp16 input (IN16): 12 registers and steps a third as long — requested earlier
+        // (BSR_H16_FETCH_TAP_F16), with a ring deep enough to keep it in flight
+        constexpr int kInFetchTap = IN16 ? BSR_H16_FETCH_TAP_F16 : T - 4;
         const bool hasD = s + R - 1 < nsteps;
 #ifndef H16_DIAG_NO_DMA
         if (hasD) dma_w(img_of(ch, q + R - 1), w_far[R - 4]);
