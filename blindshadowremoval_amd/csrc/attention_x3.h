@@ -26,6 +26,9 @@
 #include "attention.h"
 #include "igemm_h16.h"
 
+#ifndef BSR_AX3_STAGGER
+#define BSR_AX3_STAGGER 0
+#endif
 #ifndef BSR_AX3_PRIO
 #define BSR_AX3_PRIO 0      // 0: equal priorities; 1 / 2: wave group 0 / 1 at s_setprio 2 (measured: profiles/HISTORY.md round 5)
 #endif
@@ -148,9 +151,30 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
   publish_v(0);
   __syncthreads();
 
+#if BSR_AX3_STAGGER
+  // The two key-stream wave groups share every SIMD, run the same program and meet at one barrier per tile pair: left alone they stay in
+  // lock-step — both in their matrix phases (S^T, then O^T), both in their VALU phases (softmax + split of P, split + LDS staging of the
+  // next pair) — and neither pipe is busy half the time (measured: 9 400 cycles per pair and SIMD for 3 072 cycles of matrix work).
+  // Staggered: group 1 does its share of the NEXT pair's staging at the START of a step (the buffer is free since the last barrier)
+  // instead of at its end, so its phases run half a step out of phase with group 0's: stage | S | softmax | O against S | softmax | O |
+  // stage.  It therefore fetches one pair further ahead.
+  if (grp == 1 && npair > 1) fetch(1);
+#endif
   for (int pr = 0; pr < npair; ++pr) {
     const int pbuf = pr & 1;
+#if BSR_AX3_STAGGER
+    if (grp == 1) {
+      if (pr + 1 < npair) {
+        publish(pbuf ^ 1);
+        publish_v(pbuf ^ 1);
+        if (pr + 2 < npair) fetch(pr + 2);
+      }
+    } else if (pr + 1 < npair) {
+      fetch(pr + 1);
+    }
+#else
     if (pr + 1 < npair) fetch(pr + 1);
+#endif
     const float* sk = smem + (2 * pbuf + grp) * kAx3StageWords;        // this wave's tile of the pair
     const float* sv = sk + kAttKT * kAx3LdK;
 
@@ -204,8 +228,15 @@ __global__ __launch_bounds__(512, 2) void nonlocal_attention_x3_kernel(const flo
       }
 
     if (pr + 1 < npair) {
+#if BSR_AX3_STAGGER
+      if (grp == 0) {
+        publish(pbuf ^ 1);
+        publish_v(pbuf ^ 1);
+      }
+#else
       publish(pbuf ^ 1);
       publish_v(pbuf ^ 1);
+#endif
       __syncthreads();
     }
   }

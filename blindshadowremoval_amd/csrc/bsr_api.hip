@@ -156,6 +156,7 @@ struct bsr_handle {
   bool fuse_c3q = false;         // env BSR_FUSE_C3Q=1: res*.conv2 with the conv3 | theta|phi|g GEMM as its tail (one launch).  Built, bit-identical, and
                                  // OFF: one forward at a time it is 0.2 % faster, with two forwards in flight 0.8 % slower (its 150-KB, 8-wave workgroups
                                  // leave the other lane's kernels no room on the CU) — profiles/HISTORY.md, round 4
+  bool conv1_gemm_f32 = false;   // env BSR_CONV1_GEMM=2: also on the fp32 path (measured: no gain)
   bool conv1_gemm = true;        // env BSR_CONV1_GEMM=0: res*.conv1 of the 16-bit modes on the implicit-GEMM kernel at every batch (A/B measurements, bit-identity tests)
   bool fuse_attw = true;         // env BSR_FUSE_ATTW=0: attention and the `w` GEMM as two launches (A/B measurements, bit-identity tests)
   bool timing = false;
@@ -470,7 +471,7 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   h->dtype = dtype;
   if (const char* e_ = getenv("BSR_FUSE_HEADS")) h->fuse_heads = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_FUSE_ATTW")) h->fuse_attw = atoi(e_) != 0;
-  if (const char* e_ = getenv("BSR_CONV1_GEMM")) h->conv1_gemm = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_CONV1_GEMM")) { h->conv1_gemm = atoi(e_) != 0; h->conv1_gemm_f32 = atoi(e_) == 2; }
   if (const char* e_ = getenv("BSR_FUSE_C3Q")) h->fuse_c3q = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_TAIL_STAGGER")) h->tail_stagger = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_S2_PERSIST")) h->s2_persist = atoi(e_) != 0;
@@ -692,14 +693,20 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     share_layer(ws + p.xa, V.cs_a, 96, ws + p.xa, V.cs_a, 96);
   }
 
-  // res*.conv1 (1x1, 99|257|261 -> 128, + BN + LeakyReLU) in the 16-bit modes at full batches: the resident-activation GEMM with ONE
-  // workgroup per CU and all of N per workgroup (gemm_nloop.h, MINW = 1) — same split, same matrix-instruction order per output
-  // element as igemm_h16_kernel<1,1,1,..,NSPLIT = 2>: the same bits
+  // res*.conv1 (1x1, 99|257|261 -> 128, + BN + LeakyReLU) at full batches: the resident-activation GEMM with ONE workgroup per CU and
+  // all of N per workgroup (gemm_nloop.h, MINW = 1) — same operands, same matrix-instruction order per output element as the
+  // implicit-GEMM kernels (igemm_h16_kernel<1,1,1,..,NSPLIT = 2> / igemm_conv_kernel<1,1,1,..,CC = 24>): the same bits
   auto conv1_gemm = [&](const char* nm, const float* x, int x_cs) -> bool {
-    if (h->dtype == BSR_DTYPE_F32 || V.tsm || !h->conv1_gemm || L.rc != BSR_OK) return false;
-    if (ncell % 128 != 0 || (long long)(ncell / 128) * 2 < bsr::device_cu_count() || (x_cs != 128 && x_cs != 288)) return false;
+    if (V.tsm || !h->conv1_gemm || L.rc != BSR_OK) return false;
+    // fp32 (opt-in, BSR_CONV1_GEMM=2): the same kernel over the layer's 24-channel chunks (K = 120 | 264), the same bits as
+    // igemm_conv_kernel<1,1,1,..,CC = 24> — built, bit-identical, and NOT faster (27.4 vs 27.1 us per launch: with fp32 matrix
+    // instructions one wave per SIMD has nobody to fill its LDS / wait slots; profiles/HISTORY.md round 5): off
+    const bool f32 = h->dtype == BSR_DTYPE_F32;
+    if (f32 && !h->conv1_gemm_f32) return false;
+    if (ncell % 128 != 0 || (long long)(ncell / 128) * 2 < bsr::device_cu_count()) return false;
+    if (f32 ? (x_cs != 120 && x_cs != 264) : (x_cs != 128 && x_cs != 288)) return false;
     LayerW l;
-    L.rc = find_layer(h, nm, x_cs / 32, 1, 36, 128, &l);
+    L.rc = f32 ? find_layer(h, nm, x_cs / 24, 1, 28, 128, &l) : find_layer(h, nm, x_cs / 32, 1, 36, 128, &l);
     if (L.rc != BSR_OK) return true;
     bsr::ConvArgs a{};
     a.in = x; a.in_cs = x_cs; a.in_coff = 0; a.out = ws + p.t1; a.out_cs = 128; a.out_coff = 0;
@@ -707,7 +714,9 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     a.range_flag = h->range_flag;
     L.begin(K_CONV1, nm);
     if (x_cs == 128) L.check(bsr::launch_gemm_nloop<4, 4, 2, 1>(a, ncell, 1, s), nm);
-    else L.check(bsr::launch_gemm_nloop<4, 9, 2, 1>(a, ncell, 1, s), nm);
+    else if (x_cs == 288) L.check(bsr::launch_gemm_nloop<4, 9, 2, 1>(a, ncell, 1, s), nm);
+    else if (x_cs == 120) L.check((bsr::launch_gemm_nloop<4, 5, 0, 1, 24>(a, ncell, 1, s)), nm);
+    else L.check((bsr::launch_gemm_nloop<4, 11, 0, 1, 24>(a, ncell, 1, s)), nm);
     L.end();
     return true;
   };

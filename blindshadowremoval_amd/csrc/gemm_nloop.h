@@ -18,9 +18,11 @@ namespace bsr {
 // H = 0: fp32 matrix cores (v_mfma_f32_32x32x2_f32).  H = 2 / 1: 16-bit matrix cores as in igemm_h16.h — the A fragments are split
 // into hi / lo fp16 planes once, when they are loaded into registers; the weight image is the fp16 one of pack_taps_h16 (for
 // H = 2 it has the same 36-word rows as the fp32 image), and a 16-channel K group costs 3 (f32x3) or 1 (f16) v_mfma_f32_32x32x16_f16.
-template <int NI, int NCH, int H = 0>   // NI 32-wide channel tiles per group, NCH = K / 32
+// CCF: channels per K chunk of the fp32 form (32; 24 for res*.conv1, whose K = 120 | 264 is packed in 24-channel chunks)
+template <int NI, int NCH, int H = 0, int CCF = 32>   // NI 32-wide channel tiles per group, NCH = K / CC
 struct GemmNLoopCfg {
-  static constexpr int CC = 32, LDP = (H == 1 ? 20 : 36), G = (H ? 2 : 4), LO = 16, BM = 128, BN = NI * 32;
+  static_assert(H == 0 || CCF == 32, "the 16-bit forms use 32-channel chunks");
+  static constexpr int CC = CCF, LDP = (H == 1 ? 20 : CCF + 4), G = (H ? 2 : CCF / 8), LO = 16, BM = 128, BN = NI * 32;
   static constexpr int W_FLOATS = BN * LDP;
   static constexpr int MAX_TILES = 24;                        // tiles per blockIdx.y range (bias staged in LDS)
   static constexpr int SMEM_BYTES = (3 * W_FLOATS + MAX_TILES * 32) * 4;
@@ -36,9 +38,9 @@ struct GemmNLoopCfg {
 // flight at once (147 KB per CU: the input is read exactly once, at full memory-level parallelism) — and computes all of N from them.
 // The implicit-GEMM form of that layer took its input through a 3-slot LDS ring two 0.16-us steps ahead of an L2 / HBM round trip, in
 // two N blocks that each fetched and split the tile: 27 us against ~11 of HBM time.
-template <int NI, int NCH, int H = 0, int MINW = 2>
+template <int NI, int NCH, int H = 0, int MINW = 2, int CCF = 32>
 __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
-  using C = GemmNLoopCfg<NI, NCH, H>;
+  using C = GemmNLoopCfg<NI, NCH, H, CCF>;
   constexpr int LDP = C::LDP, G = C::G;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_w = smem;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const int cur = g & 1, nxt = cur ^ 1;                 // G is even: every step starts on slot 0
+        const int cur = (ch * G + g) & 1, nxt = cur ^ 1;      // fragment slots alternate across steps too (G may be odd: 24-channel chunks); every channel group has NCH * G pieces
         if (g + 1 < G) {
           read_frags(nxt, w_cur + (g + 1) * 8);
         } else if (has1) {
@@ -208,6 +210,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
       }
       __syncthreads();
       const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = tw;
+    }
+    if constexpr (((NCH * G) & 1) != 0) {      // an odd number of pieces per group: the next group's first fragments were prefetched into slot 1
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if constexpr (H == 0) bf[0][ni] = bf[1][ni];
+        else { bh[0][ni] = bh[1][ni]; if constexpr (H == 2) bl[0][ni] = bl[1][ni]; }
+      }
     }
 
     // ---- epilogue of this channel group (same form as igemm_conv_kernel's) ----
@@ -272,10 +281,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
 #endif
 }
 
-template <int NI, int NCH, int H = 0, int MINW = 2>
+template <int NI, int NCH, int H = 0, int MINW = 2, int CCF = 32>
 inline hipError_t launch_gemm_nloop(ConvArgs a, size_t total_pixels, int nsplit, hipStream_t stream) {
-  using C = GemmNLoopCfg<NI, NCH, H>;
-  auto kern = gemm_nloop_kernel<NI, NCH, H, MINW>;
+  using C = GemmNLoopCfg<NI, NCH, H, CCF>;
+  auto kern = gemm_nloop_kernel<NI, NCH, H, MINW, CCF>;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {

@@ -914,13 +914,15 @@ def test_fused_attention_w_tail_is_bit_identical_in_the_16_bit_modes(dtype, monk
         pt.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32x3", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16"])
 def test_conv1_resident_gemm_is_bit_identical_to_the_implicit_gemm_form(dtype, monkeypatch):
-    """Round 5: at full batches the 16-bit modes run res*.conv1 (1x1, K = 128 | 288 -> 128) as gemm_nloop_kernel<4, NCH, 2, MINW = 1> — one
-    workgroup per CU, the whole input tile resident in registers, all of N per workgroup — instead of igemm_h16_kernel<1,1,1>.  Same
-    operand split and matrix-instruction order per output element => the same bits; small batches keep the implicit-GEMM form."""
+    """Round 5: at full batches res*.conv1 (1x1, 99 | 257 | 261 -> 128) runs as gemm_nloop_kernel<4, NCH, H, MINW = 1> — one workgroup per
+    CU, the whole input tile resident in registers, all of N per workgroup — instead of the implicit-GEMM kernels (igemm_conv_kernel<1,1,1,
+    CC = 24> / igemm_h16_kernel<1,1,1>).  Same operands (fp32: the layer's 24-channel chunks; 16-bit: the same hi / lo split) and the same
+    matrix-instruction order per output element => the same bits; small batches keep the implicit-GEMM form."""
     from blindshadowremoval_amd import Generator
     w = init_weights(1)
+    monkeypatch.setenv("BSR_CONV1_GEMM", "2")          # 2: on the fp32 path too (there it is opt-in: bit-identical but no faster)
     new = Generator(dtype=dtype).load_weights(w)
     monkeypatch.setenv("BSR_CONV1_GEMM", "0")
     old = Generator(dtype=dtype).load_weights(w)
