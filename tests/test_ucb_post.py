@@ -12,6 +12,7 @@ FIX = np.load(os.path.join(GOLDEN, "ucb_post_9156.npz"))
 
 
 def test_fixture_covers_small_and_large_detections():
+    assert str(FIX["backend"]) in ("standin",) or str(FIX["backend"]).startswith("tf-")          # which arithmetic made the expected values
     det = {k: int(FIX[k].sum()) for k in FIX.files if k.endswith("_detected")}
     assert len(det) == 10 and any(v < 2000 for v in det.values()) and any(v > 20000 for v in det.values())
 
@@ -52,3 +53,26 @@ def test_single_channel_masks_give_the_same_result():
     assert l1 == l3
     for a, b in zip(f1, f3):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="runs the reference's test_step source (build container only)")
+def test_tf_backend_of_the_fixture_tool_dry_run(tmp_path, monkeypatch):
+    """`tools/make_ucb_post_fixture.py --backend tf` is the one command that would pin tf.image.resize / ssim / psnr (and every decision
+    that follows from them) to real TensorFlow; it cannot run here.  Its code path can: with BSR_MOCK_TF=1 the stand-in is presented as
+    the `tensorflow` module and the tool must write the committed fixture's values under `backend = "tf-mock"`.  A test of the tool, not a pin."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_ucb_post_fixture", os.path.join(root, "tools", "make_ucb_post_fixture.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    monkeypatch.setenv("BSR_MOCK_TF", "1")
+    out = tmp_path / "fix.npz"
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tool.main(["--backend", "tf", "--out", str(out)])
+    z = np.load(out)
+    assert str(z["backend"]) == "tf-mock" and set(z.files) == set(FIX.files)
+    for k in FIX.files:
+        if k != "backend":
+            np.testing.assert_array_equal(z[k], FIX[k], err_msg=k)
+    with pytest.raises(SystemExit):
+        tool.main(["--backend", "jax"])

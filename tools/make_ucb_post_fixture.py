@@ -14,7 +14,13 @@ mask PNGs (tests/golden/UCB_masks), and as generator outputs a realistic synthet
 dif = gray(gt) - gray(input) (the true shadow magnitude), plus scaled variants that push the heuristics through other branches.
 Only the expected OUTPUTS are stored.
 
-    python tools/make_ucb_post_fixture.py        # needs /root/reference
+    python tools/make_ucb_post_fixture.py [--backend standin|tf] [--out PATH]       # needs /root/reference
+
+--backend tf — the pin of `tf.image.resize` / `tf.image.ssim` / `tf.image.psnr` that is missing here (no TensorFlow in this image): on a
+machine with TensorFlow 2.3 the reference's `test_step` runs over REAL `tf` (and real `cv2` when importable) on the same cases and the
+same npz keys are written, plus `backend = "tf-<version>"`; tests/test_ucb_post.py and the GPU tests then compare against TensorFlow's
+own resize rounding and SSIM / PSNR without any change.  BSR_MOCK_TF=1 exercises that code path here over the stand-in presented as a
+`tensorflow` module (tests/test_ucb_post.py: a test of this tool's logic, not a pin).
 """
 import ast
 import os
@@ -86,37 +92,73 @@ def make_cv2():
     return cv2
 
 
-def reference_test_step():
-    """`FSRNet.test_step` compiled from the reference's file, with tf / cv2 / np bound to the stand-ins above."""
+def load_backend(backend: str):
+    """-> (tf module, cv2 module, label).  "standin": the numpy-backed stand-ins above.  "tf": real TensorFlow (+ real cv2 if present);
+    with BSR_MOCK_TF=1 the stand-in dressed as the module (a dry run of this path)."""
+    if backend == "standin":
+        return make_tf(), make_cv2(), "standin"
+    if os.environ.get("BSR_MOCK_TF") == "1":
+        mock = make_tf()
+        mock.__version__ = "mock"
+        return mock, make_cv2(), "tf-mock"
+    try:
+        import tensorflow as tf
+    except ImportError as e:
+        raise SystemExit("--backend tf needs TensorFlow (the reference pins 2.3.0, README.md:11): %s" % e)
+    try:
+        import cv2
+    except ImportError:
+        cv2 = make_cv2()
+    return tf, cv2, "tf-%s" % tf.__version__
+
+
+def reference_test_step(tf_mod=None, cv2_mod=None):
+    """`FSRNet.test_step` compiled from the reference's file, with tf / cv2 / np bound to the given modules (default: the stand-ins above)."""
     with open(os.path.join(REF, "train_test_GSC.py")) as fsrc:
         src = fsrc.read()
     tree = ast.parse(src)
     cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "FSRNet")
     fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "test_step")
     mod = ast.Module(body=[fn], type_ignores=[])
-    ns = {"tf": make_tf(), "cv2": make_cv2(), "np": np, "print": lambda *a, **k: None}
+    ns = {"tf": tf_mod if tf_mod is not None else make_tf(), "cv2": cv2_mod if cv2_mod is not None else make_cv2(), "np": np, "print": lambda *a, **k: None}
     exec(compile(mod, "<reference test_step>", "exec"), ns)
     return ns["test_step"]
 
 
-def main():
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    backend, out_path = "standin", os.path.join(ROOT, "tests", "golden", "ucb_post_9156.npz")
+    while argv:
+        a = argv.pop(0)
+        if a == "--backend" and argv:
+            backend = argv.pop(0)
+            if backend not in ("standin", "tf"):
+                raise SystemExit("--backend must be standin or tf")
+        elif a == "--out" and argv:
+            out_path = argv.pop(0)
+        else:
+            raise SystemExit(__doc__)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from ucb_cases import cases
-    step = reference_test_step()
-    out = {}
+    tf_mod, cv2_mod, label = load_backend(backend)
+    step = reference_test_step(tf_mod, cv2_mod)
+    real_tf = label.startswith("tf-") and label != "tf-mock"
+    wrap = (lambda x, dtype=None: tf_mod.convert_to_tensor(np.asarray(x, dtype=dtype))) if real_tf else _t
+    out = {"backend": np.array(label)}
     for key, row, box, m, con, dif in cases():
         fake = types.SimpleNamespace(config=types.SimpleNamespace(IMG_SIZE=256))
-        fake.gen = lambda im, uv, reg, chuck, training: (None, _t(np.repeat(con[None], 10, 0)), None, _t(np.repeat(dif[None], 10, 0)))
+        fake.gen = lambda im, uv, reg, chuck, training: (None, wrap(np.repeat(con[None], 10, 0)), None, wrap(np.repeat(dif[None], 10, 0)))
         stack = np.repeat(row[None], 10, axis=0)
-        losses, figs = step(fake, _t(stack), _t(np.asarray(box, np.int32)), _t(m["face_hair"]), _t(m["face"]), _t(m["mouth"]), _t(m["nose"]),
-                            _t(m["eyebrow"]), _t(m["eye"]), _t(m["glasses"]), False)
+        losses, figs = step(fake, wrap(stack), wrap(np.asarray(box, np.int32)), wrap(m["face_hair"]), wrap(m["face"]), wrap(m["mouth"]), wrap(m["nose"]),
+                            wrap(m["eyebrow"]), wrap(m["eye"]), wrap(m["glasses"]), False)
         out[key + "_ssim"] = np.float32(losses["ssim"])
         out[key + "_psnr"] = np.float32(losses["psnr"])
         out[key + "_detected"] = np.asarray(figs[4])[0, :, :, 0].astype(np.uint8)
         if key.endswith("a"):                              # the composite image itself for one case per item (size)
             out[key + "_out"] = np.asarray(figs[1])[0].astype(np.float16)
         print(key, "size", int(box[3] - box[1]), "ssim %.4f psnr %.2f detected %d px" % (losses["ssim"], losses["psnr"], int(out[key + "_detected"].sum())))
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ucb_post_9156.npz"), **out)
+    np.savez_compressed(out_path, **out)
+    return out
 
 
 if __name__ == "__main__":
