@@ -498,7 +498,7 @@ def attach_traffic(rf, dom_name, B, dtype):
     from blindshadowremoval_amd.build import source_sha16
     sha = source_sha16()
     sfx = "" if dtype == "f32" else "_" + dtype
-    for tag in ("r4", "r3", "r2", "r1"):
+    for tag in ("r5", "r4", "r3", "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx))
         if not os.path.isfile(tpath):
             continue
@@ -532,7 +532,7 @@ def attach_mfma(rf, dom_name, B, dtype):
     sha = source_sha16()
     sfx = "" if dtype == "f32" else "_" + dtype
     rf["mfma_busy"] = rf["clock_ghz"] = None
-    mtag = next((t for t in ("r4", "r3") if os.path.isfile(os.path.join(ROOT, "profiles", "%s_pmc_mfma%s.json" % (t, sfx)))), None)
+    mtag = next((t for t in ("r5", "r4", "r3") if os.path.isfile(os.path.join(ROOT, "profiles", "%s_pmc_mfma%s.json" % (t, sfx)))), None)
     if mtag is None:
         rf["mfma_note"] = "no profiles/r*_pmc_mfma%s.json" % sfx
         return

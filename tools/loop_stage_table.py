@@ -3,9 +3,9 @@
 the loops' own _SelectPool (one worker process per usable CPU unless --workers says otherwise) with the loops' own job formats as
 aggregate items/s, and once in this process as uncontended CPU milliseconds per item; plus what the stage costs the DRIVING thread
 per item (pickling, pipe I/O, select loop), which all stages of a real loop share.  The table bench.py --loop figures are read
-against (profiles/r4_loop_stage_table.json): a loop cannot be faster than its slowest stage alone.  No GPU is used.
+against (profiles/r5_loop_stage_table.json): a loop cannot be faster than its slowest stage alone.  No GPU is used.
 
-    python tools/loop_stage_table.py [--out gpurun_out/r4_loop_stage_table.json] [--items 400]
+    python tools/loop_stage_table.py [--out gpurun_out/r5_loop_stage_table.json] [--items 400]
 """
 import argparse
 import json
@@ -72,6 +72,34 @@ def main():
         dt, cpu = run_stage(pool, jobs)
         res["stages"]["loader_host_half"] = {"items_per_sec": round(n / dt, 1), "driver_cpu_ms_per_item": round(cpu / n * 1e3, 3), "job_cpu_ms_alone": alone_ms(build_element, jobs),
                                              "what": "prep.host_part per item (device preparation: decode + triangulate)"}
+        # ---- stage 1a (round 5): the same job + the item's seven segmentation masks (decoded, bit-packed): what FSRNet.test's loader does now that
+        # the post-processing itself runs on the device
+        ds_m = Dataset(cfg, "test", ucb=True, device_prep=0)
+        ds_m.ucb_mask_files = FSRNet(cfg)._ucb_masks()
+        base_m = list(ds_m._jobs())
+        jobs_m = [base_m[i % len(base_m)] for i in range(n)]
+        run_stage(pool, jobs_m[:nw])
+        dt, cpu = run_stage(pool, jobs_m)
+        res["stages"]["loader_host_half_with_masks"] = {"items_per_sec": round(n / dt, 1), "driver_cpu_ms_per_item": round(cpu / n * 1e3, 3),
+                                                        "job_cpu_ms_alone": alone_ms(build_element, jobs_m),
+                                                        "what": "prep.host_part per item incl. the seven UCB masks (fast grey PNG reader, bit-packed through the pipe)"}
+        # ---- stage 1c (round 5): writing the PNG files the DEVICE built (gpu_png): four writer threads in the loop's process, 256x768 and 256x1792 strips
+        from concurrent.futures import ThreadPoolExecutor
+        from blindshadowremoval_amd.pngio import stored_layout
+        for label, wpx in (("file_write_ffhq", 768), ("file_write_ucb", 1792)):
+            nbytes = stored_layout(256, wpx)[4]
+            blob = np.random.default_rng(1).integers(0, 256, (16, nbytes), dtype=np.uint8)
+
+            def put(i):
+                with open(os.path.join(out_dir, "f%05d.png" % i), "wb", buffering=0) as fh:
+                    fh.write(memoryview(blob[i % 16]))
+            with ThreadPoolExecutor(max_workers=4) as ex:
+                list(ex.map(put, range(32)))
+                t0, c0 = time.perf_counter(), time.process_time()
+                list(ex.map(put, range(n)))
+                dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+            res["stages"][label] = {"items_per_sec": round(n / dt, 1), "driver_cpu_ms_per_item": round(cpu / n * 1e3, 3), "bytes_per_png": int(nbytes),
+                                    "what": "write() of one device-built PNG file (stored deflate) from pinned memory, 4 threads in the loop's process"}
         # ---- stage 1b: the loader's full host path (build_row: everything prepared on the CPU)
         ds_h = Dataset(cfg, "test", ucb=True)
         base_h = list(ds_h._jobs())
@@ -122,9 +150,12 @@ def main():
                 pass
     st = res["stages"]
     res["reading"] = {
-        "testFFHQ": "host stages of the device-prepared loop: loader_host_half + png_strip (+ the driving thread); slowest stage alone: %.0f /s"
-                    % min(st["loader_host_half"]["items_per_sec"], st["png_strip"]["items_per_sec"]),
-        "test (UCB)": "host stages: loader_host_half + ucb_post (its PNG strip included); slowest stage alone: %.0f /s" % st["ucb_post"]["items_per_sec"],
+        "testFFHQ": "round 5 (PNG files built on the device): host stages = loader_host_half + file_write_ffhq (+ the driving thread); slowest stage alone: %.0f /s.  "
+                    "Rounds 3-4 (host encoder): loader_host_half + png_strip, slowest %.0f /s"
+                    % (min(st["loader_host_half"]["items_per_sec"], st["file_write_ffhq"]["items_per_sec"]), min(st["loader_host_half"]["items_per_sec"], st["png_strip"]["items_per_sec"])),
+        "test (UCB)": "round 5 (post-processing + PNG on the device): host stages = loader_host_half_with_masks + file_write_ucb; slowest stage alone: %.0f /s.  "
+                      "Rounds 2-4 (host post-processing): loader_host_half + ucb_post (its PNG strip included), slowest %.0f /s"
+                      % (min(st["loader_host_half_with_masks"]["items_per_sec"], st["file_write_ucb"]["items_per_sec"]), st["ucb_post"]["items_per_sec"]),
         "cpu_sum_ms_per_item_uncontended": {"testFFHQ": round(st["loader_host_half"]["job_cpu_ms_alone"] + st["png_strip"]["job_cpu_ms_alone"], 2),
                                             "test (UCB)": round(st["loader_host_half"]["job_cpu_ms_alone"] + st["ucb_post"]["job_cpu_ms_alone"], 2)},
         "note": "items_per_sec = the stage ALONE through a pool of %d worker processes on %d usable CPUs; job_cpu_ms_alone = the same job run once in one "

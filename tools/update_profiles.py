@@ -41,7 +41,8 @@ head = ("* `%s_bench_n1%s.json` — `python bench.py%s` (N = 1, %d steps, %d war
         "all kernels %.1f TFLOP/s; CPU oracle %s images/s on %s host threads.\n"
         "* `%s_kernel_stats%s.csv` — `rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 1%s --no-cpu-baseline --no-secondary --repeats 1` (%d forwards, one at a time: with two in flight a traced duration would include the time a kernel shares the chip). Per forward:\n\n"
         % (tag, sfx, "" if dtype == "f32" else " --dtype " + dtype, b["steps"], b["warmup"], b["value"],
-           (" with two forwards in flight (`single_stream`, one at a time: %.0f)" % b["single_stream"]["value"]) if b.get("single_stream") else "",
+           ((" with two forwards in flight (`single_stream`, one at a time: %.0f)" % b["single_stream"]["value"]) if b.get("single_stream") else
+            (" one forward at a time (`two_in_flight`: %.0f)" % b["two_in_flight"]["value"]) if b.get("two_in_flight") else ""),
            b["ms_per_step"], b["config"]["images_per_gpu_per_step"],
            b["repeats"]["ms_per_step_min"], b["repeats"]["ms_per_step_median"], rf["kernel"].split(" — ")[0], rf["mfma_view"]["achieved_TFLOPs"],
            100 * rf["mfma_view"]["frac"], rf["mfma_view"]["peak_TFLOPs"],
