@@ -95,11 +95,21 @@ def crop_box(lm0: np.ndarray) -> Tuple[List[int], np.ndarray]:
     return box, lm / np.float32(length * 2)
 
 
+MASK_ORDER = ("face_hair", "face", "mouth", "nose", "eyebrow", "eye", "glasses")      # train_test_GSC.py:386-392 (= the keys of ucb_post.MASK_DIRS)
+
+
+def read_masks_u8(paths) -> np.ndarray:
+    """The seven mask images of one item as grey levels, [7,S,S] uint8 in MASK_ORDER: cv2.imread(...) of the reference (:386-393) returns
+    three equal channels of exactly these values; the / 255.0 happens on the device.  (Lives here, not in ucb_post_gpu: the loaders'
+    worker processes call it and must not pay for an `import torch`.)"""
+    from .pngio import read_grey_u8
+    return np.stack([read_grey_u8(paths[k]) for k in MASK_ORDER], axis=0)
+
+
 def pack_masks(paths) -> tuple:
-    """The seven UCB segmentation masks of one item (dict in ucb_post.MASK_DIRS order -> path) as grey levels, for the device
-    post-processing (ucb_post_gpu): ("bits", [7, S*S/8] uint8) when every level is 0 or 255 — what the reference's masks are; an eighth
-    of the bytes through the worker's pipe — else ("u8", [7,S,S] uint8)."""
-    from .ucb_post_gpu import read_masks_u8
+    """The seven UCB segmentation masks of one item (dict in MASK_ORDER -> path) as grey levels, for the device post-processing
+    (ucb_post_gpu): ("bits", [7, S*S/8] uint8) when every level is 0 or 255 — what the reference's masks are; an eighth of the bytes
+    through the worker's pipe — else ("u8", [7,S,S] uint8)."""
     m = read_masks_u8(paths)
     if m.shape[1] * m.shape[2] % 8 == 0 and bool(np.all((m == 0) | (m == 255))):
         return ("bits", np.packbits((m != 0).reshape(7, -1), axis=1), m.shape[1])

@@ -12,16 +12,11 @@ import torch
 from . import _lib
 from .ucb_post import MASK_DIRS
 
-MASK_ORDER = tuple(MASK_DIRS)            # face_hair, face, mouth, nose, eyebrow, eye, glasses (train_test_GSC.py:386-392)
+from .prep import MASK_ORDER, read_masks_u8      # noqa: F401  (re-exported: the mask order of bsr_ucb_post and the reader the loaders use)
+
+assert MASK_ORDER == tuple(MASK_DIRS)
 STATUS_TEXT = {1: "a segmentation mask the reference takes a bounding box of (nose / mouth / forehead / face) is empty after the resize",
                2: "the crop box is larger than the image or empty"}
-
-
-def read_masks_u8(paths: Dict[str, str]) -> np.ndarray:
-    """The seven mask images of one item as grey levels, [7,S,S] uint8 in MASK_ORDER: cv2.imread(...) of the reference (:386-393) returns
-    three equal channels of exactly these values; the / 255.0 happens on the device."""
-    from .pngio import read_grey_u8
-    return np.stack([read_grey_u8(paths[k]) for k in MASK_ORDER], axis=0)
 
 
 class UcbPostDevice:
