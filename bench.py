@@ -486,9 +486,11 @@ def roofline_in_flight(gens, lanes, run_on, B, dtype, dom_name, ms_per_step, n_r
 
 
 # kernel-group label (KERNEL_GROUPS / the 16-bit relabelling) -> substring of the rocprofv3 kernel names of that group
-GROUP_KERNEL_KEY = (("up2, up3, clr_up3", "<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32"), ("gemm_nloop", "gemm_nloop_kernel"), ("attention", "attention"),
+GROUP_KERNEL_KEY = (("up2, up3, clr_up3", "<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32"), ("gemm_nloop", "gemm_nloop_kernel<3,"), ("attention", "attention"),
                     ("(res*.conv2)", "<3, 3, 1, false"), ("(down1-3)", "<3, 3, 2, false"), ("clr_conv1", "conv_n16_kernel<3, 3"),
-                    ("heads", "conv_n16_kernel<7, 1"), ("stem7", "stem7_kernel"), ("(res*.conv1)", "<1, 1, 1, false"))
+                    ("heads", "conv_n16_kernel<7, 1"), ("stem7", "stem7_kernel"), ("(res*.conv1)", "<1, 1, 1, false"), ("(res*.conv1)", "gemm_nloop_kernel<4,"),
+                    ("up1, clr_up2", "<3, 3, 1, true, 4, 32, 4, 1, 1, 1, 32"), ("other instantiations", "<3, 3, 1, true, 4, 32, 4, 1, 1, 1,"),
+                    ("other instantiations", "<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 24"))
 
 
 def attach_traffic(rf, dom_name, B, dtype):
@@ -519,6 +521,38 @@ def attach_traffic(rf, dom_name, B, dtype):
                                   "algorithmic bytes per launch (input read once, output written once): %.4g"
                                   % (tag, sfx, n, sha, rf["hbm_view"]["alg_GBps"] * 1e9 * rf["avg_launch_ms"] * 1e-3))
         return
+
+
+def attach_group_traffic(rf, B, dtype):
+    """Every kernel group's HBM rate from the COUNTERS (the same committed passes as `traffic`: 2 x FETCH_SIZE + WRITE_SIZE per launch,
+    summed over the group's launches of one forward) beside the algorithmic one: `counter_GBps`, `hbm_frac_counters` (of the 8 TB/s
+    spec) and `traffic_ratio` = counter bytes / algorithmic bytes (re-reads show up here) — only while the kernel sources hash to what
+    the passes ran on."""
+    from blindshadowremoval_amd.build import source_sha16
+    sfx = "" if dtype == "f32" else "_" + dtype
+    tpath = next((os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx)) for tag in ("r5", "r4")
+                  if os.path.isfile(os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx)))), None)
+    if tpath is None:
+        return
+    with open(tpath) as ft:
+        t = json.load(ft)
+    if B != t.get("batch") or t.get("kernel_src_sha16") != source_sha16():
+        return
+    per = t.get("per_kernel") or {}
+    for gname, g in rf["kernel_groups"].items():
+        keys = [k for sub, k in GROUP_KERNEL_KEY if sub in gname]
+        rows = [v for k, v in per.items() if any(key in k for key in keys)]
+        if not rows or g["ms"] <= 0:
+            continue
+        nbytes = sum(v["hbm_bytes_per_forward"] for v in rows)
+        g["counter_GBps"] = round(nbytes / g["ms"] * 1e-6, 1)
+        g["hbm_frac_counters"] = round(nbytes / g["ms"] * 1e-6 / PEAK_HBM_GBPS, 4)
+        if g.get("alg_GBps"):
+            g["traffic_ratio"] = round(g["counter_GBps"] / g["alg_GBps"], 3)
+    rf["kernel_groups_traffic_note"] = ("counter_GBps / hbm_frac_counters / traffic_ratio: HBM bytes of the group's launches from %s (separate rocprofv3 --pmc passes on "
+                                        "these kernel sources) over the event-timed ms of this run.  read = 2 x FETCH_SIZE is calibrated for wide coalesced reads (16 B per lane over whole 128-B "
+                                        "lines: MI355X_MICROARCH.md, HBM); kernels that fetch 32- / 64-byte pieces of a line per request (the stride-2 layers' 16-channel chunks, "
+                                        "the 3x3 layers' halo columns) may be over-counted by up to 2x — read their ratios as upper bounds" % os.path.basename(tpath))
 
 
 def attach_mfma(rf, dom_name, B, dtype):
@@ -584,6 +618,7 @@ def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_p
         gen_b.close()
     rf, dom = roofline_from_events(gen, lambda: gen(inp, uv, out=out), B, "f32x3")
     attach_traffic(rf, dom, B, "f32x3")
+    attach_group_traffic(rf, B, "f32x3")
     attach_mfma(rf, dom, B, "f32x3")
     res = {"dtype": "f32x3", "value": round(B * args.steps / dt_serial, 2), "unit": "images/sec (this GPU, no collective)", "ms_per_step": round(dt_serial / args.steps * 1e3, 4),
            "steps": args.steps, "forwards_in_flight": 1, "value_mode": "one forward at a time",
@@ -899,6 +934,7 @@ def run_rank(args):
             else:
                 rf, dom_name = pre_rf if pre_rf is not None else roofline_from_events(gen, lambda: forward(0, lane=0), B, args.dtype)
                 attach_traffic(rf, dom_name, B, args.dtype)
+                attach_group_traffic(rf, B, args.dtype)
                 attach_mfma(rf, dom_name, B, args.dtype)
                 result["roofline"] = rf
                 if two is not None and not distributed:

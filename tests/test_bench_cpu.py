@@ -115,3 +115,30 @@ def test_run_loop_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, "-m", "blindshadowremoval_amd.run_loop", "--loop", "ffhq", "--data", "x", "--checkpoint-dir", "/tmp/none", "--device", "0"],
                        capture_output=True, text=True, timeout=300, env=env2, cwd=root)
     assert r.returncode == 2 and "--backend gloo" in r.stderr
+
+
+def test_kernel_group_traffic_from_the_committed_counter_passes(monkeypatch):
+    """bench.attach_group_traffic: every kernel group gets its HBM rate from the committed counter passes (profiles/r5_pmc_traffic*.json)
+    beside the algorithmic one — but only while the kernel sources hash to what the passes ran on (a stale figure is never quoted)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from blindshadowremoval_amd import build
+    for dtype, sfx in (("f32", ""), ("f16", "_f16")):
+        line = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_n1%s.json" % sfx)))
+        passes = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic%s.json" % sfx)))
+        rf = json.loads(json.dumps(line["roofline"]))
+        for g in rf["kernel_groups"].values():
+            g.pop("counter_GBps", None); g.pop("hbm_frac_counters", None); g.pop("traffic_ratio", None)
+        monkeypatch.setattr(build, "source_sha16", lambda: "0" * 16)
+        bench.attach_group_traffic(rf, 32, dtype)
+        assert not any("counter_GBps" in g for g in rf["kernel_groups"].values())          # other sources: nothing quoted
+        monkeypatch.setattr(build, "source_sha16", lambda: passes["kernel_src_sha16"])
+        bench.attach_group_traffic(rf, 32, dtype)
+        got = {k: g for k, g in rf["kernel_groups"].items() if "counter_GBps" in g}
+        assert len(got) >= 8, sorted(rf["kernel_groups"])
+        for k, g in got.items():
+            assert 0.5 < g["traffic_ratio"] < 2.5 and 0 < g["hbm_frac_counters"] < 1, (k, g)
+        bench.attach_group_traffic(rf, 16, dtype)                                          # another batch than the passes': untouched
