@@ -402,6 +402,10 @@ class Dataset:
         if self.workers > 0 and self._pool is None:
             self._pool = _SelectPool(self.workers)
             self._pool.warm("rows")
+        if self.device_prep is not None and getattr(self, "_dp", None) is None:
+            from .prep import DevicePrep
+            self._dp = DevicePrep(self.device_prep, self.config.IMG_SIZE)
+            self._dp.warm(max(8 << 20, self.device_batch * (2 * 3 * self.config.IMG_SIZE ** 2 + (64 << 10)) * 5 // 4))
 
     def __del__(self):
         try:
@@ -414,7 +418,7 @@ class Dataset:
             yield from self._iterate_host()
             return
         from .prep import DevicePrep
-        dp = DevicePrep(self.device_prep, self.config.IMG_SIZE)
+        dp = self._dp if getattr(self, "_dp", None) is not None else DevicePrep(self.device_prep, self.config.IMG_SIZE)
         group = []
 
         def emit():

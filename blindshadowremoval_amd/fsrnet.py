@@ -429,6 +429,7 @@ class FSRNet(object):
         self.gpu_inflight = 2                    # batches whose forward + device-to-host copy may be outstanding while the loop feeds the next one
         self.all_losses: List[Tuple[str, Dict[str, float]]] = []      # (name, losses) of EVERY item in list order — on every rank after a data-parallel loop
         self.timings: Dict[str, float] = {}      # wall-clock split of the last test / testFFHQ loop (see _loop)
+        self._pin_pool: List[Optional[torch.Tensor]] = []      # pinned device-to-host staging buffers of the loops (kept across loops; warm_pools() pre-allocates)
         self.post_device = True                  # FSRNet.test's post-processing on the GPU when the generator lives on one (ucb_post_gpu); False: the host forms below
         self.post_threads = 8                    # threads that post-process the items of one UCB batch (post_workers == 0)
         self.post_workers = 0                    # > 0: UCB post-processing in that many worker PROCESSES, pipelined one batch behind the GPU
@@ -450,6 +451,12 @@ class FSRNet(object):
         device post-processing (post_device on a GPU) run its kernels and the PNG encoder once on a dummy item — the first launch of a
         kernel family loads its code object, the first use of a torch operator its module: ~1 s in all on a fresh process."""
         dev = getattr(self.gen, "_device", None)
+        if dev is not None and torch.cuda.is_available():      # the loops' pinned staging buffers: gpu_inflight + 1 of a batch of 16 seven-figure strips each
+            while len(self._pin_pool) < int(self.gpu_inflight) + 1:
+                self._pin_pool.append(None)
+            for k in range(int(self.gpu_inflight) + 1):
+                if self._pin_pool[k] is None:
+                    self._pin_pool[k] = torch.empty(24 << 20, dtype=torch.uint8).pin_memory()
         if self.post_device and dev is not None and torch.cuda.is_available():
             from .prep import unpack_masks
             from .ucb_post_gpu import UcbPostDevice
@@ -577,8 +584,12 @@ class FSRNet(object):
         dev = "cuda:%d" % self.gen._device if getattr(self.gen, "_device", None) is not None else "cpu"
         on_gpu = dev != "cpu"
         depth = max(0, int(self.gpu_inflight)) if on_gpu else 0
-        pins: List[Optional[torch.Tensor]] = [None] * (depth + 1)      # pinned staging buffers, one per batch that may be outstanding (+ the one being filled)
-        pin_busy: List[List] = [[] for _ in range(depth + 1)]          # file writes still reading a pinned buffer (gpu_png): waited for before its turn comes again
+        # pinned staging buffers, one per batch that may be outstanding (+ the one being filled).  They belong to the FSRNet object and
+        # survive the loop: page-locking a buffer costs ~60 ms (measured: five of them were a quarter of a 2 000-item loop's wall time)
+        while len(self._pin_pool) < depth + 1:
+            self._pin_pool.append(None)
+        pins = self._pin_pool
+        pin_busy: List[List] = [[] for _ in range(max(depth + 1, len(self._pin_pool)))]          # file writes still reading a pinned buffer (gpu_png): waited for before its turn comes again
         gpu_png = on_gpu and self.log.gpu_png
         gpu_q: List[Tuple] = []             # submitted batches whose device-to-host copy may still be running, oldest first
         turn = [0]
@@ -671,7 +682,7 @@ class FSRNet(object):
                 ev.record()
                 return view.numpy(), ev, slot
             k = turn[0]
-            turn[0] = (k + 1) % len(pins)
+            turn[0] = (k + 1) % (depth + 1)
             for fu in pin_busy[k]:                # the file writes of the batch that used this buffer depth + 1 submissions ago
                 fu.result()
             pin_busy[k] = []

@@ -213,6 +213,12 @@ class DevicePrep:
         self.device, self.size = int(device), int(size)
         self._stage, self._copied = [None, None], [None, None]
 
+    def warm(self, nbytes: int = 8 << 20) -> None:
+        """Page-lock the two staging buffers now (~60 ms each) instead of inside the first two batches of a timed loop."""
+        for k in (0, 1):
+            if self._stage[k] is None or self._stage[k].numel() < nbytes:
+                self._stage[k] = self._torch.empty(nbytes, dtype=self._torch.uint8).pin_memory()
+
     def rows(self, parts):
         torch = self._torch
         B, S = len(parts), self.size

@@ -93,8 +93,7 @@ def main(argv=None) -> int:
     try:
         ds.warm()
         fsr.log.warm()
-        if ucb:
-            fsr.warm_pools()
+        fsr.warm_pools()
         if grouped:
             import torch.distributed as dist
             dist.barrier()
