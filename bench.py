@@ -390,7 +390,9 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
         gflop = 2e-3 * sum(launch_mmac(n) for n in layers) * B
         gpeak = group_peak(layers, dtype)
         label = gname
-        if gpeak != PEAK_F32_MFMA_TFLOPS:          # the 16-bit instantiations (csrc/igemm_h16.h, attention_x3.h, gemm_nloop / conv_n16 with H = 2)
+        if gpeak != PEAK_F32_MFMA_TFLOPS and "(res*.conv1)" in gname and B * 8 * 2 >= 256:
+            label = "gemm_nloop_kernel<4,NCH,H=2,MINW=1> (res*.conv1)"      # round 5: the resident-activation GEMM at full batches (csrc/gemm_nloop.h)
+        elif gpeak != PEAK_F32_MFMA_TFLOPS:        # the 16-bit instantiations (csrc/igemm_h16.h, attention_x3.h, gemm_nloop / conv_n16 with H = 2)
             label = (gname.replace("igemm_conv_kernel", "igemm_h16_kernel").replace("nonlocal_attention_kernel", "nonlocal_attention_x3_kernel")
                      .replace("gemm_nloop_kernel", "gemm_nloop_kernel<..,H=2>").replace("conv_n16_kernel<", "conv_n16_kernel<H=2,")
                      .replace("stem7_kernel", "stem7_kernel<4,H=2>"))
