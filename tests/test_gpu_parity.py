@@ -9,6 +9,30 @@ from blindshadowremoval_amd.weights import init_weights
 
 pytestmark = pytest.mark.gpu
 
+# Tolerance of the f16 mode (BASELINE configs[3]) against the fp32 oracle, and its measured margin PER TEST (round 5: the review asked for
+# the measured value beside every use; profiles/r5_f16_margins.txt holds the lines these tests wrote on the MI355X):
+#   test_f16_mfma_mode_tracks_the_fp32_oracle      B = 2               max abs err 1.264e-3  (63 % of F16_TOL)
+#   test_config3_rank_shape_f16_batch32            B = 32              max abs err 1.373e-3  (69 %)
+#   test_config3_full_size_f16_batch256            8 rows of B = 256   max abs err 1.309e-3  (65 %)
+#   test_tsm_f16_mode_tracks_the_oracle            TSM, B = 4          max abs err 1.542e-3  (77 %)
+# A margin below 20 % of the tolerance fails the test: a kernel change that eats the headroom is noticed before it eats the tolerance.
+F16_TOL = 2e-3
+F16_MIN_MARGIN = 0.20
+
+
+def _note_f16_margin(test: str, err: float) -> None:
+    import os
+    line = "%s max_abs_err %.3e tol %.1e used %.0f%%" % (test, err, F16_TOL, 100 * err / F16_TOL)
+    print(line)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "f16_margins.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    assert err <= (1.0 - F16_MIN_MARGIN) * F16_TOL, "f16 mode: %s — less than %.0f %% of the tolerance is left" % (line, 100 * F16_MIN_MARGIN)
+
 PROBES = ("x1", "x2", "x3", "x0", "res0", "res1", "res2", "up1", "up2", "y", "res3", "res4", "res5", "f")
 
 
@@ -279,13 +303,13 @@ def test_f16_mfma_mode_tracks_the_fp32_oracle():
     fast path is dtype "f32x3" (run by every gen_w test above under the unchanged fp32 tolerances)."""
     from blindshadowremoval_amd import Generator
     from parity_util import run_and_compare
-    F16_TOL = 2e-3          # measured 1.2e-3 on this input (profiles/README.md) + 50 %
     weights = init_weights(1)
     gen = Generator(dtype="f16").load_weights(weights)
     g = torch.Generator().manual_seed(5)
     inp, uv = torch.rand(2, 256, 256, 3, generator=g), torch.rand(2, 256, 256, 3, generator=g)
     out, ref, errs, nflip = run_and_compare(gen, weights, inp, uv, tol=F16_TOL, flip_tol=F16_TOL)
     print("f16 mode: max abs err", errs, "bmask flips", nflip)
+    _note_f16_margin("test_f16_mfma_mode_tracks_the_fp32_oracle", max(errs.values()))
     assert max(errs.values()) > 1e-6          # it really is a different arithmetic (guards against silently running fp32)
     gen.close()
 
@@ -295,13 +319,13 @@ def test_config3_rank_shape_f16_batch32():
     GPU against the fp32 oracle, all 32 rows, same tolerance as the B = 2 test above."""
     from blindshadowremoval_amd import Generator
     from parity_util import run_and_compare
-    F16_TOL = 2e-3
     weights = init_weights(1)
     gen = Generator(dtype="f16").load_weights(weights)
     g = torch.Generator().manual_seed(21)
     inp, uv = torch.rand(32, 256, 256, 3, generator=g), torch.rand(32, 256, 256, 3, generator=g)
     out, ref, errs, nflip = run_and_compare(gen, weights, inp, uv, tol=F16_TOL, flip_tol=F16_TOL)
     print("f16 B=32: max abs err", errs, "bmask flips", nflip)
+    _note_f16_margin("test_config3_rank_shape_f16_batch32", max(errs.values()))
     assert out[1].shape == (32, 256, 256, 3)
     gen.close()
 
@@ -458,7 +482,6 @@ def test_config3_full_size_f16_batch256():
     size-independent output properties on all 256."""
     from blindshadowremoval_amd import Generator
     from oracle.gsc_oracle import GeneratorOracle
-    F16_TOL = 2e-3
     weights = init_weights(1)
     gen = Generator(dtype="f16").load_weights(weights)
     g = torch.Generator().manual_seed(41)
@@ -484,10 +507,13 @@ def test_config3_full_size_f16_batch256():
     flips = bm_big[rows].cpu() != pr["bmask"]
     assert not flips.any() or float((pr["d32"][flips] - 0.1).abs().max()) < F16_TOL
     ref = oracle(inp[rows], uv[rows], bmask_override=bm_big[rows].cpu())
+    worst = 0.0
     for a, b, name in zip(big, ref, ("gs", "con_rgb", "mask22", "dif")):
         err = float((a[rows].cpu() - b).abs().max())
         print("configs[3] B=256 f16 %s max abs err %.3e" % (name, err))
         assert err <= F16_TOL, name
+        worst = max(worst, err)
+    _note_f16_margin("test_config3_full_size_f16_batch256", worst)
     gen.close()
 
 
@@ -566,7 +592,6 @@ def test_tsm_f16_mode_tracks_the_oracle():
     tolerance — the combination FSRNetTSM(dtype="f16") would run."""
     from blindshadowremoval_amd import GeneratorTSM
     from oracle.gsc_oracle import GeneratorTSMOracle
-    F16_TOL = 2e-3
     w = init_weights(1, variant="tsm")
     gen = GeneratorTSM(dtype="f16").load_weights(w)
     g = torch.Generator().manual_seed(53)
@@ -584,10 +609,13 @@ def test_tsm_f16_mode_tracks_the_oracle():
     flips = bmask != pr["bmask"]
     assert not flips.any() or float((pr["d32"][flips] - 0.1).abs().max()) < F16_TOL
     ref = oracle(inp, uv, reg, 2, True, bmask_override=bmask)
+    worst = 0.0
     for a, b, name in zip(out, ref, ("gs", "con_rgb", "mask22", "dif")):
         err = float((a - b).abs().max())
         print("TSM f16 %s max abs err %.3e" % (name, err))
         assert err <= F16_TOL, name
+        worst = max(worst, err)
+    _note_f16_margin("test_tsm_f16_mode_tracks_the_oracle", worst)
     gen.close()
 
 
