@@ -39,6 +39,9 @@
 #ifndef BSR_H16_RING
 #define BSR_H16_RING 4      // slots of the LDS-DMA weight ring: the image of step s + RING - 1 is requested at the top of step s
 #endif
+#ifndef BSR_H16_BDEEP
+#define BSR_H16_BDEEP 0     // 1: f16 transposed convs read the B fragments of a whole step one step ahead (measured: 355.9 vs 358.1 us, nothing — off)
+#endif
 #ifndef BSR_H16_FETCH_TAP_F16
 #define BSR_H16_FETCH_TAP_F16 5   // = T - 4 of the transposed 3x3 layers
 #endif
@@ -387,9 +390,22 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         }
       }
     };
+    // BDEEP (round 5, f16 mode): the B fragments of a WHOLE step are read one step before their matrix instructions (two register sets
+    // by step parity) instead of one K group ahead.  With fp16 operands a K group is two 32-cycle matrix instructions; an LDS round
+    // trip under eight reading waves is 150-200 cycles, so every group waited for its fragments (98 cycles per matrix instruction
+    // measured in round 3; the stamps of the attention experiment, profiles/HISTORY.md round 5, show the same 44-80).  The image of
+    // step s + 1 is complete when step s starts (the previous barrier published it).
+    constexpr bool BDEEP = BSR_H16_BDEEP && NSPLIT == 1;
+    f16x8 Bh[BDEEP ? 2 : 1][G][NI];
+    auto read_b_step = [&](int set, int w_off_) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Bh[set][g][ni] = *reinterpret_cast<const f16x8*>(s_w + b_base[ni] + w_off_ + g * 8);
+    };
 #pragma unroll
     for (int g = 0; g < G; ++g) read_a(g, tap_offset(tap_at(0)));
-    read_b(0, w_cur, 0);
+    if constexpr (BDEEP) read_b_step(0, w_cur); else read_b(0, w_cur, 0);
     __builtin_amdgcn_s_setprio(0);
 #ifdef BSR_STAMPS
     st1 = __builtin_amdgcn_s_memtime();
@@ -413,24 +429,33 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         const int ph = ((t / 3 == 1) ? 2 : 0) + ((t % 3 == 1) ? 1 : 0);
         const bool a_last = q + 1 < T && tap_offset(tap_at(q + 1 < T ? q + 1 : q)) != tap_offset(t);      // the next tap reads another input offset
+        if constexpr (BDEEP) {
+          if (q + 1 < T) read_b_step((q + 1) & 1, w_n1);
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const int cur = (q * G + g) & 1, nxt = cur ^ 1;
-          if (g + 1 < G) {
-            read_b(nxt, w_cur, g + 1);
-          } else if (q + 1 < T) {
-            read_b(nxt, w_n1, 0);
+          if constexpr (!BDEEP) {
+            if (g + 1 < G) {
+              read_b(nxt, w_cur, g + 1);
+            } else if (q + 1 < T) {
+              read_b(nxt, w_n1, 0);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              if (NSPLIT == 2) {
-                acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aL[g][mi], bh[cur][ni], acc[ph][mi][ni], 0, 0, 0);
-                acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH[g][mi], bl[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+              if constexpr (BDEEP) {
+                acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH[g][mi], Bh[q & 1][g][ni], acc[ph][mi][ni], 0, 0, 0);
+              } else {
+                if (NSPLIT == 2) {
+                  acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aL[g][mi], bh[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+                  acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH[g][mi], bl[cur][ni], acc[ph][mi][ni], 0, 0, 0);
+                }
+                acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH[g][mi], bh[cur][ni], acc[ph][mi][ni], 0, 0, 0);
               }
-              acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH[g][mi], bh[cur][ni], acc[ph][mi][ni], 0, 0, 0);
             }
           __builtin_amdgcn_sched_barrier(0);
           if (a_last) {                 // in place, behind the last instructions that read the old fragments
@@ -460,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
           __builtin_amdgcn_s_barrier();
 #pragma unroll
           for (int g = 0; g < G; ++g) read_a(g, tap_offset(tap_at(0)));
-          read_b((T * G) & 1, w_n1, 0);
+          if constexpr (BDEEP) read_b_step(0, w_n1); else read_b((T * G) & 1, w_n1, 0);
         }
         const int tw = w_cur; w_cur = w_n1; w_n1 = w_n2; w_n2 = w_far[0];
 #pragma unroll
