@@ -43,16 +43,18 @@ def _hipcc() -> str:
 
 
 def library_sha16(path: str = None) -> str:
-    """The source hash compiled into a built library (its bsr_source_sha() export), read without touching the GPU; '' if the
-    file is not a library of this ABI generation."""
-    import ctypes
+    """The source hash compiled into a built library, read from the FILE (the bytes behind its "BSR_SRC_SHA=" tag) — nothing is
+    loaded into the process (a dlopen here, before torch is imported, would bring a second HIP runtime in); '' if there is none."""
     try:
-        lib = ctypes.CDLL(path or LIB_PATH)
-        fn = lib.bsr_source_sha
-    except (OSError, AttributeError):
+        with open(path or LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
         return ""
-    fn.restype = ctypes.c_char_p
-    return (fn() or b"").decode()
+    i = blob.find(b"BSR_SRC_SHA=")
+    if i < 0:
+        return ""
+    tail = blob[i + 12:i + 12 + 32].split(b"\0", 1)[0]
+    return tail.decode(errors="replace")
 
 
 def is_stale() -> bool:

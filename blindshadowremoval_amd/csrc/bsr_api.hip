@@ -442,7 +442,9 @@ int bsr_abi_version(void) { return 5; }
 #ifndef BSR_SRC_SHA
 #define BSR_SRC_SHA "unhashed"
 #endif
-const char* bsr_source_sha(void) { return BSR_SRC_SHA; }
+// the tag makes the hash findable in the FILE (build.library_sha16 reads it without loading the library into the process)
+static const char kSrcShaTag[] = "BSR_SRC_SHA=" BSR_SRC_SHA;
+const char* bsr_source_sha(void) { return kSrcShaTag + 12; }
 
 const char* bsr_last_error(void) { return g_last_error.c_str(); }
 

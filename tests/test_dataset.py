@@ -292,3 +292,41 @@ def test_select_pool_png_jobs_through_shared_memory(tmp_path):
         os.unlink(shm)
     for j in range(5):
         assert np.array_equal(np.asarray(Image.open(os.path.join(str(tmp_path), "s%d.png" % j))), strips[j])
+
+
+def test_ucb_masks_travel_bit_packed_with_the_loader_job(golden_dir):
+    """Round 5 (device post-processing): the loader's worker decodes the item's seven segmentation masks next to its image and sends them
+    bit-packed; unpacked (on whatever device) they are the grey levels PIL reads, in the order of train_test_GSC.py:386-392.  CPU only:
+    the host half of a device-prepared row (prep.host_part) + prep.pack_masks / unpack_masks."""
+    import torch
+    from PIL import Image
+    from blindshadowremoval_amd import prep
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    from blindshadowremoval_amd.ucb_post import MASK_DIRS
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    assert prep.MASK_ORDER == tuple(MASK_DIRS)
+    ds = D.Dataset(cfg, "test", ucb=True)
+    fsr = FSRNet.__new__(FSRNet)
+    fsr.config = cfg
+    mf = fsr._ucb_masks()
+    ds.device_prep = 0                                   # only to make _jobs() emit the device form of the job; nothing touches a GPU here
+    ds.ucb_mask_files = mf
+    jobs = list(ds._jobs())[:3]
+    assert all(len(j[1]) == 3 and j[1][0] == "<device>" and j[1][2] is mf[i] for i, j in enumerate(jobs))
+    parts = [D.build_element(j) for j in jobs]
+    assert all(len(p) == 6 and p[5][0] == "bits" and p[5][1].shape == (7, 256 * 256 // 8) and p[5][2] == 256 for p in parts)
+    un = prep.unpack_masks([p[5] for p in parts], torch.device("cpu")).numpy()
+    assert un.shape == (3, 7, 256, 256) and un.dtype == np.uint8
+    for i in range(3):
+        for k, key in enumerate(prep.MASK_ORDER):
+            assert np.array_equal(un[i, k], np.asarray(Image.open(mf[i][key]).convert("L"), np.uint8)), (i, key)
+    # a mask that is not binary travels as grey levels; a mixed batch is unpacked on the host
+    grey = ("u8", np.arange(7 * 256 * 256, dtype=np.uint32).reshape(7, 256, 256).astype(np.uint8), 256)
+    mixed = prep.unpack_masks([parts[0][5], grey], torch.device("cpu")).numpy()
+    assert np.array_equal(mixed[0], un[0]) and np.array_equal(mixed[1], grey[1])
+    # without mask files the job is the round-3 form
+    ds2 = D.Dataset(cfg, "test", ucb=True)
+    ds2.device_prep = 0
+    assert len(next(iter(ds2._jobs()))[1]) == 2
