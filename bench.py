@@ -398,6 +398,9 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
                      .replace("stem7_kernel", "stem7_kernel<4,H=2>"))
         gbytes = 1e-9 * sum(layer_bytes(n, dtype) for n in layers) * B
         groups[label] = {"ms": round(ms, 4), "launches": len(layers), "tflops": round(gflop / ms, 2), "peak": round(gpeak, 1),
+                         "peak_kind": ("hardware roof: fp32 matrix pipe" if gpeak == PEAK_F32_MFMA_TFLOPS else
+                                       "hardware roof: dense fp16 matrix pipe" if gpeak == PEAK_F16_MFMA_TFLOPS else
+                                       "emulation-adjusted ceiling, NOT a hardware roof: the fp16 matrix peak / 3 (one algorithmic MAC = three fp16 MACs: hi.hi + hi.lo + lo.hi)"),
                          "frac": round(gflop / ms / gpeak, 4), "alg_GBps": round(gbytes / ms * 1e3, 1), "hbm_frac": round(gbytes / ms * 1e3 / PEAK_HBM_GBPS, 4),
                          "gflop": gflop}
         gexec = 2e-3 * sum(launch_mmac_executed(n) for n in layers) * B
@@ -422,7 +425,7 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
     glue_ms = sum(ms for n, ms in layer_ms.items() if n not in LAYER_MMAC and n not in FUSED_LAUNCHES)
     # the dominant kernel is priced against both roofs; `bound` names the nearer one (fp32 kernels: the fp32 matrix pipe; the 16-bit
     # kernels of f32x3 / f16: HBM once the matrix work has shrunk by 16/3 or 16)
-    mfma_view = {"achieved_TFLOPs": dom["tflops"], "peak_TFLOPs": peak, "frac": dom["frac"]}
+    mfma_view = {"achieved_TFLOPs": dom["tflops"], "peak_TFLOPs": peak, "frac": dom["frac"], "peak_kind": dom["peak_kind"]}
     hbm_view = {"alg_GBps": dom["alg_GBps"], "peak_GBps": PEAK_HBM_GBPS, "frac": dom["hbm_frac"],
                 "note": "algorithmic activation bytes (input read once + output written once) / device time of the same launches"}
     hbm_bound = dom["hbm_frac"] > dom["frac"]
