@@ -491,7 +491,7 @@ def roofline_in_flight(gens, lanes, run_on, B, dtype, dom_name, ms_per_step, n_r
 
 
 # kernel-group label (KERNEL_GROUPS / the 16-bit relabelling) -> substring of the rocprofv3 kernel names of that group
-GROUP_KERNEL_KEY = (("up2, up3, clr_up3", "<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32"), ("gemm_nloop", "gemm_nloop_kernel<3,"), ("attention", "attention"),
+GROUP_KERNEL_KEY = (("up2, up3, clr_up3", "<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32"), ("(res*.c3q", "gemm_nloop_kernel<3,"), ("attention", "attention"),
                     ("(res*.conv2)", "<3, 3, 1, false"), ("(down1-3)", "<3, 3, 2, false"), ("clr_conv1", "conv_n16_kernel<3, 3"),
                     ("heads", "conv_n16_kernel<7, 1"), ("stem7", "stem7_kernel"), ("(res*.conv1)", "<1, 1, 1, false"), ("(res*.conv1)", "gemm_nloop_kernel<4,"),
                     ("up1, clr_up2", "<3, 3, 1, true, 4, 32, 4, 1, 1, 1, 32"), ("other instantiations", "<3, 3, 1, true, 4, 32, 4, 1, 1, 1,"),

@@ -8,6 +8,10 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbsr_hip.so")
 SOURCES = ["csrc/bsr_api.hip"]
+# the loaders' host-side helper (plain C, gcc, no GPU code: PNG scanline reconstruction for the worker processes) — its own small
+# library so that a worker can load it without bringing the HIP runtime in
+HOST_LIB_PATH = os.path.join(PKG_DIR, "libbsr_host.so")
+HOST_SOURCES = ["hostsrc/png_unfilter.c"]
 
 
 def _deps():
@@ -97,3 +101,48 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
+
+
+def host_source_sha16() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in HOST_SOURCES:
+        with open(os.path.join(PKG_DIR, f), "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def host_library_sha16(path: str = None) -> str:
+    try:
+        with open(path or HOST_LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return ""
+    i = blob.find(b"BSR_HOST_SHA=")
+    return blob[i + 13:i + 13 + 32].split(b"\0", 1)[0].decode(errors="replace") if i >= 0 else ""
+
+
+def build_host_library(force: bool = False) -> str:
+    """gcc -O3 -> blindshadowremoval_amd/libbsr_host.so (in-tree, bound to its source by an embedded hash like libbsr_hip.so)."""
+    if not force and host_library_sha16() == host_source_sha16():
+        return HOST_LIB_PATH
+    import fcntl
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("no C compiler: libbsr_host.so cannot be built")
+    with open(HOST_LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and host_library_sha16() == host_source_sha16():
+                return HOST_LIB_PATH
+            tmp = "%s.%d.tmp" % (HOST_LIB_PATH, os.getpid())
+            cmd = [cc, "-O3", "-shared", "-fPIC", '-DBSR_HOST_SHA="%s"' % host_source_sha16(), "-o", tmp] + [os.path.join(PKG_DIR, s) for s in HOST_SOURCES]
+            res = subprocess.run(cmd, cwd=PKG_DIR, capture_output=True, text=True)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("building libbsr_host.so failed:\n" + res.stderr[-4000:])
+            os.replace(tmp, HOST_LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return HOST_LIB_PATH

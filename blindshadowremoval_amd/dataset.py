@@ -399,6 +399,8 @@ class Dataset:
 
     def warm(self) -> None:
         """Start the worker processes and let them import their modules now (otherwise the first elements pay for it)."""
+        from .pngio import _host_lib
+        _host_lib()                               # libbsr_host.so (the workers' PNG reconstruction) is built HERE, once, not by the first worker that needs it
         if self.workers > 0 and self._pool is None:
             self._pool = _SelectPool(self.workers)
             self._pool.warm("rows")

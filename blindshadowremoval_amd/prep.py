@@ -28,11 +28,8 @@ assert ROW_DTYPE.itemsize == 88
 
 
 def _imread_u8(path: str) -> np.ndarray:
-    from PIL import Image
-    im = Image.open(path)
-    if im.mode != "RGB":                      # an RGB file is decoded straight into the array (convert() would copy it once more)
-        im = im.convert("RGB")
-    return np.ascontiguousarray(np.asarray(im, np.uint8))
+    from .pngio import read_rgb_u8            # round 5: plain 8-bit PNG files bypass PIL's decoder (4x faster; pngio.read_rgb_u8)
+    return read_rgb_u8(path)
 
 
 def _tri_table(tri, zs: Sequence[np.ndarray]) -> np.ndarray:

@@ -97,3 +97,24 @@ def test_a_stale_library_is_refused(lib, tmp_path):
              "print('STALE' if build.is_stale() else 'FRESH')\n" % (ROOT, str(stale)))
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
     assert r.stdout.strip() == "STALE", r.stdout + r.stderr
+
+
+def test_host_helper_library_exports_its_header():
+    """include/bsr_host.h (the loaders' plain-C helper, libbsr_host.so): consumable by a C compiler, every declared symbol exported."""
+    import ctypes
+    import re
+    import shutil
+    import subprocess
+    from blindshadowremoval_amd import build
+    hdr = os.path.join(ROOT, "include", "bsr_host.h")
+    gcc = shutil.which("gcc")
+    if gcc:
+        res = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+    names = re.findall(r"\b(bsr_[a-z0-9_]+)\s*\(", open(hdr).read())
+    assert set(names) == {"bsr_png_unfilter", "bsr_host_source_sha"}
+    lib = ctypes.CDLL(build.build_host_library())
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.bsr_host_source_sha.restype = ctypes.c_char_p
+    assert lib.bsr_host_source_sha().decode() == build.host_source_sha16()

@@ -67,3 +67,83 @@ def test_fast_grey_reader_equals_pil(tmp_path):
         q = tmp_path / ("pil_%s.png" % mode)
         Image.fromarray(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)).convert(mode).save(q)
         assert np.array_equal(read_grey_u8(str(q)), np.asarray(Image.open(q).convert("L"), np.uint8))
+
+
+def _filtered_png(a: np.ndarray, filters) -> bytes:
+    """A PNG file of `a` [H,W,C] whose scanline y uses filter type filters[y % len(filters)] — the forward filters of the PNG
+    specification (9.2) written out with numpy, so that every reconstruction branch of hostsrc/png_unfilter.c gets real input."""
+    import struct
+    import zlib
+    from blindshadowremoval_amd.pngio import _SIGNATURE, _chunk
+    h, w, c = a.shape
+    x = a.reshape(h, w * c).astype(np.int32)
+    left = np.zeros_like(x); left[:, c:] = x[:, :-c]
+    up = np.zeros_like(x); up[1:] = x[:-1]
+    ul = np.zeros_like(x); ul[1:, c:] = x[:-1, :-c]
+    p = left + up - ul
+    pa, pb, pc = abs(p - left), abs(p - up), abs(p - ul)
+    paeth = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, ul))
+    forms = [x, x - left, x - up, x - ((left + up) >> 1), x - paeth]
+    raw = np.empty((h, 1 + w * c), np.uint8)
+    for y in range(h):
+        ft = filters[y % len(filters)]
+        raw[y, 0] = ft
+        raw[y, 1:] = forms[ft][y] & 255
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2, 4: 6}[c], 0, 0, 0)
+    z = zlib.compress(raw.tobytes(), 1)
+    cut = len(z) // 3                                  # several IDAT chunks, as real encoders write them
+    return b"".join((_SIGNATURE, _chunk(b"IHDR", ihdr), _chunk(b"IDAT", z[:cut]), _chunk(b"IDAT", z[cut:]), _chunk(b"IEND", b"")))
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("filters", [(0,), (1,), (2,), (3,), (4,), (4, 3, 1, 2, 0), (2, 4, 4, 3)])
+def test_fast_reader_reconstructs_every_filter_type_like_pil(tmp_path, c, filters):
+    """pngio.read_rgb_u8 / read_grey_u8 through libbsr_host.so (hostsrc/png_unfilter.c: Sub / Up / Average / Paeth, the SIMD Paeth for
+    3 and 4 channels) against PIL's decoder, on smooth and on random content, odd sizes included."""
+    from blindshadowremoval_amd import pngio
+    assert pngio._host_lib() is not None, "libbsr_host.so did not build"
+    rng = np.random.default_rng(7 * c + len(filters))
+    for h, w in ((1, 1), (2, 3), (29, 37), (64, 64)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        smooth = ((yy * 3 + xx * 5)[:, :, None] + np.arange(c) * 40 + rng.integers(0, 6, (h, w, c))) & 255
+        for a in (smooth.astype(np.uint8), rng.integers(0, 256, (h, w, c), dtype=np.uint8)):
+            path = tmp_path / "f.png"
+            path.write_bytes(_filtered_png(a, filters))
+            want = Image.open(path)
+            np.testing.assert_array_equal(np.asarray(want).reshape(h, w, c), a)                      # the test's own encoder is a valid PNG
+            fast = pngio._decode_fast(path.read_bytes())
+            assert fast is not None
+            np.testing.assert_array_equal(fast, a)
+            np.testing.assert_array_equal(pngio.read_rgb_u8(str(path)), np.asarray(want.convert("RGB")))
+            if c == 1:
+                np.testing.assert_array_equal(pngio.read_grey_u8(str(path)), a[:, :, 0])
+
+
+def test_fast_reader_leaves_other_files_to_pil(tmp_path):
+    """Palette, 16-bit, interlaced-free-but-gamma'd and non-PNG files: not a case for the C path, PIL's conversion comes back."""
+    from blindshadowremoval_amd import pngio
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (20, 24, 3), dtype=np.uint8)
+    pal = tmp_path / "p.png"
+    Image.fromarray(rgb).quantize(16).save(pal)
+    deep = tmp_path / "d.png"
+    Image.fromarray(rng.integers(0, 65536, (20, 24), dtype=np.uint16)).save(deep)
+    jpg = tmp_path / "j.jpg"
+    Image.fromarray(rgb).save(jpg, quality=90)
+    for path in (pal, deep, jpg):
+        assert pngio._decode_fast(path.read_bytes()) is None
+        np.testing.assert_array_equal(pngio.read_rgb_u8(str(path)), np.asarray(Image.open(path).convert("RGB"), np.uint8))
+    # a corrupt stream / an undefined filter type is refused by the C path (and then by PIL: the error is PIL's)
+    bad = bytearray(_filtered_png(rgb, (1,)))
+    assert pngio._decode_fast(bytes(bad[:-40])) is None
+    import zlib, struct
+    raw = np.zeros((4, 1 + 12), np.uint8); raw[2, 0] = 7
+    body = b"".join((pngio._SIGNATURE, pngio._chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)), pngio._chunk(b"IDAT", zlib.compress(raw.tobytes())),
+                     pngio._chunk(b"IEND", b"")))
+    assert pngio._decode_fast(body) is None
+
+
+def test_host_library_is_bound_to_its_source():
+    from blindshadowremoval_amd import build
+    path = build.build_host_library()
+    assert build.host_library_sha16(path) == build.host_source_sha16() != ""
