@@ -37,6 +37,10 @@ def main() -> int:
                 else:
                     import matplotlib.tri  # noqa: F401
                     import PIL.Image  # noqa: F401
+                    if len(job) > 2:                                                 # map the parent's shared-memory ring while its file still has a name
+                        import numpy as np
+                        from blindshadowremoval_amd import prep
+                        prep._RING_VIEWS[job[2]] = np.memmap(job[2], np.uint8, "r+")
                 time.sleep(0.2)                                                      # keeps this worker busy so that the pool starts the others too
                 result = True
             elif isinstance(job, tuple) and job and job[0] == "png":                 # ("png", path, uint8 strip | (shm file, shape, index)): Logging(png_workers=N)

@@ -287,10 +287,11 @@ def build_sfw_video(label_path: str, size: int = 256) -> Tuple[np.ndarray, np.nd
 def build_element(job) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """One dataset element `(img[1,R,size,size,16], box[1,4], name[1])` from a job `(lm_path, gt_path, sibling lm paths, size)`.
     Top-level so that worker processes can run it (the rows of an element never depend on another element)."""
-    lm_path, gt_path, siblings, size = job
+    lm_path, gt_path, siblings, size = job[:4]
     if isinstance(gt_path, tuple) and gt_path[0] == "<device>":            # the host half of a device-prepared row (prep.py)
-        from .prep import host_part
-        return host_part((lm_path, gt_path[1], size) + ((gt_path[2],) if len(gt_path) > 2 else ()))
+        from .prep import host_part, host_part_ring
+        hjob = (lm_path, gt_path[1], size) + ((gt_path[2],) if len(gt_path) > 2 else ())
+        return host_part_ring(hjob, job[4]) if len(job) > 4 else host_part(hjob)            # job[4]: (ring file, slot, slot bytes)
     if gt_path == "<sfw>":
         return build_sfw_pair(lm_path, size)
     if gt_path == "<sfw_video>":
@@ -382,14 +383,36 @@ class Dataset:
                 # ucb_mask_files (set by FSRNet.test for its device post-processing): the item's seven mask PNGs are decoded by the same
                 # worker that decodes its image, and travel bit-packed
                 masks = self.ucb_mask_files[i] if self.ucb_mask_files is not None else None
-                yield (lm_path, ("<device>", gt) + ((masks,) if masks is not None else ()), sibs, size)
+                job = (lm_path, ("<device>", gt) + ((masks,) if masks is not None else ()), sibs, size)
+                ring = getattr(self, "_ring", None)
+                if ring is not None:
+                    # the k-th device job of this Dataset writes slot k mod nslots; that slot last held job k - nslots, whose batch has
+                    # been handed to the copy engine long ago (nslots >= prefetch + 3 batches) — its copy must have FINISHED
+                    k = self._ring_seq
+                    self._ring_seq += 1
+                    if k >= ring.nslots:
+                        while self._ring_copies and self._ring_copies[0][0] <= k - ring.nslots:       # batches that ended before that job: older copies
+                            self._ring_copies.pop(0)
+                        if not self._ring_copies:
+                            raise RuntimeError("loader ring: slot %d is still waiting for its batch (ring of %d slots too small)" % (k % ring.nslots, ring.nslots))
+                        if not self._ring_copies[0][2]:
+                            self._ring_copies[0][1].synchronize()
+                            self._ring_copies[0][2] = True
+                    job = job + ((ring.path_for_workers, k % ring.nslots, ring.cap),)
+                yield job
             else:
                 yield (lm_path, gt, sibs, size)
 
-    def close(self) -> None:
+    def _close_pool(self) -> None:
         pool, self._pool = self._pool, None
         if pool is not None:
             pool.shutdown()
+
+    def close(self) -> None:
+        self._close_pool()
+        ring, self._ring = getattr(self, "_ring", None), None
+        if ring is not None:
+            ring.close()
 
     def poll(self) -> None:
         """Non-blocking: move the results the workers have finished out of their pipes (a worker whose pipe is full waits with its
@@ -408,6 +431,28 @@ class Dataset:
             from .prep import DevicePrep
             self._dp = DevicePrep(self.device_prep, self.config.IMG_SIZE)
             self._dp.warm(max(8 << 20, self.device_batch * (2 * 3 * self.config.IMG_SIZE ** 2 + (64 << 10)) * 5 // 4))
+        self._ensure_ring()
+
+    def _ensure_ring(self) -> None:
+        """Device preparation with worker processes: the workers write their results into a page-locked shared-memory ring
+        (prep.SlotRing / host_part_ring) instead of pickling ~0.5 MB per item through their pipes.  BSR_LOADER_RING=0 keeps the pipes."""
+        if (self.device_prep is None or self.workers <= 0 or getattr(self, "_ring", None) is not None or getattr(self, "_started", False)
+                or os.environ.get("BSR_LOADER_RING", "1") == "0"):
+            return
+        from .prep import SlotRing
+        if self._pool is None:
+            self._pool = _SelectPool(self.workers)
+        b = max(1, self.device_batch)
+        ring = SlotRing(((self.prefetch + 3 * b + b - 1) // b) * b)
+        if not ring.pinned:                       # registration refused: the pipes it is
+            ring.close()
+            return
+        ring.path_for_workers = ring.path
+        self._pool.warm("rows", ring.path)        # every worker maps the file now ...
+        ring.unlink()                             # ... so its name can go: nothing is left behind whatever happens to this process
+        self._ring, self._ring_seq, self._ring_copies = ring, 0, []
+        if getattr(self, "_dp", None) is not None:
+            self._dp.ring = ring
 
     def __del__(self):
         try:
@@ -421,22 +466,34 @@ class Dataset:
             return
         from .prep import DevicePrep
         dp = self._dp if getattr(self, "_dp", None) is not None else DevicePrep(self.device_prep, self.config.IMG_SIZE)
+        self._ensure_ring()
+        dp.ring = getattr(self, "_ring", None)
         group = []
+        self._emitted = 0
 
         def emit():
-            out, boxes = dp.rows(group)
-            for i, part in enumerate(group):
-                if len(part) > 5 and part[5] is not None:      # + the item's seven segmentation masks (host, bit-packed or grey levels: prep.pack_masks)
-                    yield out[i:i + 1][None], boxes[i][None], np.array([part[4]]), part[5]
+            out, boxes, masks, names = dp.rows_ex(group)
+            self._emitted += len(group)
+            if dp.ring is not None:
+                self._ring_copies.append([self._emitted, dp.last_copy, False])       # jobs < _emitted have left their slots once this event is done
+            for i in range(len(group)):
+                if masks[i] is not None:      # + the item's seven segmentation masks (bit-packed or grey levels, host or device: prep.pack_masks / rows_ex)
+                    yield out[i:i + 1][None], boxes[i][None], np.array([names[i]]), masks[i]
                 else:
-                    yield out[i:i + 1][None], boxes[i][None], np.array([part[4]])
-        for part in self._iterate_host():
-            group.append(part)
-            if len(group) >= self.device_batch:
+                    yield out[i:i + 1][None], boxes[i][None], np.array([names[i]])
+        try:
+            for part in self._iterate_host():
+                group.append(part)
+                if len(group) >= self.device_batch:
+                    yield from emit()
+                    group = []
+            if group:
                 yield from emit()
-                group = []
-        if group:
-            yield from emit()
+        finally:
+            if dp.ring is not None and getattr(dp, "last_copy", None) is not None:
+                dp.last_copy.synchronize()          # the copy engine may still be reading the last slots
+            dp.ring = None
+            self.close()
 
     def _iterate_host(self):
         jobs = self._jobs()
@@ -449,7 +506,7 @@ class Dataset:
         try:
             yield from self._pool.imap(jobs, self.prefetch)
         finally:
-            self.close()
+            self._close_pool()              # the ring outlives the workers: the last group's slots are still to be copied (_iterate closes it)
 
 
 class _JobFailed(Exception):
@@ -598,9 +655,9 @@ class _SelectPool:
                 return
             self._pump(block=True)
 
-    def warm(self, kind: str) -> None:
+    def warm(self, kind: str, ring_path: Optional[str] = None) -> None:
         for w in range(len(self.procs)):
-            self._send(w, ("warm", kind))
+            self._send(w, ("warm", kind) + ((ring_path,) if ring_path else ()))
         while any(self._load):
             self._pump(block=True)
         self._done.clear()

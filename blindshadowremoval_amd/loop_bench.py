@@ -52,11 +52,13 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
             # round 5: test_step's post-processing + the PNG encoding run on the device (ucb_post_gpu / gpu_png); the loader's workers also
             # decode the seven masks of every item
             modes[-1][2]["post_device"] = False
-            modes.append(("device_post", dict(workers=max(2, ncpu), device_prep=fsr.gen._device, device_batch=batch),
+            # worker counts (both device modes): 3/4 of the usable CPUs — with the C scanline reconstruction and the shared-memory ring the
+            # loop's own thread and its four file-writer threads need the rest (16 workers on 16 CPUs: -25 %; scratch/loop_workers_sweep.py)
+            modes.append(("device_post", dict(workers=max(2, ncpu * 3 // 4), device_prep=fsr.gen._device, device_batch=batch),
                           dict(post_workers=0, png_workers=0, post_inflight=3, gpu_png=True, post_device=True)))
         if not ucb:
             # round 5: the PNG files themselves are built on the device (gpu_png.py): no encoder pool, every usable CPU decodes / triangulates
-            modes.append(("device_png", dict(workers=max(2, ncpu), device_prep=fsr.gen._device, device_batch=batch),
+            modes.append(("device_png", dict(workers=max(2, ncpu * 3 // 4), device_prep=fsr.gen._device, device_batch=batch),
                           dict(post_workers=0, png_workers=0, post_inflight=3, gpu_png=True)))
         for label, ds_kw, fsr_kw in modes:
             ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)

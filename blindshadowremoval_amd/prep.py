@@ -117,6 +117,15 @@ def unpack_masks(packed: Sequence[tuple], device):
     """[pack_masks(...)] of a batch -> uint8 [B,7,S,S] grey levels on `device` (bit-packed items are expanded there)."""
     import torch
     S = packed[0][2]
+    if any(p[0].startswith("dev_") for p in packed):           # ring items: the bytes are already in HBM (views of the batch's blob)
+        shifts = torch.arange(7, -1, -1, device=device, dtype=torch.uint8)
+
+        def full(p):
+            t = p[1] if p[0].startswith("dev_") else torch.from_numpy(p[1]).to(device, non_blocking=True)
+            return (((t[..., None] >> shifts) & 1) * 255).to(torch.uint8).reshape(7, S, S) if p[0].endswith("bits") else t.reshape(7, S, S)
+        if all(p[0] == "dev_bits" for p in packed):
+            return (((torch.stack([p[1] for p in packed], dim=0)[..., None] >> shifts) & 1) * 255).to(torch.uint8).reshape(len(packed), 7, S, S)
+        return torch.stack([full(p) for p in packed], dim=0)
     if all(p[0] == "bits" for p in packed):
         bits = torch.from_numpy(np.stack([p[1] for p in packed], axis=0)).to(device, non_blocking=True)          # [B,7,S*S/8]
         shifts = torch.arange(7, -1, -1, device=bits.device, dtype=torch.uint8)
@@ -142,8 +151,99 @@ def host_part(job):
     return out + (masks,) if masks is not None else out
 
 
+RING_CAP = 1 << 20        # bytes of one slot of the loaders' shared-memory ring (a 256x256 UCB item with ground truth, tables and masks: ~0.55 MB)
+_RING_VIEWS: dict = {}
+
+
+def _is_ring(part) -> bool:
+    return isinstance(part[0], str)
+
+
+def host_part_ring(job, ring):
+    """`host_part(job)` written INTO slot `slot` of the shared-memory ring the parent page-locked (SlotRing) instead of pickled through
+    the worker's pipe: -> ("ring", slot, (h, w), has_gt, image offsets, table offsets, table lengths, box, name, mask record | None,
+    bytes used) — a few hundred bytes.  The loop's own thread then neither reads, unpickles nor repacks the ~0.5 MB of an item (0.1 ms
+    per item of the one thread every batch goes through): the slot goes to the device as it lies, by one copy per batch.  An item that
+    does not fit a slot comes back the old way."""
+    path, slot, cap = ring
+    part = host_part(job)
+    img, gt, box, tabs, name = part[:5]
+    masks = part[5] if len(part) > 5 else None
+    arrays = [img] + ([gt] if gt is not None else []) + list(tabs) + ([masks[1]] if masks is not None else [])
+    offs, off = [], 0
+    for a in arrays:
+        offs.append(off)
+        off = (off + a.nbytes + 7) & ~7
+    if off > cap:
+        return part
+    view = _RING_VIEWS.get(path)
+    if view is None:
+        view = _RING_VIEWS[path] = np.memmap(path, np.uint8, "r+")
+    base = int(slot) * int(cap)
+    for o, a in zip(offs, arrays):
+        raw = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        view[base + o:base + o + raw.size] = raw
+    k = 2 if gt is not None else 1
+    mrec = None if masks is None else (masks[0], int(masks[2]), offs[k + 4], int(masks[1].nbytes))
+    return ("ring", int(slot), (int(img.shape[0]), int(img.shape[1])), gt is not None, tuple(offs[:k]), tuple(offs[k:k + 4]),
+            tuple(int(t.shape[0]) for t in tabs), np.asarray(box, np.int32), name, mrec, off)
+
+
+class SlotRing:
+    """Parent side of the ring: `nslots` x `cap` bytes of shared memory (a file under /dev/shm, unlinked as soon as every worker has
+    mapped it), page-locked with hipHostRegister so that the copy engine reads the workers' bytes where they wrote them."""
+
+    def __init__(self, nslots: int, cap: int = RING_CAP):
+        import mmap
+        import tempfile
+        import torch
+        self.nslots, self.cap = int(nslots), int(cap)
+        d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        fd, self.path = tempfile.mkstemp(prefix="bsr_ring_%d_" % os.getpid(), dir=d)
+        try:
+            os.ftruncate(fd, self.nslots * self.cap)
+            self._mm = mmap.mmap(fd, self.nslots * self.cap)
+        finally:
+            os.close(fd)
+        self.tensor = torch.frombuffer(self._mm, dtype=torch.uint8)
+        self._torch = torch
+        self.pinned = False
+        if torch.cuda.is_available():
+            rc = torch.cuda.cudart().cudaHostRegister(self.tensor.data_ptr(), self.nslots * self.cap, 0)
+            self.pinned = int(rc) == 0 and bool(self.tensor.is_pinned())
+
+    def unlink(self) -> None:
+        path, self.path = self.path, None
+        if path:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+
+    def close(self) -> None:
+        self.unlink()
+        t, self.tensor = self.tensor, None
+        if t is not None and self.pinned:
+            try:
+                self._torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+            except Exception:
+                pass
+        self.pinned = False
+
+
 def _layout(parts, size: int):
-    """Offsets of every section of the blob (all 8-byte aligned): -> (total bytes, rows_off, grid_off, rows table, [(offset, array)])."""
+    """The blob of a batch of `host_part` results that all came through the pipe: see _layout_ex."""
+    total, rows_off, grid_off, pieces, _, cells = _layout_ex(parts, size, RING_CAP)
+    if cells:
+        raise ValueError("_layout: ring items need DevicePrep.rows_ex")
+    return total, rows_off, grid_off, pieces
+
+
+def _layout_ex(parts, size: int, cap: int):
+    """Offsets of every section of the blob (all 8-byte aligned): -> (total bytes, rows_off, grid_off, [(offset, array)], head bytes,
+    ring cells).  Items that came through the pipe are packed behind the records (the `head`, staged by the caller); every ring item
+    gets one `cap`-byte cell behind the head, in batch order — cells = [(part index, slot, cell offset)] — which the caller fills
+    with the slot's bytes."""
     B = len(parts)
     rows = np.zeros(B, ROW_DTYPE)
     pieces = []
@@ -158,6 +258,8 @@ def _layout(parts, size: int):
     grid_off = take(size * 8)
     pieces.append((grid_off, np.linspace(0, 1, size).astype("<f8")))
     for i, part in enumerate(parts):
+        if _is_ring(part):
+            continue
         img, gt, box, tabs = part[:4]
         r = rows[i]
         r["h"], r["w"] = img.shape[0], img.shape[1]
@@ -174,13 +276,34 @@ def _layout(parts, size: int):
             r["ntri"][m] = t.shape[0]
             pieces.append((int(r["tri_off"][m]), t))
     pieces.append((rows_off, rows))
+    head, cells = off, []
+    for i, part in enumerate(parts):
+        if not _is_ring(part):
+            continue
+        _, slot, (h, w), has_gt, ioff, toff, ntri, box, _, _, used = part
+        base = off
+        off += cap
+        if used > cap or min(ioff + toff) < 0:
+            raise ValueError("prep blob: ring item %d claims %d bytes of a %d-byte slot" % (i, used, cap))
+        cells.append((i, int(slot), base))
+        r = rows[i]
+        r["h"], r["w"] = h, w
+        r["img_off"] = base + ioff[0]
+        r["gt_off"] = base + (ioff[1] if has_gt else ioff[0])
+        r["box"] = box
+        for m in range(4):
+            r["tri_off"][m] = base + toff[m]
+            r["ntri"][m] = ntri[m]
+        ends = [ioff[0] + h * w * 3, (ioff[1] if has_gt else ioff[0]) + h * w * 3] + [toff[m] + ntri[m] * TRI_DOUBLES * 8 for m in range(4)]
+        if max(ends) > cap:
+            raise ValueError("prep blob: ring item %d points outside its slot" % i)
     # the kernel dereferences these offsets on the device without bounds information: every record is checked against the blob here
     for i, r in enumerate(rows):
         ends = [int(r["img_off"]) + int(r["h"]) * int(r["w"]) * 3, int(r["gt_off"]) + int(r["h"]) * int(r["w"]) * 3]
         ends += [int(r["tri_off"][m]) + int(r["ntri"][m]) * TRI_DOUBLES * 8 for m in range(4)]
         if min(int(r["img_off"]), int(r["gt_off"]), *(int(x) for x in r["tri_off"])) < 0 or max(ends) > off or any(int(n) > MAX_TRI or int(n) < 0 for n in r["ntri"]):
             raise ValueError("prep blob: row %d points outside the %d-byte blob" % (i, off))
-    return off, rows_off, grid_off, pieces
+    return off, rows_off, grid_off, pieces, head, cells
 
 
 def pack_into(buf: np.ndarray, pieces) -> None:
@@ -217,28 +340,55 @@ class DevicePrep:
                 self._stage[k] = self._torch.empty(nbytes, dtype=self._torch.uint8).pin_memory()
 
     def rows(self, parts):
+        out, boxes, _, _ = self.rows_ex(parts)
+        return out, boxes
+
+    def rows_ex(self, parts):
+        """-> (rows [B,S,S,16] float32 on the device, boxes [B,4], per item its masks as device views | None, per item its name).
+        `parts`: `host_part` results (pickled through a worker's pipe) and / or `host_part_ring` records (the bytes lie in self.ring)."""
         torch = self._torch
         B, S = len(parts), self.size
-        total, rows_off, grid_off, pieces = _layout(parts, S)
+        ring = getattr(self, "ring", None)
+        cap = ring.cap if ring is not None else RING_CAP
+        total, rows_off, grid_off, pieces, head, cells = _layout_ex(parts, S, cap)
+        if cells and ring is None:
+            raise RuntimeError("DevicePrep.rows_ex: ring records without a ring")
         dev = "cuda:%d" % self.device
         with torch.cuda.device(self.device):
             # two pinned staging buffers used alternately: the sections are copied straight into page-locked memory and go to the
             # device in one asynchronous copy; a buffer is reused only after the copy that read it has finished
             k = self._turn = (getattr(self, "_turn", 0) + 1) & 1
             stage = self._stage[k]
-            if stage is None or stage.numel() < total:
-                stage = self._stage[k] = torch.empty(max(total, 1 << 22) * 5 // 4, dtype=torch.uint8).pin_memory()
+            if stage is None or stage.numel() < head:
+                stage = self._stage[k] = torch.empty(max(head, 1 << 22) * 5 // 4, dtype=torch.uint8).pin_memory()
             if self._copied[k] is not None:
                 self._copied[k].synchronize()
             pack_into(stage.numpy(), pieces)
             d_blob = torch.empty(total, dtype=torch.uint8, device=dev)
-            d_blob.copy_(stage[:total], non_blocking=True)
-            ev = self._copied[k] = torch.cuda.Event()
+            d_blob[:head].copy_(stage[:head], non_blocking=True)
+            # ring items: consecutive slots of consecutive cells go in ONE copy (the usual case: the whole batch), whole slots as they lie
+            c = 0
+            while c < len(cells):
+                e = c + 1
+                while e < len(cells) and cells[e][1] == cells[e - 1][1] + 1:
+                    e += 1
+                src = ring.tensor[cells[c][1] * cap:(cells[e - 1][1] + 1) * cap]
+                d_blob[cells[c][2]:cells[c][2] + (e - c) * cap].copy_(src, non_blocking=True)
+                c = e
+            ev = self._copied[k] = self.last_copy = torch.cuda.Event()
             ev.record()
             out = torch.empty((B, S, S, 16), dtype=torch.float32, device=dev)
             tmp = torch.empty((B, S, S), dtype=torch.float32, device=dev)
             rc = self._lib.bsr_prep_rows(self.device, d_blob.data_ptr(), total, rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
                                          torch.cuda.current_stream().cuda_stream)
         self._check(rc, "bsr_prep_rows")
-        boxes = np.stack([np.asarray(p[2], np.float32) for p in parts], axis=0)
-        return out, boxes
+        boxes = np.stack([np.asarray(p[7] if _is_ring(p) else p[2], np.float32) for p in parts], axis=0)
+        names = [p[8] if _is_ring(p) else p[4] for p in parts]
+        masks = [(p[5] if len(p) > 5 else None) if not _is_ring(p) else None for p in parts]
+        for i, _, base in cells:
+            m = parts[i][9]
+            if m is not None:
+                kind, ms, moff, nbytes = m
+                v = d_blob[base + moff:base + moff + nbytes]
+                masks[i] = ("dev_" + kind, v.view(7, -1) if kind == "bits" else v.view(7, ms, ms), ms)
+        return out, boxes, masks, names

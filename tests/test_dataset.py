@@ -330,3 +330,112 @@ def test_ucb_masks_travel_bit_packed_with_the_loader_job(golden_dir):
     ds2 = D.Dataset(cfg, "test", ucb=True)
     ds2.device_prep = 0
     assert len(next(iter(ds2._jobs()))[1]) == 2
+
+
+def test_loader_ring_slot_holds_what_the_pipe_would_carry(tmp_path, golden_dir):
+    """Round 5 (shared-memory transport of the device-prepared loops): prep.host_part_ring writes an item's image, ground truth, four
+    triangle tables and bit-packed masks into its slot of the ring and answers with a small record; the blob layout built from such
+    records (prep._layout_ex) points at exactly the bytes the pipe form (prep.host_part -> _layout) packs.  CPU only: the ring is a
+    plain file here, no page-locking, no device."""
+    import torch
+    from blindshadowremoval_amd import prep
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    ds = D.Dataset(cfg, "test", ucb=True)
+    fsr = FSRNet.__new__(FSRNet)
+    fsr.config = cfg
+    ds.device_prep = 0
+    ds.ucb_mask_files = fsr._ucb_masks()
+    jobs = list(ds._jobs())[:3]
+    cap, nslots = prep.RING_CAP, 4
+    path = str(tmp_path / "ring")
+    with open(path, "wb") as f:
+        f.truncate(nslots * cap)
+    slots = [2, 3, 0]                                                      # a batch that wraps around the end of the ring
+    recs = [D.build_element(j + ((path, s, cap),)) for j, s in zip(jobs, slots)]
+    pipe = [D.build_element(j) for j in jobs]
+    assert all(r[0] == "ring" and r[1] == s and r[10] <= cap for r, s in zip(recs, slots))
+    assert all(len(pickle_bytes(r)) < 1000 for r in recs) and all(len(pickle_bytes(p)) > 400000 for p in pipe)
+    ring = np.fromfile(path, np.uint8)
+    total, rows_off, grid_off, pieces, head, cells = prep._layout_ex(recs, 256, cap)
+    assert [c[:2] for c in cells] == [(0, 2), (1, 3), (2, 0)] and total == head + 3 * cap
+    blob = np.zeros(total, np.uint8)
+    prep.pack_into(blob, pieces)
+    for i, slot, base in cells:                                            # what DevicePrep.rows_ex's copies do
+        blob[base:base + cap] = ring[slot * cap:(slot + 1) * cap]
+    t2, r2, g2, p2 = prep._layout(pipe, 256)
+    blob2 = np.zeros(t2, np.uint8)
+    prep.pack_into(blob2, p2)
+    rows = blob[rows_off:rows_off + 3 * prep.ROW_DTYPE.itemsize].view(prep.ROW_DTYPE)
+    rows2 = blob2[r2:r2 + 3 * prep.ROW_DTYPE.itemsize].view(prep.ROW_DTYPE)
+    assert np.array_equal(blob[grid_off:grid_off + 2048], blob2[g2:g2 + 2048])
+    for a, b, rec, part in zip(rows, rows2, recs, pipe):
+        assert (a["h"], a["w"], list(a["box"]), list(a["ntri"])) == (b["h"], b["w"], list(b["box"]), list(b["ntri"]))
+        n = int(a["h"]) * int(a["w"]) * 3
+        assert np.array_equal(blob[a["img_off"]:a["img_off"] + n], blob2[b["img_off"]:b["img_off"] + n])
+        assert np.array_equal(blob[a["gt_off"]:a["gt_off"] + n], blob2[b["gt_off"]:b["gt_off"] + n]) and a["gt_off"] != a["img_off"]
+        for m in range(4):
+            k = int(a["ntri"][m]) * prep.TRI_DOUBLES * 8
+            assert np.array_equal(blob[a["tri_off"][m]:a["tri_off"][m] + k], blob2[b["tri_off"][m]:b["tri_off"][m] + k])
+        kind, S, moff, nbytes = rec[9]
+        assert (kind, S, nbytes) == ("bits", 256, 7 * 256 * 256 // 8)
+        base = [c[2] for c in cells if recs[c[0]] is rec][0]
+        assert np.array_equal(blob[base + moff:base + moff + nbytes].reshape(7, -1), part[5][1])
+        assert rec[8] == part[4] and np.array_equal(rec[7], part[2])
+    # masks that already lie on a "device": the same grey levels as the host form
+    dev = [("dev_bits", torch.from_numpy(p[5][1].copy()), 256) for p in pipe]
+    assert torch.equal(prep.unpack_masks(dev, torch.device("cpu")), prep.unpack_masks([p[5] for p in pipe], torch.device("cpu")))
+    assert torch.equal(prep.unpack_masks([dev[0], pipe[1][5]], torch.device("cpu")), prep.unpack_masks([p[5] for p in pipe[:2]], torch.device("cpu")))
+    # an item that does not fit a slot comes back through the pipe; a record that lies about its slot is refused before any kernel sees it
+    small = D.build_element(jobs[0] + ((path, 0, 1 << 16),))
+    assert not prep._is_ring(small) and np.array_equal(small[0], pipe[0][0])
+    bad = list(recs[0]); bad[5] = (cap - 8,) + tuple(bad[5][1:])
+    with pytest.raises(ValueError, match="outside its slot"):
+        prep._layout_ex([tuple(bad)], 256, cap)
+    with pytest.raises(ValueError, match="ring items"):
+        prep._layout(recs, 256)
+
+
+def pickle_bytes(x) -> bytes:
+    import pickle
+    return pickle.dumps(x, protocol=pickle.HIGHEST_PROTOCOL)
+
+
+@pytest.mark.gpu
+def test_loader_ring_and_pipe_give_identical_rows(golden_dir, monkeypatch):
+    """The device-prepared loader through the page-locked shared-memory ring against the same loader through the workers' pipes
+    (BSR_LOADER_RING=0): identical rows, boxes, names and masks, over a list long enough for every slot to be reused several times."""
+    import torch
+    from blindshadowremoval_amd import prep
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    fsr = FSRNet.__new__(FSRNet)
+    fsr.config = cfg
+    mf = fsr._ucb_masks()
+    n = 150
+
+    def run(ring: bool):
+        monkeypatch.setenv("BSR_LOADER_RING", "1" if ring else "0")
+        ds = D.Dataset(cfg, "test", ucb=True, workers=3, prefetch=6, device_prep=0, device_batch=8)
+        base = list(ds.name_list)
+        ds.name_list = (base * 2)[:n]
+        ds.ucb_mask_files = (mf * 2)[:n]
+        ds.warm()
+        assert (getattr(ds, "_ring", None) is not None) == ring
+        if ring:
+            assert ds._ring.pinned and ds._ring.nslots == 32 and ds._ring.path is None          # 6 + 3 x 8 rounded up to batches; the file's name is gone
+        sums, boxes, names, msum = [], [], [], []
+        for el in ds.feed:
+            sums.append(el[0].double().sum(dim=(0, 1, 2, 3)).cpu())
+            boxes.append(el[1]); names.append(el[2][0])
+            assert el[3][0] == ("dev_bits" if ring else "bits")
+            msum.append(prep.unpack_masks([el[3]], torch.device("cuda", 0)).double().sum(dim=(2, 3)).cpu())
+        ds.close()
+        return torch.stack(sums), np.concatenate(boxes), names, torch.cat(msum)
+    a, b = run(True), run(False)
+    assert len(a[2]) == n and a[2] == b[2] and np.array_equal(a[1], b[1])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
