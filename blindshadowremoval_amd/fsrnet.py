@@ -592,6 +592,7 @@ class FSRNet(object):
         pin_busy: List[List] = [[] for _ in range(max(depth + 1, len(self._pin_pool)))]          # file writes still reading a pinned buffer (gpu_png): waited for before its turn comes again
         gpu_png = on_gpu and self.log.gpu_png
         gpu_q: List[Tuple] = []             # submitted batches whose device-to-host copy may still be running, oldest first
+        d2h = torch.cuda.Stream(device=self.gen._device) if on_gpu else None
         turn = [0]
         # batches bound for a worker pool (PNG strips, UCB post-processing) are copied device -> a pinned SHARED-MEMORY slot the workers
         # read in place (_ShmPinnedRing); [ring | None, already tried]
@@ -675,12 +676,22 @@ class FSRNet(object):
                 return payload.numpy(), None, None
             nbytes = payload.numel() * payload.element_size()
             slot = ring_slot(nbytes, to_pool, int(payload.shape[0]))
+
+            def copy_out(view):
+                """the device-to-host copy on its own stream, behind the kernels that wrote `payload`: the compute stream goes straight on
+                with the next batch instead of idling for the ~10 MB of files / strips of this one"""
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(d2h):
+                    d2h.wait_event(ready)
+                    view.copy_(payload, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                payload.record_stream(d2h)
+                return ev
             if slot is not None:
                 view = ring_state[0].view(slot, payload.dtype, tuple(payload.shape))
-                view.copy_(payload, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                return view.numpy(), ev, slot
+                return view.numpy(), copy_out(view), slot
             k = turn[0]
             turn[0] = (k + 1) % (depth + 1)
             for fu in pin_busy[k]:                # the file writes of the batch that used this buffer depth + 1 submissions ago
@@ -689,18 +700,17 @@ class FSRNet(object):
             if pins[k] is None or pins[k].numel() < nbytes:
                 pins[k] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
             view = pins[k][:nbytes].view(payload.dtype).reshape(payload.shape)
-            view.copy_(payload, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            return view.numpy(), ev, (-1 - k if pin_id else None)       # pin_id: the "slot" names the private pinned buffer (negative), for pin_busy
+            return view.numpy(), copy_out(view), (-1 - k if pin_id else None)       # pin_id: the "slot" names the private pinned buffer (negative), for pin_busy
 
         def submit():
             """one batch: rows -> device -> generator -> what the host needs, on its way to pinned memory; nothing here waits for the GPU"""
             if not pending:
                 return
             t0 = time.perf_counter()
-            rows = torch.cat([self._split_row0(p[2]) for p in pending], dim=0)
-            rows_d = rows.to(dev, non_blocking=True)                # ONE host-to-device copy of the packed rows (none when the loader prepared them on the device)
+            rows_d = self._whole_batch(pending)                     # the loader's device tensor itself when the batch is exactly its group (no 64 MB concatenation)
+            if rows_d is None:
+                rows = torch.cat([self._split_row0(p[2]) for p in pending], dim=0)
+                rows_d = rows.to(dev, non_blocking=True)            # ONE host-to-device copy of the packed rows (none when the loader prepared them on the device)
             im_d, gt_d, uv_d, _, face_d = torch.split(rows_d, list(SPLIT_FFHQ), dim=3)
             gs, con_rgb, _, mask_pred = self.gen(im_d, uv_d, None, chuck=4 if ucb else 1, training=False)
             items = list(pending)
@@ -907,6 +917,22 @@ class FSRNet(object):
         self.log.losses = acc
         if rank == 0:
             print(Logging.format_line(acc, num_list - 1, num_list), end='', flush=True)
+
+    @staticmethod
+    def _whole_batch(pending):
+        """The elements of a device-prepared loader are views `out[i:i+1][None]` of one [B,S,S,16] tensor per group: when a batch is
+        exactly such a group, in order, that tensor is the batch."""
+        first = pending[0][2]
+        base = getattr(first, "_base", None) if isinstance(first, torch.Tensor) else None
+        if base is None or base.dim() != 4 or base.shape[0] != len(pending) or base.dtype != torch.float32 or not base.is_contiguous():
+            return None
+        step = base.stride(0) * base.element_size()
+        for i, p in enumerate(pending):
+            t = p[2]
+            tb = t._base if isinstance(t, torch.Tensor) else None
+            if tb is None or tb.data_ptr() != base.data_ptr() or tb.shape != base.shape or t.data_ptr() != base.data_ptr() + i * step or t.numel() != base.stride(0):
+                return None
+        return base
 
     def _split_row0(self, img) -> torch.Tensor:
         s = self.config.IMG_SIZE

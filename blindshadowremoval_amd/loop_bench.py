@@ -52,13 +52,13 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
             # round 5: test_step's post-processing + the PNG encoding run on the device (ucb_post_gpu / gpu_png); the loader's workers also
             # decode the seven masks of every item
             modes[-1][2]["post_device"] = False
-            # worker counts (both device modes): 3/4 of the usable CPUs — with the C scanline reconstruction and the shared-memory ring the
+            # worker counts of the device modes: 3/4 (UCB: two images + seven masks per item) and 5/8 (FFHQ) of the usable CPUs — with the C scanline reconstruction and the shared-memory ring the
             # loop's own thread and its four file-writer threads need the rest (16 workers on 16 CPUs: -25 %; scratch/loop_workers_sweep.py)
             modes.append(("device_post", dict(workers=max(2, ncpu * 3 // 4), device_prep=fsr.gen._device, device_batch=batch),
                           dict(post_workers=0, png_workers=0, post_inflight=3, gpu_png=True, post_device=True)))
         if not ucb:
             # round 5: the PNG files themselves are built on the device (gpu_png.py): no encoder pool, every usable CPU decodes / triangulates
-            modes.append(("device_png", dict(workers=max(2, ncpu * 3 // 4), device_prep=fsr.gen._device, device_batch=batch),
+            modes.append(("device_png", dict(workers=max(2, ncpu * 5 // 8), device_prep=fsr.gen._device, device_batch=batch),
                           dict(post_workers=0, png_workers=0, post_inflight=3, gpu_png=True)))
         for label, ds_kw, fsr_kw in modes:
             ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
@@ -69,7 +69,8 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
             fsr.log.gpu_png = bool(fsr_kw.get("gpu_png", False))        # the earlier modes keep the host encoders they were measured with
             fsr.post_device = bool(fsr_kw.get("post_device", False))
             base = list(ds.name_list)
-            n_items = items * ((10 if ucb else 20) if fsr_kw else 1)     # the fast mode needs a longer list for a steady-state rate (~2-4 s of loop)
+            fast = bool(fsr_kw.get("gpu_png"))                          # the round-5 device modes: ~1 s of loop needs 2 000 / 4 000 items
+            n_items = items * (((20 if fast else 10) if ucb else (40 if fast else 20)) if fsr_kw else 1)     # the fast modes need a longer list for a steady-state rate
             reps = (n_items + len(base) - 1) // len(base)
             ds.name_list = (base * reps)[:n_items]
             # item i of the repeated list is evaluated against mask i of the equally repeated mask list (FSRNet.test indexes strictly)

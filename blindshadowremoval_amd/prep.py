@@ -277,32 +277,41 @@ def _layout_ex(parts, size: int, cap: int):
             pieces.append((int(r["tri_off"][m]), t))
     pieces.append((rows_off, rows))
     head, cells = off, []
-    for i, part in enumerate(parts):
-        if not _is_ring(part):
-            continue
-        _, slot, (h, w), has_gt, ioff, toff, ntri, box, _, _, used = part
-        base = off
-        off += cap
-        if used > cap or min(ioff + toff) < 0:
-            raise ValueError("prep blob: ring item %d claims %d bytes of a %d-byte slot" % (i, used, cap))
-        cells.append((i, int(slot), base))
-        r = rows[i]
-        r["h"], r["w"] = h, w
-        r["img_off"] = base + ioff[0]
-        r["gt_off"] = base + (ioff[1] if has_gt else ioff[0])
-        r["box"] = box
-        for m in range(4):
-            r["tri_off"][m] = base + toff[m]
-            r["ntri"][m] = ntri[m]
-        ends = [ioff[0] + h * w * 3, (ioff[1] if has_gt else ioff[0]) + h * w * 3] + [toff[m] + ntri[m] * TRI_DOUBLES * 8 for m in range(4)]
-        if max(ends) > cap:
-            raise ValueError("prep blob: ring item %d points outside its slot" % i)
+    ring_idx = [i for i, part in enumerate(parts) if _is_ring(part)]
+    if ring_idx:
+        # the records of the ring items in whole columns (per-field assignments on a structured array cost ~15 us each: 0.3 ms per batch
+        # of the loop's own thread when done item by item)
+        rp = [parts[i] for i in ring_idx]
+        n = len(rp)
+        bases = off + cap * np.arange(n, dtype=np.int64)
+        off += cap * n
+        hw = np.array([p[2] for p in rp], np.int64).reshape(n, 2)
+        has_gt = np.array([p[3] for p in rp], bool)
+        io0 = np.array([p[4][0] for p in rp], np.int64)
+        io1 = np.where(has_gt, np.array([p[4][-1] for p in rp], np.int64), io0)
+        toff = np.array([p[5] for p in rp], np.int64).reshape(n, 4)
+        ntri = np.array([p[6] for p in rp], np.int64).reshape(n, 4)
+        used = np.array([p[10] for p in rp], np.int64)
+        npx = hw[:, 0] * hw[:, 1] * 3
+        ends = np.maximum(np.maximum(io0, io1) + npx, (toff + ntri * (TRI_DOUBLES * 8)).max(axis=1))
+        bad = (used > cap) | (np.minimum(np.minimum(io0, io1), toff.min(axis=1)) < 0) | (ends > cap) | (hw.min(axis=1) < 0) | (ntri.min(axis=1) < 0)
+        if bad.any():
+            raise ValueError("prep blob: ring item %d points outside its slot (%d-byte slots)" % (ring_idx[int(np.argmax(bad))], cap))
+        sel = np.array(ring_idx)
+        rows["h"][sel], rows["w"][sel] = hw[:, 0], hw[:, 1]
+        rows["img_off"][sel] = bases + io0
+        rows["gt_off"][sel] = bases + io1
+        rows["box"][sel] = np.stack([np.asarray(p[7], np.int32).reshape(4) for p in rp])
+        rows["tri_off"][sel] = bases[:, None] + toff
+        rows["ntri"][sel] = ntri
+        cells = [(i, int(p[1]), int(bs)) for i, p, bs in zip(ring_idx, rp, bases)]
     # the kernel dereferences these offsets on the device without bounds information: every record is checked against the blob here
-    for i, r in enumerate(rows):
-        ends = [int(r["img_off"]) + int(r["h"]) * int(r["w"]) * 3, int(r["gt_off"]) + int(r["h"]) * int(r["w"]) * 3]
-        ends += [int(r["tri_off"][m]) + int(r["ntri"][m]) * TRI_DOUBLES * 8 for m in range(4)]
-        if min(int(r["img_off"]), int(r["gt_off"]), *(int(x) for x in r["tri_off"])) < 0 or max(ends) > off or any(int(n) > MAX_TRI or int(n) < 0 for n in r["ntri"]):
-            raise ValueError("prep blob: row %d points outside the %d-byte blob" % (i, off))
+    h64, w64 = rows["h"].astype(np.int64), rows["w"].astype(np.int64)
+    ends = np.maximum(np.maximum(rows["img_off"], rows["gt_off"]) + h64 * w64 * 3, (rows["tri_off"] + rows["ntri"].astype(np.int64) * (TRI_DOUBLES * 8)).max(axis=1))
+    lows = np.minimum(np.minimum(rows["img_off"], rows["gt_off"]), rows["tri_off"].min(axis=1))
+    bad = (lows < 0) | (ends > off) | (rows["ntri"].max(axis=1) > MAX_TRI) | (rows["ntri"].min(axis=1) < 0) | (h64 < 0) | (w64 < 0)
+    if bad.any():
+        raise ValueError("prep blob: row %d points outside the %d-byte blob" % (int(np.argmax(bad)), off))
     return off, rows_off, grid_off, pieces, head, cells
 
 
@@ -364,23 +373,46 @@ class DevicePrep:
             if self._copied[k] is not None:
                 self._copied[k].synchronize()
             pack_into(stage.numpy(), pieces)
-            d_blob = torch.empty(total, dtype=torch.uint8, device=dev)
-            d_blob[:head].copy_(stage[:head], non_blocking=True)
-            # ring items: consecutive slots of consecutive cells go in ONE copy (the usual case: the whole batch), whole slots as they lie
-            c = 0
-            while c < len(cells):
-                e = c + 1
-                while e < len(cells) and cells[e][1] == cells[e - 1][1] + 1:
-                    e += 1
-                src = ring.tensor[cells[c][1] * cap:(cells[e - 1][1] + 1) * cap]
-                d_blob[cells[c][2]:cells[c][2] + (e - c) * cap].copy_(src, non_blocking=True)
-                c = e
-            ev = self._copied[k] = self.last_copy = torch.cuda.Event()
-            ev.record()
-            out = torch.empty((B, S, S, 16), dtype=torch.float32, device=dev)
-            tmp = torch.empty((B, S, S), dtype=torch.float32, device=dev)
-            rc = self._lib.bsr_prep_rows(self.device, d_blob.data_ptr(), total, rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
-                                         torch.cuda.current_stream().cuda_stream)
+            # the host-to-device copies run on their OWN stream: the copy engine moves batch k + 1 while the compute stream is still in
+            # batch k's forward (on one stream the ~16 MB of a batch sat between two forwards: ~0.4 ms of a 4 ms step)
+            main = torch.cuda.current_stream()
+            if getattr(self, "_h2d", None) is None:
+                self._h2d = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._h2d):
+                d_blob = torch.empty(total, dtype=torch.uint8, device=dev)
+                d_blob[:head].copy_(stage[:head], non_blocking=True)
+                # ring items: consecutive slots of consecutive cells go in ONE copy (the usual case: the whole batch), whole slots as they lie
+                c = 0
+                while c < len(cells):
+                    e = c + 1
+                    while e < len(cells) and cells[e][1] == cells[e - 1][1] + 1:
+                        e += 1
+                    src = ring.tensor[cells[c][1] * cap:(cells[e - 1][1] + 1) * cap]
+                    d_blob[cells[c][2]:cells[c][2] + (e - c) * cap].copy_(src, non_blocking=True)
+                    c = e
+                ev = self._copied[k] = self.last_copy = torch.cuda.Event()
+                ev.record()
+                # the preparation kernel follows its input on the same side stream (BSR_PREP_SIDE=0: on the compute stream): a short
+                # bandwidth-bound kernel that shares the chip with the previous batch's forward instead of standing in line behind it
+                side = os.environ.get("BSR_PREP_SIDE", "1") != "0"
+                if side:
+                    out = torch.empty((B, S, S, 16), dtype=torch.float32, device=dev)
+                    tmp = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+                    rc = self._lib.bsr_prep_rows(self.device, d_blob.data_ptr(), total, rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
+                                                 self._h2d.cuda_stream)
+                    done = torch.cuda.Event()
+                    done.record()
+            if side:
+                main.wait_event(done)
+                out.record_stream(main)
+            else:
+                main.wait_event(ev)
+            d_blob.record_stream(main)             # allocated on the side stream, read by the compute stream (the mask views; the kernel when it runs there)
+            if not side:
+                out = torch.empty((B, S, S, 16), dtype=torch.float32, device=dev)
+                tmp = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+                rc = self._lib.bsr_prep_rows(self.device, d_blob.data_ptr(), total, rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
+                                             main.cuda_stream)
         self._check(rc, "bsr_prep_rows")
         boxes = np.stack([np.asarray(p[7] if _is_ring(p) else p[2], np.float32) for p in parts], axis=0)
         names = [p[8] if _is_ring(p) else p[4] for p in parts]

@@ -78,8 +78,8 @@ def main(argv=None) -> int:
     ucb = args.loop == "ucb"
     ncpu = cpu_share()                      # this rank's share of the node's usable CPUs
     # worker counts: sweeps on the 16-CPU GPU box (loop_bench.py).  With post-processing and PNG encoding on the device (the default) the
-    # loader's workers — PNG decode, Delaunay meshes, the UCB masks — are the only host stage: 3/4 of this rank's share of the CPUs (the loop's own thread and its file writers need the rest)
-    ds_kw = dict(workers=max(1, (ncpu * 5 // 8 if ucb else ncpu * 7 // 8) if args.host_post else max(1, ncpu * 3 // 4)))
+    # loader's workers — PNG decode, Delaunay meshes, the UCB masks — are the only host stage: 3/4 (UCB) / 5/8 (FFHQ) of this rank's share of the CPUs (the loop's own thread and its file writers need the rest)
+    ds_kw = dict(workers=max(1, (ncpu * 5 // 8 if ucb else ncpu * 7 // 8) if args.host_post else max(1, ncpu * 3 // 4 if ucb else ncpu * 5 // 8)))
     if not args.host_prep:
         ds_kw.update(device_prep=local_rank, device_batch=args.batch)
     ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
