@@ -71,7 +71,7 @@ def main():
         run_stage(pool, jobs[:nw])
         dt, cpu = run_stage(pool, jobs)
         res["stages"]["loader_host_half"] = {"items_per_sec": round(n / dt, 1), "driver_cpu_ms_per_item": round(cpu / n * 1e3, 3), "job_cpu_ms_alone": alone_ms(build_element, jobs),
-                                             "what": "prep.host_part per item (device preparation: decode + triangulate)"}
+                                             "what": "prep.host_part per item (device preparation: inflate + C scanline reconstruction + triangulate)"}
         # ---- stage 1a (round 5): the same job + the item's seven segmentation masks (decoded, bit-packed): what FSRNet.test's loader does now that
         # the post-processing itself runs on the device
         ds_m = Dataset(cfg, "test", ucb=True, device_prep=0)
@@ -82,7 +82,7 @@ def main():
         dt, cpu = run_stage(pool, jobs_m)
         res["stages"]["loader_host_half_with_masks"] = {"items_per_sec": round(n / dt, 1), "driver_cpu_ms_per_item": round(cpu / n * 1e3, 3),
                                                         "job_cpu_ms_alone": alone_ms(build_element, jobs_m),
-                                                        "what": "prep.host_part per item incl. the seven UCB masks (fast grey PNG reader, bit-packed through the pipe)"}
+                                                        "what": "prep.host_part per item incl. the seven UCB masks (C scanline reconstruction, bit-packed)"}
         # ---- stage 1c (round 5): writing the PNG files the DEVICE built (gpu_png): four writer threads in the loop's process, 256x768 and 256x1792 strips
         from concurrent.futures import ThreadPoolExecutor
         from blindshadowremoval_amd.pngio import stored_layout

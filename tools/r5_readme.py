@@ -97,8 +97,11 @@ resident batch of 32); the two-lane throughput of rounds 3-4 is the side figure 
 * **`r5_loop_stage_table.json`** — the host stages that are LEFT, each alone through %d worker processes: loader host half %.0f items/s (%.2f ms of
   CPU per item), the same with the item's seven masks %.0f /s (%.2f ms), writing the device-built PNG files %.0f /s (FFHQ strips) and %.0f /s
   (UCB strips); for comparison the stages round 5 took off the host: PNG strip encoding %.0f /s (%.2f ms), UCB post-processing %.0f /s (%.1f ms).
-  Reading: both loops now run at 0.6-0.75 of their loader stage alone; the rest is the loop's own thread (pipe reads, staging copies, launches)
-  sharing the %d-CPU quota with %d loader workers.
+  The loader's half shrank twice late in the round: PNG scanline reconstruction in C (`libbsr_host.so`, SIMD Paeth — PIL spent 2.0 of its
+  2.2 ms per 256x256 photograph there) and a page-locked shared-memory slot ring between the workers and the device (no pickling, no
+  repacking of ~0.5 MB per item on the loop's own thread; `scratch/loop_ablate.py`: the loops WITHOUT a loader sustain ~4 850 (FFHQ) /
+  ~3 300 (UCB) items/s, the B = 16 forward alone 5 800).  Reading: the loops run at ~0.8 of what the GPU side sustains; the rest is the
+  loop's own thread sharing the %d-CPU quota with the loader's workers (table measured with %d; the loops use 5/8 and 3/4 of the CPUs).
 <!-- END r5 NOTES -->''' % (
     b["value"], b["two_in_flight_value"], r4["single_stream_value"], r4["value"], rf["frac"], 100 * (rf.get("mfma_busy") or 0), rf.get("clock_ghz") or 0,
     (rf.get("traffic") or 0) / 1e6, tr["dominant_kernel_algorithmic_bytes_per_launch"] / 1e6, rf["path_3x3"]["frac"], rf["all_kernels_tflops"],
@@ -169,8 +172,9 @@ What the round did (`profiles/README.md` has the tables, `profiles/HISTORY.md` w
   failed de-phasing experiments in HISTORY.md), and every other 16-bit launch is a 20-150 us one- or few-round grid at 0.2-0.4 of both roofs.
 * **The loops** (§6): `FSRNet.test` **%s images/s** end to end (round 4: 351) — post-processing of `test_step` and PNG encoding on the device,
   every figure bit-identical to the host statement, masks decoded by the loader's workers; `FSRNet.testFFHQ` **%s** (round 4: 1 794).  What is
-  left on the host is the loader's half (PNG decode + Delaunay meshes: %.2f / %.2f ms of CPU per item without / with the UCB masks) and one
-  `write()` per item.
+  left on the host is the loader's half (inflate + scanline reconstruction in C + Delaunay meshes: %.2f / %.2f ms of CPU per item without /
+  with the UCB masks; the bytes travel through a page-locked shared-memory ring, copies and the preparation kernel on side streams) and
+  one `write()` per item.
 * **Measurement contract**: `value` config-exact; `roofline` for `--workload tsm512`; kernel-trace summaries for tsm512 and B = 16; the
   library carries the hash of its sources and a stale one does not load.
 * **Multi-GPU readiness** (§5): peer-copy gather as an opt-in alternative to RCCL's kernels (mechanism tested with two ranks on one GPU);
@@ -182,7 +186,8 @@ What the round did (`profiles/README.md` has the tables, `profiles/HISTORY.md` w
 2. **16-bit modes**: a one-wave-per-SIMD attention kernel with the softmax interleaved into the matrix stream by hand (the counters say 34 %% busy);
    the conv2 -> conv3|qkv tail of the fp32 path carried over; the f16 transposed convs' 2-byte stores.
 3. **Parity** stays unpinned until someone runs `tools/make_model_fixture.py --backend tf` and `tools/make_ucb_post_fixture.py --backend tf`.
-4. **Loops**: bound by the loader's PNG decode (PIL, 1.1-1.7 ms per 256x256 image) and the loop's own thread; a device-side inflate would be next.
+4. **Loops**: at ~0.8 of what the GPU side sustains without a loader (B = 16 forward + strips + PNG + copies); next are the strip assembly as
+   one kernel in front of the PNG encoder (eleven elementwise launches per batch today) and qhull (1.1 of the loader's 1.5 ms per item).
 <!-- END r5 DESIGN -->''' % (
     b["value"], b["two_in_flight_value"], r4["single_stream_value"], r4["value"], b["ms_per_step"], rf["achieved"], 100 * rf["frac"],
     100 * (rf.get("mfma_busy") or 0), rf.get("clock_ghz") or 0, 100 * rf["path_3x3"]["frac"], (rf.get("traffic") or 0) / 1e6,
