@@ -443,8 +443,13 @@ class Dataset:
         if self._pool is None:
             self._pool = _SelectPool(self.workers)
         b = max(1, self.device_batch)
-        ring = SlotRing(((self.prefetch + 3 * b + b - 1) // b) * b)
+        try:
+            ring = SlotRing(((self.prefetch + 3 * b + b - 1) // b) * b)
+        except OSError as e:                      # no room in /dev/shm: the pipes it is
+            self.ring_error = str(e)
+            return
         if not ring.pinned:                       # registration refused: the pipes it is
+            self.ring_error = "hipHostRegister refused the shared mapping"
             ring.close()
             return
         ring.path_for_workers = ring.path

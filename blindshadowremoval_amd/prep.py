@@ -199,6 +199,12 @@ class SlotRing:
         import torch
         self.nslots, self.cap = int(nslots), int(cap)
         d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        if d is not None:
+            # a tmpfs smaller than the ring would let ftruncate succeed and kill a worker with SIGBUS at its first write beyond the limit
+            # (containers often mount 64 MB there): the ring is only built where twice its size is free
+            st = os.statvfs(d)
+            if st.f_bavail * st.f_frsize < 2 * self.nslots * self.cap:
+                raise OSError("/dev/shm has %d MB free, the loader ring needs %d MB" % (st.f_bavail * st.f_frsize >> 20, self.nslots * self.cap >> 20))
         fd, self.path = tempfile.mkstemp(prefix="bsr_ring_%d_" % os.getpid(), dir=d)
         try:
             os.ftruncate(fd, self.nslots * self.cap)

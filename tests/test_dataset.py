@@ -439,3 +439,25 @@ def test_loader_ring_and_pipe_give_identical_rows(golden_dir, monkeypatch):
     a, b = run(True), run(False)
     assert len(a[2]) == n and a[2] == b[2] and np.array_equal(a[1], b[1])
     assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+
+
+def test_slot_ring_file_lifecycle_and_small_tmpfs(monkeypatch):
+    """prep.SlotRing on a box without a GPU: the file exists until unlink(), the mapping stays usable after it, nothing is page-locked;
+    a /dev/shm with less than twice the ring's size free refuses the ring (a worker's write beyond a tmpfs limit would be a SIGBUS)."""
+    import types
+    from blindshadowremoval_amd import prep
+    ring = prep.SlotRing(4, 4096)
+    path = ring.path
+    assert os.path.getsize(path) == 4 * 4096 and ring.tensor.numel() == 4 * 4096 and not ring.pinned
+    view = np.memmap(path, np.uint8, "r+")
+    ring.unlink()
+    assert not os.path.exists(path) and ring.path is None
+    view[4096:4100] = [1, 2, 3, 4]                                       # a worker's write after the name is gone
+    assert ring.tensor[4096:4100].tolist() == [1, 2, 3, 4]
+    del view
+    ring.close()
+    if os.path.isdir("/dev/shm"):
+        real = os.statvfs
+        monkeypatch.setattr(os, "statvfs", lambda p: types.SimpleNamespace(f_bavail=16, f_frsize=4096) if p == "/dev/shm" else real(p))
+        with pytest.raises(OSError, match="loader ring needs"):
+            prep.SlotRing(112)
