@@ -655,7 +655,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     const bool x3 = h->dtype != BSR_DTYPE_F32;                     // split precision in both 16-bit modes
     L.rc = find_layer(h, "conv1", 1, 7, x3 ? 36 : 28, 32, &l);
     if (L.rc == BSR_OK) {
-      bsr::StemArgs a{inputs, ws + p.x1, l.w, l.b, H, W, 0, 0, h->range_flag};
+      bsr::StemArgs a{inputs, ws + p.x1, l.w, l.b, H, W, 0, 0, 0, h->range_flag};
       L.begin(K_CONV7, "conv1");
       if (h->dtype == BSR_DTYPE_F16)
         L.check((bsr::launch_stem7<4, 2, true>(a, B, s)), "conv1");                 // x1 stored as fp16

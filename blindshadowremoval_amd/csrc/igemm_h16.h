@@ -39,6 +39,9 @@
 #ifndef BSR_H16_RING
 #define BSR_H16_RING 4      // slots of the LDS-DMA weight ring: the image of step s + RING - 1 is requested at the top of step s
 #endif
+#ifndef BSR_H16_PACK_STORES
+#define BSR_H16_PACK_STORES 0          // 1: the fp16 epilogues trade values between neighbouring lanes and store two channels (4 bytes) per lane — measured: transposed convs 370 vs 359 us, stem 85 vs 88 (the permutes and selects cost more than the halved store count saves): off
+#endif
 #ifndef BSR_H16_BDEEP
 #define BSR_H16_BDEEP 0     // 1: f16 transposed convs read the B fragments of a whole step one step ahead (measured: 355.9 vs 358.1 us, nothing — off)
 #endif
@@ -55,6 +58,17 @@ namespace bsr {
 constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
 // vmcnt <= n AND lgkmcnt == 0 (every LDS access of this wave done): what a workgroup barrier needs while LDS-DMAs stay in flight.
 // __syncthreads() cannot be used there: hipcc drains vmcnt to 0 in front of it as soon as a global_load_lds is outstanding.
+// fp16 epilogue stores, two channels per lane (round 5, opt-in BSR_H16_PACK_STORES: measured slower, see the switch).  In a 32x32 accumulator tile lane r holds ONE channel of 16 pixels, so a
+// 2-byte store per value moved 128 bytes per instruction.  Neighbouring lanes (channels r, r ^ 1) trade values through a quad
+// permute: for the pixel pair (k, k + step) the even lane ends up with both channels of pixel k, the odd lane with both of pixel
+// k + step — one 4-byte store each: half the store instructions, 256 bytes per instruction, the same fp16 values (RNE) as before.
+__device__ __forceinline__ unsigned pack_pair_f16(float own_k, float own_k1, bool odd) {
+  const float send = odd ? own_k : own_k1;
+  const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+  const _Float16 lo = (_Float16)(odd ? recv : own_k), hi = (_Float16)(odd ? own_k1 : recv);
+  return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
 constexpr int waitcnt_vm_lgkm0(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4); }
 
 template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, int NSPLIT>
@@ -648,6 +662,10 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   const size_t blk_pix = (size_t)img * p.Ho * p.Wo + (size_t)(SX * y0) * p.Wo + SX * x0;
   constexpr unsigned OB = OUT16 ? 2u : 4u;                       // bytes per output element
   const unsigned lane_out = ((unsigned)(SX * 4 * h) * (unsigned)p.out_cs + (unsigned)r) * OB;
+  // OUT16: packed two-channel stores (pack_pair_f16) when every pixel's channel run starts 4-byte aligned; the odd lane writes the NEXT pixel of a pair
+  const bool odd = (r & 1) != 0;
+  const bool pk = OUT16 && BSR_H16_PACK_STORES && ((p.out_cs | p.out_coff) & 1) == 0;
+  const unsigned lane_out_pk = ((unsigned)(SX * (4 * h + (odd ? 1 : 0))) * (unsigned)p.out_cs + (unsigned)(r & ~1)) * 2u;
   const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.out) + (blk_pix * p.out_cs + p.out_coff) * OB));
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
@@ -674,6 +692,23 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
           for (int i = 0; i < 16; i += 4) amax = amax4(f32x4{v[i], v[i + 1], v[i + 2], v[i + 3]}, amax);
           range_report(voff == kLaneOff ? 0.f : amax, p.range_flag);
         }
+        if (OUT16 && pk) {
+          const bool pair_ok = nt + (r | 1) < p.n_store;
+          const unsigned voff_pk = pair_ok ? lane_out_pk : kLaneOff;
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const int k = SX * ((i & 3) + 8 * (i >> 2));
+            const unsigned soff = (tile_off + (unsigned)k * (unsigned)p.out_cs) * 2u;
+            __builtin_amdgcn_raw_buffer_store_b32(pack_pair_f16(v[i], v[i + 1], odd), orsrc, voff_pk, soff, 0);
+          }
+          if (voff != kLaneOff && !pair_ok) {       // the last channel of an odd channel count has no partner: its own 2-byte stores
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int k = SX * ((i & 3) + 8 * (i >> 2));
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[i]), orsrc, voff, (tile_off + (unsigned)k * (unsigned)p.out_cs) * 2u, 0);
+            }
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = SX * ((i & 3) + 8 * (i >> 2));
@@ -682,6 +717,7 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v[i]), orsrc, voff, soff, 0);
           else
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, voff, soff, 0);
+        }
         }
       }
 #ifdef BSR_STAMPS

@@ -20,6 +20,7 @@ struct StemArgs {
   const float* bias;   // [32]
   int H, W;
   int tiles_x, tiles_y;
+  int n_tiles;            // tiles_x * tiles_y * batch (set by launch_stem7)
   unsigned* range_flag;   // H = 2: set when an image value does not fit fp16 (igemm_h16.h); OUT16: when an output does not; may be null
 };
 
@@ -32,52 +33,103 @@ struct StemCfg {
   static constexpr int TH = 4 * RW, TW = 32, IH = TH + 6, ROWF = 120;   // 38 pixels x 3 floats = 114 used, reads reach 116 (H = 2: 124)
   static constexpr int IN_FLOATS = IH * ROWF + (H ? 8 : 0);
   static constexpr int W_FLOATS = H ? 7 * 32 * 36 : 7 * 32 * 28;
-  static constexpr int SMEM_BYTES = (IN_FLOATS + W_FLOATS) * 4;
+  static constexpr int SMEM_BYTES = (2 * IN_FLOATS + W_FLOATS) * 4;      // two tile buffers (persistent workgroups)
 };
 
 // OUT16 (f16 mode): x1 is written as fp16 (its consumer, down1, rounds it to fp16 anyway): half the bytes of the largest early tensor.
+//
+// Round 5: PERSISTENT workgroups (BSR_STEM_PERSIST, default 1; 0 = one workgroup per tile as before — the same kernel with a grid of
+// one tile each).  The 7 taps' weights are 25 KB (fp32) / 32 KB (split) per workgroup against 10.6 KB of image tile: with one tile per
+// workgroup three quarters of what a workgroup staged was the same weights again, 4 096 times per launch at B = 32.  A workgroup now
+// stages them once and walks tiles b, b + grid, ...: the NEXT tile's 11 image words per thread are requested before the current tile's
+// matrix loop and written (split) into the other of two LDS tile buffers after its stores — one LDS-only barrier per tile, no drain
+// of the outstanding stores.  Same fragments, same accumulation order: bit-identical outputs.
+#ifndef BSR_STEM_PERSIST
+#define BSR_STEM_PERSIST 1
+#endif
+
 template <int RW, int H = 0, bool OUT16 = false>
 __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
   using C = StemCfg<RW, H>;
   constexpr int ROWF = C::ROWF;
+  constexpr int NE = (C::IN_FLOATS + 255) / 256;              // image words per thread and tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_w = smem;                    // weights first: 16-byte aligned rows for ds_read_b128
-  float* s_in = smem + C::W_FLOATS;
+  float* s_in0 = smem + C::W_FLOATS;    // two tile buffers
 
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
-  int bid = blockIdx.x;
-  const int tile_x = bid % p.tiles_x;
-  bid /= p.tiles_x;
-  const int tile_y = bid % p.tiles_y;
-  const int img = bid / p.tiles_y;
-  const int y0 = tile_y * C::TH, x0 = tile_x * C::TW;
-  const float* in_img = p.in + (size_t)img * p.H * p.W * 3;
+  const int per_img = p.tiles_x * p.tiles_y;
+  const int total = p.n_tiles;
 
-  // stage the weights (linear copy) and the raw image tile (zero outside the image: TF SAME padding 3/3)
-  for (int i = tid; i < C::W_FLOATS / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
-  float amax = 0.f;
-  for (int i = tid; i < C::IN_FLOATS; i += 256) {
-    const int row = i / ROWF, f = i % ROWF;
-    const int px = f / 3, c = f % 3;
-    const int iy = y0 - 3 + row, ix = x0 - 3 + px;
-    float v = 0.f;
-    if (row < C::IH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = in_img[((size_t)iy * p.W + ix) * 3 + c];
-    if constexpr (H == 0) {
-      s_in[i] = v;
-    } else {
-      amax = __builtin_fmaxf(__builtin_fabsf(v), amax);
-      const _Float16 vh = (_Float16)v, vl = (_Float16)(v - (float)vh);
-      reinterpret_cast<unsigned*>(s_in)[i] = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
-    }
+  // this thread's words of a tile: word i = tid + 256 e -> tile row i / ROWF, float f = i % ROWF = 3 px + c
+  int e_goff[NE];                       // offset in floats from the tile's origin pixel (y0, x0), channel 0
+  int e_rp[NE];                         // row | px << 8 | in-range << 16
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int i = tid + e * 256;
+    const int row = i / ROWF, f = i % ROWF, px = f / 3, c = f % 3;
+    e_goff[e] = ((row - 3) * p.W + (px - 3)) * 3 + c;
+    e_rp[e] = row | (px << 8) | ((i < C::IN_FLOATS && row < C::IH) ? (1 << 16) : 0);
   }
-  if constexpr (H != 0) range_report(amax, p.range_flag);
+  auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
+    const int tile_x = t % p.tiles_x, rest = t / p.tiles_x;
+    x0 = tile_x * C::TW;
+    y0 = (rest % p.tiles_y) * C::TH;
+    img = rest / p.tiles_y;
+  };
+  auto load_tile = [&](int t, float (&v)[NE]) {               // zero outside the image: TF SAME padding 3/3
+    int img, y0, x0;
+    tile_origin(t, img, y0, x0);
+    const float* org = p.in + ((size_t)img * p.H * p.W + (size_t)y0 * p.W + x0) * 3;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = e_rp[e] & 0xFF, px = (e_rp[e] >> 8) & 0xFF;
+      const int iy = y0 - 3 + row, ix = x0 - 3 + px;
+      const bool ok = (e_rp[e] >> 16) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      v[e] = ok ? org[e_goff[e]] : 0.f;
+    }
+  };
+  auto write_tile = [&](float* s_dst, const float (&v)[NE]) {
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = tid + e * 256;
+      if (i < C::IN_FLOATS) {
+        if constexpr (H == 0) {
+          s_dst[i] = v[e];
+        } else {
+          amax = __builtin_fmaxf(__builtin_fabsf(v[e]), amax);
+          const _Float16 vh = (_Float16)v[e], vl = (_Float16)(v[e] - (float)vh);
+          reinterpret_cast<unsigned*>(s_dst)[i] = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
+        }
+      }
+    }
+    if constexpr (H != 0) range_report(amax, p.range_flag);
+  };
+
+  int t = blockIdx.x;
+  if (t >= total) return;
+  // stage the weights (linear copy, once per workgroup) and the first tile
+  float stg[NE];
+  load_tile(t, stg);
+  for (int i = tid; i < C::W_FLOATS / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+  write_tile(s_in0, stg);
   const float bias = p.bias[r];
+  __syncthreads();
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  int cur = 0;
+  for (; t < total; t += gridDim.x) {
+  const float* s_in = s_in0 + cur * C::IN_FLOATS;
+  const int tn = t + (int)gridDim.x;
+  const bool has_next = tn < total;                              // uniform over the workgroup
+  if (has_next) load_tile(tn, stg);                              // in flight during this tile's matrix loop
+  int img, y0, x0;
+  tile_origin(t, img, y0, x0);
   f32x16 acc[RW];
 #pragma unroll
   for (int mi = 0; mi < RW; ++mi) acc[mi] = bias_tile(h, bias);      // one matrix instruction per tile (igemm_conv.h)
-  __syncthreads();
   __builtin_amdgcn_s_setprio(0);
 
   if constexpr (H == 0) {
@@ -132,7 +184,6 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
 
   __builtin_amdgcn_s_setprio(3);
   // raw-buffer stores (igemm_conv.h): SGPR offset per element, one constant lane offset
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   constexpr unsigned OB = OUT16 ? 2u : 4u;
   const unsigned lane_out = ((unsigned)(4 * h) * 32u + (unsigned)r) * OB;
   const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(reinterpret_cast<const float*>(
@@ -152,6 +203,15 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
       for (int i = 0; i < 16; i += 4) om = amax4(f32x4{v[i], v[i + 1], v[i + 2], v[i + 3]}, om);
       range_report(om, p.range_flag);
     }
+    if constexpr (OUT16 && BSR_H16_PACK_STORES) {      // two channels per lane (igemm_h16.h: pack_pair_f16): the odd lane writes the next pixel of a pair
+      const bool odd = (r & 1) != 0;
+      const unsigned lane_pk = ((unsigned)(4 * h + (odd ? 1 : 0)) * 32u + (unsigned)(r & ~1)) * 2u;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const int k = (i & 3) + 8 * (i >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(pack_pair_f16(v[i], v[i + 1], odd), orsrc, lane_pk, ((unsigned)(mi * p.W + k) * 32u) * 2u, 0);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int k = (i & 3) + 8 * (i >> 2);
@@ -160,6 +220,15 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(StemArgs p) {
       else
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), orsrc, lane_out, ((unsigned)(mi * p.W + k) * 32u) * OB, 0);
     }
+    }
+  }
+  if (!has_next) break;
+  write_tile(s_in0 + (cur ^ 1) * C::IN_FLOATS, stg);             // that buffer was last read one tile ago, behind the previous barrier
+  // LDS-only barrier: __syncthreads() would also wait for this tile's stores to be acknowledged (vmcnt 0) — a memory round trip per tile
+  __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));
+  __builtin_amdgcn_s_barrier();
+  cur ^= 1;
+  __builtin_amdgcn_s_setprio(0);
   }
 }
 
@@ -168,7 +237,17 @@ inline hipError_t launch_stem7(StemArgs a, int batch, hipStream_t stream) {
   using C = StemCfg<RW, H>;
   a.tiles_x = a.W / C::TW;
   a.tiles_y = a.H / C::TH;
-  hipLaunchKernelGGL((stem7_kernel<RW, H, OUT16>), dim3(a.tiles_x * a.tiles_y * batch), dim3(256), C::SMEM_BYTES, stream, a);
+  a.n_tiles = a.tiles_x * a.tiles_y * batch;
+  const int resident = 2 * device_cu_count();                    // __launch_bounds__(256, 2): two workgroups per CU
+  const int grid = BSR_STEM_PERSIST ? (a.n_tiles < resident ? a.n_tiles : resident) : a.n_tiles;
+  static PerDeviceOnce once;
+  const int dev = PerDeviceOnce::current();
+  if (C::SMEM_BYTES > 48 * 1024 && (dev < 0 || !once.done[dev])) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7_kernel<RW, H, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES);
+    if (e != hipSuccess) return e;
+    if (dev >= 0) once.done[dev] = true;
+  }
+  hipLaunchKernelGGL((stem7_kernel<RW, H, OUT16>), dim3(grid), dim3(256), C::SMEM_BYTES, stream, a);
   return hipGetLastError();
 }
 
