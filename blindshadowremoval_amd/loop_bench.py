@@ -60,7 +60,13 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
             # round 5: the PNG files themselves are built on the device (gpu_png.py): no encoder pool, every usable CPU decodes / triangulates
             modes.append(("device_png", dict(workers=max(2, ncpu * 5 // 8), device_prep=fsr.gen._device, device_batch=batch),
                           dict(post_workers=0, png_workers=0, post_inflight=3, gpu_png=True)))
+        if not ucb:
+            # the same loop with 32 items per forward (testFFHQ's batch is the caller's choice; 16 is configs[2]'s UCB batch): the loop's
+            # own thread pays its per-batch Python once per 32 items and the forward runs at its B = 32 rate
+            modes.append(("device_png_batch32", dict(workers=max(2, ncpu * 5 // 8), device_prep=fsr.gen._device, device_batch=2 * batch),
+                          dict(post_workers=0, png_workers=0, post_inflight=3, gpu_png=True, batch=2 * batch)))
         for label, ds_kw, fsr_kw in modes:
+            mb = int(fsr_kw.get("batch", batch))                         # items per forward in this mode
             ds = Dataset(cfg, "test", ucb=ucb, **ds_kw)
             fsr.post_workers = fsr_kw.get("post_workers", 0)
             fsr.post_inflight = fsr_kw.get("post_inflight", fsr.post_inflight)
@@ -81,7 +87,7 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
                 fsr.warm_pools()                                         # pinned staging buffers; worker pools / device kernels of the post-processing
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
-                out = fsr.test(ds, batch=batch, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=batch)
+                out = fsr.test(ds, batch=mb, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=mb)
             dt = time.perf_counter() - t0
             tm = dict(fsr.timings)
             res[label] = {"workers": ds.workers, "items": len(out), "images_per_sec": round(len(out) / dt, 2), "seconds": round(dt, 3),
@@ -89,7 +95,7 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
             if fsr_kw:
                 t_first = tm.get("first_batch_done_s", 0.0)
                 res[label].update(post_workers=fsr.post_workers if ucb else 0, png_workers=fsr.log.png_workers, gpu_png=fsr.log.gpu_png, post_device=fsr.post_device,
-                                  steady_images_per_sec=round((len(out) - batch) / max(dt - t_first, 1e-9), 2),
+                                  batch=mb, steady_images_per_sec=round((len(out) - mb) / max(dt - t_first, 1e-9), 2),
                                   note="worker processes started and warmed before the clock; steady_images_per_sec = items after the first batch / time after it")
             ds.close()
     finally:

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from blindshadowremoval_amd.dataset import Dataset, cpu_share
 from blindshadowremoval_amd.fsrnet import Config, FSRNet
 from blindshadowremoval_amd.weights import init_weights
+BATCH = int(os.environ.get("LOOP_BATCH", "16"))
 kind = sys.argv[1]
 items = int(sys.argv[2])
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -17,7 +18,7 @@ fsr.return_figs = False
 print("cpu_share", cpu_share())
 for rep in range(2):
     for workers in [int(w) for w in sys.argv[3:]]:
-        ds = Dataset(cfg, "test", ucb=ucb, workers=workers, device_prep=0, device_batch=16)
+        ds = Dataset(cfg, "test", ucb=ucb, workers=workers, device_prep=0, device_batch=BATCH)
         base = list(ds.name_list)
         reps = (items + len(base) - 1) // len(base)
         ds.name_list = (base * reps)[:items]
@@ -25,7 +26,7 @@ for rep in range(2):
         ds.warm(); fsr.log.warm(); fsr.warm_pools()
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()):
-            out = fsr.test(ds, batch=16, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=16)
+            out = fsr.test(ds, batch=BATCH, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=BATCH)
         dt = time.perf_counter() - t0
         print(kind, "workers", workers, "items", len(out), round(len(out) / dt, 1), "/s", {k: round(v, 3) for k, v in fsr.timings.items() if k.endswith("_s")}, flush=True)
         ds.close()

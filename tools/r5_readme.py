@@ -93,7 +93,7 @@ resident batch of 32); the two-lane throughput of rounds 3-4 is the side figure 
   runs each): `FSRNet.test` (UCB: seven masks per item, post-processing, SSIM / PSNR, seven-figure strips) **%s images/s** with the
   post-processing and the PNG encoding on the device (`device_post`; steady %s) against %s with the host post-processing of round 4
   (`device_prep`) on the same boxes; `FSRNet.testFFHQ` **%s images/s** with device-built PNG files (`device_png`; steady %s) against %s with
-  the host encoder pool.
+  the host encoder pool; the same loop with 32 items per forward (`device_png_batch32`: the batch of `testFFHQ` is the caller's) %s.
 * **`r5_loop_stage_table.json`** — the host stages that are LEFT, each alone through %d worker processes: loader host half %.0f items/s (%.2f ms of
   CPU per item), the same with the item's seven masks %.0f /s (%.2f ms), writing the device-built PNG files %.0f /s (FFHQ strips) and %.0f /s
   (UCB strips); for comparison the stages round 5 took off the host: PNG strip encoding %.0f /s (%.2f ms), UCB post-processing %.0f /s (%.1f ms).
@@ -113,6 +113,7 @@ resident batch of 32); the two-lane throughput of rounds 3-4 is the side figure 
     sweep_rows, loops["ucb"][0].get("usable_cpus", 16),
     rng(loop("ucb", "device_post")), rng(loop("ucb", "device_post", "steady_images_per_sec")), rng(loop("ucb", "device_prep")),
     rng(loop("ffhq", "device_png")), rng(loop("ffhq", "device_png", "steady_images_per_sec")), rng(loop("ffhq", "device_prep")),
+    rng(loop("ffhq", "device_png_batch32")) if all("device_png_batch32" in r for r in loops["ffhq"]) else "(not measured)",
     st["worker_processes"], stg["loader_host_half"]["items_per_sec"], stg["loader_host_half"]["job_cpu_ms_alone"],
     stg["loader_host_half_with_masks"]["items_per_sec"], stg["loader_host_half_with_masks"]["job_cpu_ms_alone"],
     stg["file_write_ffhq"]["items_per_sec"], stg["file_write_ucb"]["items_per_sec"], stg["png_strip"]["items_per_sec"], stg["png_strip"]["job_cpu_ms_alone"],
