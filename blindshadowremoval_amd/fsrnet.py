@@ -446,11 +446,22 @@ class FSRNet(object):
             self._post_pool, self._post_pool_n = _SelectPool(self.post_workers), self.post_workers
         return self._post_pool
 
-    def warm_pools(self) -> None:
+    def warm_pools(self, batch: Optional[int] = None) -> None:
         """Start the post-processing workers (post_workers > 0) and let them import torch / scipy now, not inside the timed loop; with the
         device post-processing (post_device on a GPU) run its kernels and the PNG encoder once on a dummy item — the first launch of a
         kernel family loads its code object, the first use of a torch operator its module: ~1 s in all on a fresh process."""
         dev = getattr(self.gen, "_device", None)
+        if batch and dev is not None and torch.cuda.is_available():
+            # one forward of the loop's batch: the library sizes its workspace for the largest batch it has seen (a hipMalloc + the first
+            # launches of the batch-dependent instantiations: ~0.15 s that would otherwise sit in the loop's first batch)
+            s_ = self.config.IMG_SIZE
+            z = torch.zeros((int(batch), s_, s_, 3), dtype=torch.float32, device="cuda:%d" % dev)
+            self.gen(z, z, None, chuck=1, training=False)
+            torch.cuda.synchronize(dev)
+            try:
+                self.gen.check_range()             # zeros in, nothing out of range: leaves the flag clear
+            except Exception:
+                pass
         if dev is not None and torch.cuda.is_available():      # the loops' pinned staging buffers: gpu_inflight + 1 of a batch of 16 seven-figure strips each
             while len(self._pin_pool) < int(self.gpu_inflight) + 1:
                 self._pin_pool.append(None)

@@ -84,7 +84,7 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
             if fsr_kw:                                                   # worker start-up (python + torch imports) is not part of the loop's rate
                 ds.warm()
                 fsr.log.warm()
-                fsr.warm_pools()                                         # pinned staging buffers; worker pools / device kernels of the post-processing
+                fsr.warm_pools(batch=mb)                                 # pinned staging buffers; worker pools / device kernels of the post-processing; the workspace of this batch
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
                 out = fsr.test(ds, batch=mb, mask_files=masks) if ucb else fsr.testFFHQ(ds, batch=mb)

@@ -93,7 +93,7 @@ def main(argv=None) -> int:
     try:
         ds.warm()
         fsr.log.warm()
-        fsr.warm_pools()
+        fsr.warm_pools(batch=args.batch)
         if grouped:
             import torch.distributed as dist
             dist.barrier()
