@@ -235,6 +235,13 @@ class SlotRing:
             except Exception:
                 pass
         self.pinned = False
+        del t
+        mm, self._mm = getattr(self, "_mm", None), None
+        if mm is not None:
+            try:
+                mm.close()                       # refused (BufferError) while a view of the mapping is still alive somewhere: the GC takes it then
+            except (BufferError, ValueError):
+                pass
 
 
 def _layout(parts, size: int):
