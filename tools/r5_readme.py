@@ -188,7 +188,8 @@ What the round did (`profiles/README.md` has the tables, `profiles/HISTORY.md` w
    the conv2 -> conv3|qkv tail of the fp32 path carried over; the f16 transposed convs' 2-byte stores.
 3. **Parity** stays unpinned until someone runs `tools/make_model_fixture.py --backend tf` and `tools/make_ucb_post_fixture.py --backend tf`.
 4. **Loops**: at ~0.8 of what the GPU side sustains without a loader (B = 16 forward + strips + PNG + copies); what is left is qhull (1.1 of the
-   loader's 1.5 ms per item) and the loop's own Python thread.  Fusing the strip assembly into the PNG encoder was bounded first
+   loader's 1.5 ms per FFHQ item), zlib's inflate of the UCB items' two compressed RGB files (~1.3 ms each on this container's CPU: half
+   of a UCB item's host time) and the loop's own Python thread.  Fusing the strip assembly into the PNG encoder was bounded first
    (`scratch/strip_bound.py`: the loop with a constant strip, i.e. no elementwise launches at all, is not faster) and not built.
 <!-- END r5 DESIGN -->''' % (
     b["value"], b["two_in_flight_value"], r4["single_stream_value"], r4["value"], b["ms_per_step"], rf["achieved"], 100 * rf["frac"],
