@@ -132,3 +132,64 @@ def test_device_zero_extended_crop(tmp_path):
     torch.cuda.synchronize()
     err = np.abs(out[0].cpu().numpy() - row_host).max(axis=(0, 1))
     assert err.max() <= 1e-6, err
+
+
+def _culled_winner(t, lin, by, bx):
+    """numpy statement of prep_rows_kernel's round-5 block culling for one 16x16-pixel block of one mesh: -> (index of the winning
+    triangle per pixel, -1 when every triangle was culled; its min barycentric; how many triangles the block walks)."""
+    gx0, gx1, gy0, gy1 = lin[bx * 16], lin[bx * 16 + 15], lin[by * 16], lin[by * 16 + 15]
+    keep = np.ones(t.shape[0], bool)
+    for i in range(3):
+        mx = np.maximum(t[:, 3 * i] * gx0, t[:, 3 * i] * gx1)
+        my = np.maximum(t[:, 3 * i + 1] * gy0, t[:, 3 * i + 1] * gy1)
+        keep &= ((mx + my) + t[:, 3 * i + 2] >= -1.0e-9)
+    idx = np.nonzero(keep)[0]                                   # survivors in their original order
+    px, py = np.meshgrid(lin[bx * 16:bx * 16 + 16], lin[by * 16:by * 16 + 16])
+    if idx.size == 0:
+        return np.full(px.shape, -1), np.full(px.shape, -1.0e300), 0
+    s = t[idx]
+    l = np.stack([(s[:, 3 * i][:, None, None] * px + s[:, 3 * i + 1][:, None, None] * py) + s[:, 3 * i + 2][:, None, None] for i in range(3)], 0).min(0)
+    best = l.argmax(0)                                          # first of equal maxima, as the kernel's strict `>`
+    return idx[best], np.take_along_axis(l, best[None], 0)[0], int(idx.size)
+
+
+def test_block_culling_keeps_every_winner(golden_dir, tmp_path):
+    """Round 5: a workgroup of prep_rows_kernel walks only the triangles whose edge functions can reach -1e-9 somewhere on its 16x16-pixel
+    block.  For every block of every mesh of the sample and of the corner case: wherever the full search finds a triangle `inside`
+    (>= -1e-12), the culled search finds THE SAME triangle; where it finds none, neither does the culled one — the two cases the
+    kernel's outputs depend on.  And the point of it: a block walks a small fraction of the mesh."""
+    size = 256
+    lin = np.linspace(0, 1, size)
+    px, py = np.meshgrid(lin, lin)
+    corner = prep.host_part((_border_case(tmp_path) + ".npy", None, size))
+    walked, total = 0, 0
+    for part in (_sample_part(golden_dir), corner):
+        for t in part[3]:
+            l = np.stack([(t[:, 3 * i][:, None, None] * px + t[:, 3 * i + 1][:, None, None] * py) + t[:, 3 * i + 2][:, None, None] for i in range(3)], 0).min(0)
+            full_best = l.argmax(0)
+            full_l = np.take_along_axis(l, full_best[None], 0)[0]
+            for by in range(size // 16):
+                for bx in range(size // 16):
+                    cb, cl, n = _culled_winner(t, lin, by, bx)
+                    sl = (slice(by * 16, by * 16 + 16), slice(bx * 16, bx * 16 + 16))
+                    inside = full_l[sl] >= -1e-12
+                    assert np.array_equal(cb[inside], full_best[sl][inside])
+                    assert np.array_equal(cl >= -1e-12, inside)
+                    walked += n
+                    total += t.shape[0]
+    assert walked < 0.2 * total, (walked, total)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [64, 128])
+def test_device_rows_at_other_sizes_match_the_host_path(golden_dir, size):
+    """The block mapping of the kernel (16x16 pixels per workgroup, S / 16 blocks per row) at other S than the reference's 256."""
+    import torch
+    base = os.path.join(golden_dir, "sample_imgs", "02165", "02165")
+    row_host, _ = D.build_row(base + ".png", base + ".npy", None, size)
+    out, _ = prep.DevicePrep(0, size).rows([prep.host_part((base + ".npy", None, size))])
+    torch.cuda.synchronize()
+    got = out[0].cpu().numpy()
+    assert got.shape == (size, size, 16)
+    err = np.abs(got - row_host).max(axis=(0, 1))
+    assert err.max() <= 1e-6, err
