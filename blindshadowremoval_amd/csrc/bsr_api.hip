@@ -437,7 +437,7 @@ int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
 
 extern "C" {
 
-int bsr_abi_version(void) { return 5; }
+int bsr_abi_version(void) { return 6; }
 
 #ifndef BSR_SRC_SHA
 #define BSR_SRC_SHA "unhashed"
@@ -873,7 +873,7 @@ size_t bsr_png_file_bytes(int H, int W) {
   return bsr::png_geometry(H, W, &g) ? (size_t)g.file_bytes : 0;
 }
 
-size_t bsr_png_scratch_bytes(int B) { return B > 0 ? (size_t)B * 4 * sizeof(unsigned long long) : 0; }
+size_t bsr_png_scratch_bytes(int B) { return B > 0 ? (size_t)B * bsr::kPngSub * 4 * sizeof(unsigned long long) : 0; }
 
 int bsr_png_encode(int device, const unsigned char* pixels, int B, int H, int W, unsigned char* out, size_t out_stride, void* scratch, void* stream) {
   if (pixels == nullptr || out == nullptr || scratch == nullptr) return fail(BSR_ERR_ARG, "bsr_png_encode: null argument");
@@ -883,7 +883,39 @@ int bsr_png_encode(int device, const unsigned char* pixels, int B, int H, int W,
   if (reinterpret_cast<uintptr_t>(scratch) % 8 != 0) return fail(BSR_ERR_ARG, "bsr_png_encode: scratch must be 8-byte aligned");
   DeviceGuard guard(device);
   HIP_TRY(guard.err);
-  HIP_TRY(bsr::launch_png_encode(pixels, B, g, out, out_stride, static_cast<unsigned long long*>(scratch), static_cast<hipStream_t>(stream)));
+  bsr::PngFigs none{};
+  HIP_TRY(bsr::launch_png_encode(pixels, none, B, g, out, out_stride, static_cast<unsigned long long*>(scratch), static_cast<hipStream_t>(stream)));
+  return BSR_OK;
+}
+
+int bsr_png_encode_figs(int device, int n_figs, const float* const* figs, const float* const* muls, const float* scales, const int* channels,
+                        const int* pixel_strides, const int* mul_strides, int B, int H, int Wf, unsigned char* out, size_t out_stride, void* scratch,
+                        void* stream) {
+  if (figs == nullptr || channels == nullptr || pixel_strides == nullptr || out == nullptr || scratch == nullptr)
+    return fail(BSR_ERR_ARG, "bsr_png_encode_figs: null argument");
+  if (n_figs < 1 || n_figs > bsr::kPngMaxFigs) return fail(BSR_ERR_ARG, "bsr_png_encode_figs: 1 to 8 figures per strip");
+  bsr::PngGeom g;
+  if (B <= 0 || Wf <= 0 || !bsr::png_geometry(H, n_figs * Wf, &g))
+    return fail(BSR_ERR_ARG, "bsr_png_encode_figs: B, H, Wf must be positive, the strip's width n_figs * Wf <= 5461 and H <= 65535");
+  if (out_stride < g.file_bytes) return fail(BSR_ERR_ARG, "bsr_png_encode_figs: out_stride is smaller than bsr_png_file_bytes(H, n_figs * Wf)");
+  if (reinterpret_cast<uintptr_t>(scratch) % 8 != 0) return fail(BSR_ERR_ARG, "bsr_png_encode_figs: scratch must be 8-byte aligned");
+  bsr::PngFigs f{};
+  f.n = n_figs;
+  f.Wf = Wf;
+  for (int k = 0; k < n_figs; ++k) {
+    if (figs[k] == nullptr || (channels[k] != 1 && channels[k] != 3) || pixel_strides[k] < channels[k])
+      return fail(BSR_ERR_ARG, "bsr_png_encode_figs: every figure needs a pointer, 1 or 3 channels and a pixel stride of at least its channels");
+    f.ptr[k] = figs[k];
+    f.mul[k] = muls != nullptr ? muls[k] : nullptr;
+    f.scale[k] = scales != nullptr ? scales[k] : 1.f;
+    f.ch[k] = channels[k];
+    f.ps[k] = pixel_strides[k];
+    f.mps[k] = (mul_strides != nullptr && f.mul[k] != nullptr) ? mul_strides[k] : 1;
+    if (f.mul[k] != nullptr && f.mps[k] < 1) return fail(BSR_ERR_ARG, "bsr_png_encode_figs: a multiplier needs a positive pixel stride");
+  }
+  DeviceGuard guard(device);
+  HIP_TRY(guard.err);
+  HIP_TRY(bsr::launch_png_encode(nullptr, f, B, g, out, out_stride, static_cast<unsigned long long*>(scratch), static_cast<hipStream_t>(stream)));
   return BSR_OK;
 }
 

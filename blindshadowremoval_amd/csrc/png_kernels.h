@@ -91,11 +91,34 @@ __device__ inline unsigned crc_shift_bytes(const PngGeom& g, unsigned c, unsigne
 
 constexpr int kPngSegMax = 16384 + 16;                        // LDS bytes per wave: a scanline + the headers that may precede it
 constexpr int kPngWaves = 4;
+constexpr int kPngSub = 8;                                    // checksum sub-accumulators per file (workgroup b adds into b % 8: at most H / 32 atomics per address)
+constexpr int kPngMaxFigs = 8;
 
-// pixels: [B][H][W][3] uint8 (device).  out: B files, `stride` bytes apart.  acc: [B][4] 64-bit words, zeroed: {sum d, sum (n - j) d, crc xor, -}
+// Source of a strip as FIGURES (round 5, bsr_png_encode_figs): the strip is n figures side by side, figure k a float32 [B][H][Wf] image
+// of ch[k] = 1 or 3 channels whose pixels are ps[k] floats apart (a channel slice of a wider NHWC tensor is fine), optionally multiplied
+// by a one-channel float32 image mul[k] (pixels mps[k] floats apart) and by scale[k]; a pixel's byte is round-half-even(clamp(v, 0, 1) * 255)
+// — Logging.get_imgs / strips_on_device (fsrnet.py) for the whole strip, without the uint8 strip tensor or any of its elementwise passes.
+struct PngFigs {
+  const float* ptr[kPngMaxFigs];
+  const float* mul[kPngMaxFigs];
+  float scale[kPngMaxFigs];
+  int ch[kPngMaxFigs], ps[kPngMaxFigs], mps[kPngMaxFigs];
+  int n, Wf;                                                  // n == 0: the source is the uint8 strip
+};
+
+__device__ __forceinline__ unsigned char png_quantise(float v) {
+#pragma clang fp contract(off)
+  const float c = __builtin_fminf(__builtin_fmaxf(v, 0.f), 1.f) * 255.f;
+  return (unsigned char)__builtin_rintf(c);
+}
+
+// pixels: [B][H][W][3] uint8 (device), or figs.n > 0.  out: B files, `stride` bytes apart.  acc: [B][kPngSub][4] 64-bit words, zeroed:
+// {sum d, sum (n - j) d, crc xor, -}; a workgroup reduces its four scanlines in LDS and adds ONCE, into sub-accumulator blockIdx.x % 8
+// (one atomic per scanline into one address per file serialised 768 atomics per file: 0.11 ms per 16 strips, most of this kernel)
 __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __restrict__ pixels, unsigned char* __restrict__ out, size_t stride,
-                                                       unsigned long long* __restrict__ acc, PngGeom g) {
+                                                       unsigned long long* __restrict__ acc, PngGeom g, PngFigs figs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char png_smem[];
+  __shared__ unsigned long long s_red[kPngWaves][3];
   unsigned* s_tab = reinterpret_cast<unsigned*>(png_smem);                       // 256-entry CRC table
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned char* seg = png_smem + 1024 + (size_t)wave * kPngSegMax;
@@ -133,7 +156,26 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
     }
     const unsigned char* src = pixels + ((size_t)item * g.H + y) * (size_t)(3 * g.W);
     const int nb = 3 * g.W;
-    if (((3 * g.W) & 3) == 0 && (reinterpret_cast<uintptr_t>(pixels) & 3) == 0) {
+    if (figs.n > 0) {
+      unsigned char* d = seg + hdr + 1;
+      const size_t rowpix = ((size_t)item * g.H + y) * (size_t)figs.Wf;
+      for (int k = 0; k < figs.n; ++k) {
+        const float* fp = figs.ptr[k];
+        const float* mp = figs.mul[k];
+        const float sc = figs.scale[k];
+        const int ch3 = figs.ch[k] == 3;
+        for (int x = lane; x < figs.Wf; x += 64) {
+#pragma clang fp contract(off)
+          const float* px = fp + (rowpix + x) * (size_t)figs.ps[k];
+          const float m = mp != nullptr ? mp[(rowpix + x) * (size_t)figs.mps[k]] : 1.f;
+          float v0 = px[0], v1 = ch3 ? px[1] : v0, v2 = ch3 ? px[2] : v0;
+          if (mp != nullptr) { v0 = v0 * m; v1 = v1 * m; v2 = v2 * m; }
+          if (sc != 1.f) { v0 = v0 * sc; v1 = v1 * sc; v2 = v2 * sc; }
+          unsigned char* o = d + 3 * (k * figs.Wf + x);
+          o[0] = png_quantise(v0); o[1] = png_quantise(v1); o[2] = png_quantise(v2);
+        }
+      }
+    } else if (((3 * g.W) & 3) == 0 && (reinterpret_cast<uintptr_t>(pixels) & 3) == 0) {
       const unsigned* src4 = reinterpret_cast<const unsigned*>(src);
       for (int i = lane; i < nb / 4; i += 64) {
         const unsigned v = src4[i];
@@ -145,7 +187,8 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
     }
   }
   __syncthreads();
-  if (!live) return;
+  if (lane == 0) { s_red[wave][0] = 0ull; s_red[wave][1] = 0ull; s_red[wave][2] = 0ull; }
+  if (live) {
   const int seg_len = hdr + g.RB;
   // copy the segment to the file image
   unsigned char* dst = out + (size_t)item * stride + file_off;
@@ -174,11 +217,18 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
     sa += __shfl_xor(sa, o);
     sb += __shfl_xor(sb, o);
   }
-  if (lane == 0) {
-    unsigned long long* a = acc + (size_t)item * 4;
-    atomicAdd(a, sa);
-    atomicAdd(a + 1, sb);
-    atomicXor(reinterpret_cast<unsigned*>(a + 2), contrib);
+  if (lane == 0) { s_red[wave][0] = sa; s_red[wave][1] = sb; s_red[wave][2] = contrib; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long ra = 0, rb = 0;
+    unsigned rc = 0;
+#pragma unroll
+    for (int w = 0; w < kPngWaves; ++w) { ra += s_red[w][0]; rb += s_red[w][1]; rc ^= (unsigned)s_red[w][2]; }
+    unsigned long long* a = acc + ((size_t)item * kPngSub + (blockIdx.x % kPngSub)) * 4;
+    atomicAdd(a, ra);
+    atomicAdd(a + 1, rb);
+    atomicXor(reinterpret_cast<unsigned*>(a + 2), rc);
   }
 }
 
@@ -196,9 +246,13 @@ __global__ void png_finish_kernel(unsigned char* __restrict__ out, size_t stride
   f[24] = 8; f[25] = 2; f[26] = 0; f[27] = 0; f[28] = 0;     // 8 bits, truecolour, deflate, adaptive filtering, no interlace
   be32(29, g.ihdr_crc);
   be32(33, g.zlen);
-  const unsigned long long* a = acc + (size_t)item * 4;
+  unsigned long long a[3] = {0ull, 0ull, 0ull};               // fold the sub-accumulators (sums and XOR: any order)
+  for (int k = 0; k < kPngSub; ++k) {
+    const unsigned long long* ak = acc + ((size_t)item * kPngSub + k) * 4;
+    a[0] += ak[0]; a[1] += ak[1]; a[2] ^= ak[2];
+  }
   const unsigned long long n_raw = (unsigned long long)g.H * (unsigned long long)g.RB;
-  const unsigned A = (unsigned)((1ull + a[0]) % 65521ull), Bv = (unsigned)((n_raw + a[1]) % 65521ull);
+  const unsigned A = (unsigned)((1ull + a[0] % 65521ull) % 65521ull), Bv = (unsigned)((n_raw % 65521ull + a[1] % 65521ull) % 65521ull);
   const unsigned adler = (Bv << 16) | A;
   const unsigned tail = 41u + g.zlen - 4u;                   // file offset of the Adler-32
   be32(tail, adler);
@@ -210,9 +264,9 @@ __global__ void png_finish_kernel(unsigned char* __restrict__ out, size_t stride
   be32(tail + 16, 0xAE426082u);
 }
 
-inline hipError_t launch_png_encode(const unsigned char* pixels, int B, const PngGeom& g, unsigned char* out, size_t stride,
+inline hipError_t launch_png_encode(const unsigned char* pixels, const PngFigs& figs, int B, const PngGeom& g, unsigned char* out, size_t stride,
                                     unsigned long long* acc, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * 4 * sizeof(unsigned long long), stream);
+  hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * kPngSub * 4 * sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   const int smem = 1024 + kPngWaves * kPngSegMax;
   static PerDeviceOnce once;
@@ -222,7 +276,7 @@ inline hipError_t launch_png_encode(const unsigned char* pixels, int B, const Pn
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
-  hipLaunchKernelGGL(png_rows_kernel, dim3((unsigned)((g.H + kPngWaves - 1) / kPngWaves), (unsigned)B), dim3(256), smem, stream, pixels, out, stride, acc, g);
+  hipLaunchKernelGGL(png_rows_kernel, dim3((unsigned)((g.H + kPngWaves - 1) / kPngWaves), (unsigned)B), dim3(256), smem, stream, pixels, out, stride, acc, g, figs);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(png_finish_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, out, stride, acc, g, B);

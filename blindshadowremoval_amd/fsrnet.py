@@ -129,8 +129,23 @@ class Logging(object):
 
     def files_on_device(self, figs: Sequence[torch.Tensor]) -> torch.Tensor:
         """strips_on_device + the PNG encoding itself on the device: uint8 [B, file_bytes] — row j is the complete PNG file of item j's
-        strip (decodes to exactly get_imgs' pixels)."""
-        return self.encode_strips(self.strips_on_device(figs))
+        strip (decodes to exactly get_imgs' pixels).  A figure may be a tuple (tensor, one-channel multiplier | None, scale)."""
+        dev = None
+        for f in figs:
+            t = f[0] if isinstance(f, tuple) else f
+            dev = t.device.index if t.is_cuda else None
+            break
+        if dev is not None:
+            # round 5: the kernel reads the figures themselves (bsr_png_encode_figs) — no uint8 strip tensor, none of its eleven elementwise /
+            # concatenation launches (0.26 ms of GPU time per 16 strips); same bytes.  A figure layout it does not address -> the strip path.
+            if dev not in self._encoders:
+                from .gpu_png import StripEncoder
+                self._encoders[dev] = StripEncoder(dev)
+            files = self._encoders[dev].encode_figs(figs)
+            if files is not None:
+                return files
+        plain = [(f[0] * f[1] * f[2] if f[1] is not None else f[0] * f[2]) if isinstance(f, tuple) else f for f in figs]
+        return self.encode_strips(self.strips_on_device(plain))
 
     def encode_strips(self, strips: torch.Tensor) -> torch.Tensor:
         """uint8 [B,S,W,3] strips on a GPU -> their PNG files [B, file_bytes] on that GPU (gpu_png.StripEncoder, one per device)."""
@@ -745,9 +760,13 @@ class FSRNet(object):
             else:
                 # FFHQ / raw-UCB: the figures stay on the device; the PNG strips of the whole batch are assembled there and come
                 # over as bytes in one copy (Logging.strips_on_device = get_imgs per item, same arithmetic)
+                lazy = gpu_png and not self.return_figs        # nobody gets the figures back: the encoder clips / multiplies while it reads them
                 if ucb:
                     figs_b = [im_d, gs, con_rgb, mask_pred, gt_d, face_d]
-                    shown_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]
+                    shown_b = [im_d, con_rgb, (mask_pred, face_d, 2.0)] if lazy else [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]
+                elif lazy:
+                    figs_b = None
+                    shown_b = [im_d, con_rgb, (mask_pred, face_d, 2.0)]                          # clip(con_rgb, 0, 1) is the encoder's own clamp
                 else:
                     figs_b = [im_d, torch.clamp(con_rgb, 0, 1), mask_pred * face_d * 2]        # train_test_GSC.py:872-873,889
                     shown_b = figs_b
@@ -851,7 +870,7 @@ class FSRNet(object):
             for j, (step, name, _, box) in enumerate(items):
                 self.log.display({}, 0, step, False, num_list)
                 tm["items"] += 1
-                results.append((name, [f[j:j + 1] for f in figs_b]))
+                results.append((name, [f[j:j + 1] for f in figs_b] if figs_b is not None else None))
             tm["png_s"] += time.perf_counter() - t1
 
         try:

@@ -141,6 +141,18 @@ size_t bsr_png_scratch_bytes(int B);
 int bsr_png_encode(int device, const unsigned char* pixels, int B, int H, int W, unsigned char* out, size_t out_stride, void* scratch,
                    void* stream);
 
+/* The same files straight from the FIGURES: replaces Logging.get_imgs + cv2.imwrite (/root/reference/utils.py:180-204: clip to [0,1],
+ * x 255, to uint8, figures side by side) for a batch.  The strip is n_figs figures of H x Wf pixels side by side (W = n_figs * Wf);
+ * figure k is float32 [B,H,Wf] with channels[k] = 1 (grey, replicated) or 3 channels, its pixels pixel_strides[k] floats apart (a
+ * channel slice of a wider NHWC tensor is fine), optionally multiplied by the one-channel float32 image muls[k] (pixels mul_strides[k]
+ * floats apart; muls / its entries may be NULL) and by scales[k] (scales may be NULL = 1): test_step_FFHQ's third figure is
+ * mask_pred * face * 2 (/root/reference/train_test_GSC.py:872-873).  byte = round-half-even(clamp(v, 0, 1) * 255), each product rounded
+ * to float32 as the reference's elementwise operations are.  The pointer arrays are HOST arrays of DEVICE pointers.  out, out_stride,
+ * scratch, stream: as bsr_png_encode with W = n_figs * Wf.  ABI 6. */
+int bsr_png_encode_figs(int device, int n_figs, const float* const* figs, const float* const* muls, const float* scales, const int* channels,
+                        const int* pixel_strides, const int* mul_strides, int B, int H, int Wf, unsigned char* out, size_t out_stride, void* scratch,
+                        void* stream);
+
 /* The per-item post-processing of FSRNet.test_step on the device: replaces /root/reference/train_test_GSC.py:424-748 (resize to the crop
  * box + zero pad :437-477, region thresholds :479-590, 4-connected components :594-615, nose rule :650-666, composite :711-722, SSIM /
  * PSNR :724-725, the seven figures of :744 as one strip) for a batch of B items.

@@ -105,3 +105,37 @@ def test_device_encoder_refuses_bad_arguments():
         enc.encode(torch.zeros((1, 4, 4, 3), dtype=torch.uint8))
     with pytest.raises(ValueError):
         enc.encode(torch.zeros((1, 4, 6000, 3), dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(16, 256, 256), (3, 64, 40), (2, 5, 7), (1, 1, 1)])
+def test_files_from_figures_equal_files_from_strips(geom):
+    """bsr_png_encode_figs (round 5): the PNG files written straight from the float figures — channel slices of a wider NHWC tensor, a
+    one-channel figure, a one-channel figure times a multiplier image times 2 (test_step_FFHQ's strip) — are byte for byte the files of
+    the strip path (Logging.strips_on_device -> bsr_png_encode), values below 0, above 1 and exactly on .5 ties included."""
+    import torch
+    from blindshadowremoval_amd.fsrnet import Logging
+    from blindshadowremoval_amd.gpu_png import StripEncoder
+    b, h, wf = geom
+    g = torch.Generator(device="cpu").manual_seed(b * 1000 + h * 10 + wf)
+    rows = (torch.rand((b, h, wf, 16), generator=g) * 1.6 - 0.3).cuda(0)                 # spills over both ends of [0, 1]
+    ties = ((torch.arange(b * h * wf * 3, dtype=torch.float32).reshape(b, h, wf, 3) % 255) + 0.5) / 255.0      # k + 0.5 after the x 255 where fp32 allows it
+    packed = torch.cat([ties.cuda(0), torch.rand((b, h, wf, 1), generator=g).cuda(0) * 1.5 - 0.25], dim=3).contiguous()
+    im, face = rows[..., 0:3], rows[..., 15:16]
+    con, mask = packed[..., 0:3], packed[..., 3:4]
+    enc = StripEncoder(0)
+    lazy = enc.encode_figs([im, con, (mask, face, 2.0), mask])
+    assert lazy is not None
+    strips = Logging.strips_on_device([im, torch.clamp(con, 0, 1), mask * face * 2, mask])
+    want = enc.encode(strips)
+    torch.cuda.synchronize()
+    assert torch.equal(lazy, want)
+    assert np.array_equal(_decode(lazy[b - 1].cpu().numpy().tobytes()), strips[b - 1].cpu().numpy())
+    # a second call reuses the scratch (its accumulators are cleared by the call itself)
+    again = enc.encode_figs([im, con, (mask, face, 2.0), mask])
+    torch.cuda.synchronize()
+    assert torch.equal(again, want)
+    # layouts the kernel does not address go back to the caller
+    assert enc.encode_figs([im.permute(0, 2, 1, 3), con]) is None or h == wf
+    assert enc.encode_figs([im.double(), con]) is None
+    assert enc.encode_figs([rows[..., 0:2], con]) is None
