@@ -11,7 +11,7 @@ SOURCES = ["csrc/bsr_api.hip"]
 # the loaders' host-side helper (plain C, gcc, no GPU code: PNG scanline reconstruction for the worker processes) — its own small
 # library so that a worker can load it without bringing the HIP runtime in
 HOST_LIB_PATH = os.path.join(PKG_DIR, "libbsr_host.so")
-HOST_SOURCES = ["hostsrc/png_unfilter.c"]
+HOST_SOURCES = ["hostsrc/png_unfilter.c", "hostsrc/inflate.c"]
 
 
 def _deps():

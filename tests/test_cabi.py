@@ -112,7 +112,7 @@ def test_host_helper_library_exports_its_header():
         res = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr
     names = re.findall(r"\b(bsr_[a-z0-9_]+)\s*\(", open(hdr).read())
-    assert set(names) == {"bsr_png_unfilter", "bsr_host_source_sha"}
+    assert set(names) == {"bsr_png_unfilter", "bsr_inflate_zlib", "bsr_host_source_sha"}
     lib = ctypes.CDLL(build.build_host_library())
     for n in names:
         assert hasattr(lib, n), n
