@@ -15,6 +15,7 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import time
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -619,6 +620,7 @@ class FSRNet(object):
         gpu_png = on_gpu and self.log.gpu_png
         gpu_q: List[Tuple] = []             # submitted batches whose device-to-host copy may still be running, oldest first
         d2h = torch.cuda.Stream(device=self.gen._device) if on_gpu else None
+        post_stream = torch.cuda.Stream(device=self.gen._device) if on_gpu and os.environ.get("BSR_POST_SIDE", "1") != "0" else None
         turn = [0]
         # batches bound for a worker pool (PNG strips, UCB post-processing) are copied device -> a pinned SHARED-MEMORY slot the workers
         # read in place (_ShmPinnedRing); [ring | None, already tried]
@@ -745,13 +747,25 @@ class FSRNet(object):
                 # train_test_GSC.py:424-748 for the whole batch on the device; the seven figures leave as PNG files
                 from .prep import pack_masks, unpack_masks
                 packed = [pend_masks.pop(it[0], None) or pack_masks(mask_files[it[0]]) for it in items]      # a feed without masks: read here
-                boxes = torch.from_numpy(np.stack([np.asarray(it[3], np.float32).reshape(-1)[:4] for it in items])).to(dev, non_blocking=True)
-                losses_d, strips_d, figs_d, status_d = post_dev.run(torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3), unpack_masks(packed, dev), boxes,
-                                                                    want_figs=self.return_figs)
-                files_d = self.log.encode_strips(strips_d)
-                nfile = files_d.shape[1]
-                payload = torch.cat([losses_d.view(torch.uint8).reshape(-1), status_d.view(torch.uint8).reshape(-1), files_d.reshape(-1)])      # 12 bytes per item, then the files
-                host, ev, slot = to_host_async(payload, to_pool=False, pin_id=True)
+                # The post-processing runs on its OWN stream behind this batch's forward (BSR_POST_SIDE=0: on the compute stream): its
+                # per-item kernel is ONE workgroup per item — 16 of 256 CUs busy for 1.2 ms per batch of 16 (scratch/loop_trace.sh) — so
+                # the next batch's forward shares the chip with it instead of waiting behind it
+                side = post_stream is not None
+                if side:
+                    fwd_done = torch.cuda.Event()
+                    fwd_done.record()
+                    for t_ in (rows_d, con_rgb, mask_pred) + tuple(pk[1] for pk in packed if isinstance(pk[1], torch.Tensor)):
+                        t_.record_stream(post_stream)      # allocated on other streams, read by this one
+                with torch.cuda.stream(post_stream) if side else contextlib.nullcontext():
+                    if side:
+                        post_stream.wait_event(fwd_done)
+                    boxes = torch.from_numpy(np.stack([np.asarray(it[3], np.float32).reshape(-1)[:4] for it in items])).to(dev, non_blocking=True)
+                    losses_d, strips_d, figs_d, status_d = post_dev.run(torch.cat([im_d, gt_d, con_rgb, mask_pred], dim=3), unpack_masks(packed, dev), boxes,
+                                                                        want_figs=self.return_figs)
+                    files_d = self.log.encode_strips(strips_d)
+                    nfile = files_d.shape[1]
+                    payload = torch.cat([losses_d.view(torch.uint8).reshape(-1), status_d.view(torch.uint8).reshape(-1), files_d.reshape(-1)])      # 12 bytes per item, then the files
+                    host, ev, slot = to_host_async(payload, to_pool=False, pin_id=True)
                 figs_b = ("post_dev", nfile, figs_d)
             elif ucb and postprocess:
                 # train_test_GSC.py:424-748 runs on the host, one independent item per call: what it reads comes over in ONE copy
