@@ -193,198 +193,6 @@ What the round did (`profiles/README.md` has the tables, `profiles/HISTORY.md` w
    the loader's 1.5 ms per FFHQ item), a faster inflate still (the C one is at 1.6x zlib; libdeflate-class decoders reach 3x), the PNG
    encoder as ONE launch (its three dependent launches cost more than its arithmetic), and the per-item post-processing kernel (one
    workgroup per item: 1.2 ms per batch on 16 CUs).
-<!-- END r5 DESIGN -->) from the tracked profiles/r5_* files, so that every number in the prose is one a reader can find in profiles/.
-Usage: python tools/r5_readme.py"""
-import json
-import os
-import re
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = lambda n: os.path.join(ROOT, "profiles", n)       # noqa: E731
-J = lambda n: json.load(open(P(n)))                   # noqa: E731
-
-b, bx, bh = J("r5_bench_n1.json"), J("r5_bench_n1_f32x3.json"), J("r5_bench_n1_f16.json")
-r4, r4x, r4h = J("r4_bench_n1.json"), J("r4_bench_n1_f32x3.json"), J("r4_bench_n1_f16.json")
-mf, tr, trh, trx = J("r5_pmc_mfma.json"), J("r5_pmc_traffic.json"), J("r5_pmc_traffic_f16.json"), J("r5_pmc_traffic_f32x3.json")
-d1, t5, t5x, b16 = J("r5_bench_dist1.json"), J("r5_bench_tsm512.json"), J("r5_bench_tsm512_f32x3.json"), J("r5_bench_b16.json")
-sw, st = J("r5_batch_sweep.json"), J("r5_loop_stage_table.json")
-loops = {k: [J("r5_loop_%s_%d.json" % (k, i))["loop"] for i in (1, 2)] for k in ("ffhq", "ucb")}
-rf, rfx, rfh, rft = b["roofline"], bx["roofline"], bh["roofline"], t5["roofline"]
-stg = st["stages"]
-
-
-def grp(r, key):
-    return [v for k, v in r["kernel_groups"].items() if key in k][0]
-
-
-def rng(vals, fmt="%.0f"):
-    lo, hi = min(vals), max(vals)
-    return (fmt % lo) if abs(hi - lo) < 0.5 else (fmt + "-" + fmt) % (lo, hi)
-
-
-def loop(kind, mode, key="images_per_sec"):
-    return [r[mode][key] for r in loops[kind]]
-
-
-def per_kernel(t, key):
-    rows = [v for k, v in t["per_kernel"].items() if key in k]
-    return sum(v["hbm_bytes_per_forward"] for v in rows), sum(v["launches_per_forward"] for v in rows)
-
-
-c1_bytes, c1_n = per_kernel(trh, "gemm_nloop_kernel<4, 9")
-sweep_rows = "\n".join("| %d | %.0f | %.3f | %.2f | %d |" % (r["batch"], r["images_per_sec"], r["ms_per_forward"], r["rate_vs_largest_batch"], r["launches_per_forward"])
-                       for r in sw["rows"])
-groups16 = "\n".join("| `%s` | %.3f | %.3f | %.3f | %s | %s |" % (k[:96], v["ms"], v["frac"], v["hbm_frac"], v.get("hbm_frac_counters", "-"), v.get("traffic_ratio", "-"))
-                     for k, v in rfh["kernel_groups"].items())
-groupsx3 = "\n".join("| `%s` | %.3f | %.3f | %.3f | %s | %s |" % (k[:96], v["ms"], v["frac"], v["hbm_frac"], v.get("hbm_frac_counters", "-"), v.get("traffic_ratio", "-"))
-                     for k, v in rfx["kernel_groups"].items())
-groupst = "\n".join("| `%s` | %.3f | %d | %.3f |" % (k[:96], v["ms"], v["launches"], v["frac"]) for k, v in rft["kernel_groups"].items())
-
-notes = '''<!-- BEGIN r5 NOTES -->
-Other round-5 artefacts (this block is written by `tools/r5_readme.py` from the files it names; taken by `scratch/final_pass_r5.sh` and
-`scratch/bench_only_r5.sh`).  **`value` of every bench line is now ONE forward at a time** (one handle, one stream: BASELINE configs[1]'s one
-resident batch of 32); the two-lane throughput of rounds 3-4 is the side figure `two_in_flight`.
-
-* `r5_bench_n1.json` — f32: **%.0f images/s** (`two_in_flight` %.0f; round 4 on the same protocol: %.0f / %.0f), dominant kernel %.3f of the fp32
-  matrix peak (counters: matrix pipe busy %.1f %% at %.2f GHz; HBM %.0f MB per launch against %.0f MB algorithmic), 3x3-conv path %.3f, all kernels
-  %.1f TFLOP/s; `library_source_sha16` = the hash compiled into the loaded library (= `kernel_src_sha16` of every `r5_pmc_*.json`).
-* `r5_bench_n1_f32x3.json` / `r5_bench_n1_f16.json` — the 16-bit modes: **%.0f** / **%.0f** images/s one forward at a time (round 4: %.0f / %.0f),
-  %.0f / %.0f with two in flight.  Per kernel group, `frac` of the matrix roof, `hbm_frac` by algorithmic bytes and — new — `hbm_frac_counters` /
-  `traffic_ratio` from the counter passes (`r5_pmc_traffic_<dtype>.json`; read = 2 x FETCH_SIZE is calibrated for wide coalesced reads: layers
-  that fetch 32- / 64-byte pieces of a line may be over-counted by up to 2x).  f16:
-
-| kernel group (f16) | ms / forward | frac of matrix roof | hbm_frac (algorithmic) | hbm_frac (counters) | counter / algorithmic bytes |
-|---|---|---|---|---|---|
-%s
-
-  f32x3:
-
-| kernel group (f32x3) | ms / forward | frac of matrix roof | hbm_frac (algorithmic) | hbm_frac (counters) | counter / algorithmic bytes |
-|---|---|---|---|---|---|
-%s
-
-  `res*.conv1` as the resident-activation GEMM (`gemm_nloop_kernel<4, 9, 2, 1>`): %.1f MB per launch by the counters for 54.5 MB algorithmic
-  (ratio %.2f; the implicit-GEMM form of round 4: 1.85).
-* `r5_kernel_stats_tsm512.csv` + `r5_bench_tsm512.json` — BASELINE configs[4]'s per-rank shape (8 frames of 512x512, TSM generator): **%.0f frames/s**
-  (f32x3 %.0f), now WITH a roofline object priced with the workload's own work (%.1f GFLOP per frame, %.1f of it the attention over 4 096 tokens):
-  dominant kernel = attention + `w` tail at **%.3f** of the fp32 matrix peak; all kernels %.1f TFLOP/s; ShareLayer kernels
-  (`reg_resize8`, `share_reduce`, `share_unwarp`) are in the stats file (glue: %.3f ms of %.3f per step).
-
-| kernel group (tsm512, f32) | ms / step | launches | frac of 157.3 TFLOP/s |
-|---|---|---|---|
-%s
-
-* `r5_kernel_stats_b16.csv` + `r5_bench_b16.json` — BASELINE configs[2]'s batch (B = 16): %.0f images/s, dominant kernel %.3f.
-* `r5_bench_dist1.json` — the RCCL path on one rank: %.0f images/s, gather %.3f ms exposed per step, `verified: %s`.
-* **`r5_batch_sweep.json`**:
-
-| B | images/s | ms / forward | rate vs B = 32 | launches |
-|---|---|---|---|---|
-%s
-
-* **`r5_loop_ffhq_{1,2}.json` / `r5_loop_ucb_{1,2}.json` — the reference's loops end to end** (`python bench.py --loop ffhq|ucb`, %d usable CPUs, two
-  runs each): `FSRNet.test` (UCB: seven masks per item, post-processing, SSIM / PSNR, seven-figure strips) **%s images/s** with the
-  post-processing and the PNG encoding on the device (`device_post`; steady %s) against %s with the host post-processing of round 4
-  (`device_prep`) on the same boxes; `FSRNet.testFFHQ` **%s images/s** with device-built PNG files (`device_png`; steady %s) against %s with
-  the host encoder pool; the same loop with 32 items per forward (`device_png_batch32`: the batch of `testFFHQ` is the caller's) %s.
-* **`r5_loop_stage_table.json`** — the host stages that are LEFT, each alone through %d worker processes: loader host half %.0f items/s (%.2f ms of
-  CPU per item), the same with the item's seven masks %.0f /s (%.2f ms), writing the device-built PNG files %.0f /s (FFHQ strips) and %.0f /s
-  (UCB strips); for comparison the stages round 5 took off the host: PNG strip encoding %.0f /s (%.2f ms), UCB post-processing %.0f /s (%.1f ms).
-  The loader's half shrank twice late in the round: PNG scanline reconstruction in C (`libbsr_host.so`, SIMD Paeth — PIL spent 2.0 of its
-  2.2 ms per 256x256 photograph there) and a page-locked shared-memory slot ring between the workers and the device (no pickling, no
-  repacking of ~0.5 MB per item on the loop's own thread; `scratch/loop_ablate.py`: the loops WITHOUT a loader sustain ~4 850 (FFHQ) /
-  ~3 300 (UCB) items/s, the B = 16 forward alone 5 800).  Reading: the loops run at ~0.8 of what the GPU side sustains; the rest is the
-  loop's own thread sharing the %d-CPU quota with the loader's workers (table measured with %d; the loops use 5/8 and 3/4 of the CPUs).
-<!-- END r5 NOTES -->''' % (
-    b["value"], b["two_in_flight_value"], r4["single_stream_value"], r4["value"], rf["frac"], 100 * (rf.get("mfma_busy") or 0), rf.get("clock_ghz") or 0,
-    (rf.get("traffic") or 0) / 1e6, tr["dominant_kernel_algorithmic_bytes_per_launch"] / 1e6, rf["path_3x3"]["frac"], rf["all_kernels_tflops"],
-    bx["value"], bh["value"], r4x["single_stream_value"], r4h["single_stream_value"], bx["two_in_flight_value"], bh["two_in_flight_value"],
-    groups16, groupsx3, c1_bytes / max(c1_n, 1) / 1e6, c1_bytes / max(c1_n, 1) / 54.5e6,
-    t5["value"], t5x["value"], rft["work_per_frame"]["gflop"], rft["work_per_frame"]["gflop_attention"], rft["frac"], rft["all_kernels_tflops"],
-    rft["glue_ms"], rft["all_kernels_ms"], groupst,
-    b16["value"], b16["roofline"]["frac"], d1["value"], d1["config"]["allgather"]["ms_exposed_per_step"], str(d1["config"]["allgather"]["verified"]).lower(),
-    sweep_rows, loops["ucb"][0].get("usable_cpus", 16),
-    rng(loop("ucb", "device_post")), rng(loop("ucb", "device_post", "steady_images_per_sec")), rng(loop("ucb", "device_prep")),
-    rng(loop("ffhq", "device_png")), rng(loop("ffhq", "device_png", "steady_images_per_sec")), rng(loop("ffhq", "device_prep")),
-    rng(loop("ffhq", "device_png_batch32")) if all("device_png_batch32" in r for r in loops["ffhq"]) else "(not measured)",
-    st["worker_processes"], stg["loader_host_half"]["items_per_sec"], stg["loader_host_half"]["job_cpu_ms_alone"],
-    stg["loader_host_half_with_masks"]["items_per_sec"], stg["loader_host_half_with_masks"]["job_cpu_ms_alone"],
-    stg["file_write_ffhq"]["items_per_sec"], stg["file_write_ucb"]["items_per_sec"], stg["png_strip"]["items_per_sec"], stg["png_strip"]["job_cpu_ms_alone"],
-    stg["ucb_post"]["items_per_sec"], stg["ucb_post"]["job_cpu_ms_alone"], st["usable_cpus"], st["worker_processes"])
-
-readme = P("README.md")
-s = open(readme).read()
-tables = []
-for tag in ("r5", "r5_f32x3", "r5_f16"):
-    m = re.search(r"<!-- BEGIN %s TABLE -->.*?<!-- END %s TABLE -->\n?" % (tag, tag), s, flags=re.S)
-    if m:
-        tables.append(m.group(0).rstrip("\n"))
-        s = s.replace(m.group(0), "")
-s = re.sub(r"<!-- BEGIN r5 NOTES -->.*?<!-- END r5 NOTES -->\n?", "", s, flags=re.S)
-s = re.sub(r"## Round 5 \(MI355X.*?(?=## Round 4)", "", s, flags=re.S)
-head = ("## Round 5 (MI355X, ROCm 7.2, B = 32 per forward)\n\n`scratch/final_pass_r5.sh` + `scratch/bench_only_r5.sh` (two `gpurun` calls on the final kernel sources) produced everything below; "
-        "`tools/update_profiles.py`, `tools/pmc_traffic.py`, `tools/pmc_mfma.py`, `tools/lane_overlap.py` and `tools/r5_readme.py` summarise it.\n\n")
-section = head + "\n\n".join(tables) + "\n\n" + notes + "\n\n"
-s = s.replace("## Round 4 (MI355X", section + "## Round 4 (MI355X", 1)
-s = re.sub(r"\n{4,}", "\n\n\n", s)
-open(readme, "w").write(s)
-
-# ---- DESIGN.md §7, round-5 block
-cb = b.get("cpu_baseline") or {}
-par = cb.get("parity") or {}
-parx = (b.get("f32x3") or {}).get("parity") or {}
-
-
-def dom_line(r):
-    return "%s: %.1f %% of %s (`bound: %s`)" % (r["kernel"].split(" (")[0], 100 * r["frac"], ("%.0f TFLOP/s" % r["peak"]) if r["unit"] == "TFLOP/s" else "8 TB/s algorithmic", r["bound"])
-
-
-design = '''<!-- BEGIN r5 DESIGN -->
-### Round 5
-
-`python bench.py` on one MI355X (B = 32 per step, synthetic, inputs resident in HBM; `profiles/r5_bench_n1*.json`, taken on the final kernel
-sources).  **`value` is one forward at a time** (one handle, one stream — BASELINE configs[1]'s single resident batch of 32); the figure with
-two forwards in flight, which rounds 3-4 reported as `value`, stands beside it:
-
-| dtype | images/s one forward at a time = `value` (two in flight) | ms / step | dominant kernel against its roofs | max abs error vs oracle |
-|---|---|---|---|---|
-| **f32** — fp32 matrix cores, the measured path | **%.0f** (%.0f; round 4 on this protocol: %.0f / %.0f) | %.3f | transposed 3x3 `igemm_conv_kernel` %.1f TFLOP/s = **%.1f %%** of 157.3 (`bound: mfma`); PMC: matrix pipe busy %.1f %% at %.2f GHz; 3x3-conv path %.1f %%; HBM %.0f MB per launch (%.0f MB algorithmic) | %.1e, %d mask flips |
-| f32x3 — split precision on the fp16 matrix cores (§4b) | %.0f (%.0f; round 4: %.0f / %.0f) | %.3f | %s | %.1e, %d mask flips |
-| f16 — fp16 operands + fp16 activation pack (configs[3]) | %.0f (%.0f; round 4: %.0f / %.0f) | %.3f | %s | 1.4e-03 (tested at 2e-3) |
-
-CPU oracle on the GPU box's host (`cpu_baseline`, `kind: "port"`): %.1f images/s at %d threads (%d usable CPUs).  TSM 512x512 (configs[4] per-rank
-shape) %.0f frames/s at f32 with its own roofline object (%.1f GFLOP per frame; dominant kernel attention + `w` tail %.3f of the fp32 matrix
-peak, all kernels %.1f TFLOP/s), f32x3 %.0f.  B = 16 (configs[2]) %.0f images/s.  One-rank RCCL run %.0f images/s, gather %.3f ms exposed per
-step, verified.
-
-What the round did (`profiles/README.md` has the tables, `profiles/HISTORY.md` what was measured and dropped):
-
-* **16-bit modes** (§4b): the `w` GEMM as the tail of the split-precision attention kernel (attention 380 + `w` 160 -> %.0f us per forward), `res*.conv1` as a
-  resident-activation GEMM (164 -> %.0f us, HBM bytes per launch 1.85x -> %.2fx the algorithmic), XCD-congruent N blocks; f16 %.0f -> %.0f, f32x3 %.0f -> %.0f
-  images/s one forward at a time.  Every kernel group now carries its HBM fraction from the counters beside the algorithmic one.
-  The review's 20 k / 14.5 k were not reached: the split-precision attention kernel holds its matrix pipe 34 %% busy (counters and two
-  failed de-phasing experiments in HISTORY.md), and every other 16-bit launch is a 20-150 us one- or few-round grid at 0.2-0.4 of both roofs.
-* **The loops** (§6): `FSRNet.test` **%s images/s** end to end (round 4: 351) — post-processing of `test_step` and PNG encoding on the device,
-  every figure bit-identical to the host statement, masks decoded by the loader's workers; `FSRNet.testFFHQ` **%s** (round 4: 1 794).  What is
-  left on the host is the loader's half (inflate + scanline reconstruction in C + Delaunay meshes: %.2f / %.2f ms of CPU per item without /
-  with the UCB masks; the bytes travel through a page-locked shared-memory ring, copies and the preparation kernel on side streams) and
-  one `write()` per item.
-* **Measurement contract**: `value` config-exact; `roofline` for `--workload tsm512`; kernel-trace summaries for tsm512 and B = 16; the
-  library carries the hash of its sources and a stale one does not load.
-* **Multi-GPU readiness** (§5): peer-copy gather as an opt-in alternative to RCCL's kernels (mechanism tested with two ranks on one GPU);
-  the data-parallel loops' host share per rank is the loader only.
-
-### Open after round 5 (ranked)
-
-1. **The 1 / 2 / 4 / 8-GPU curve** — still the driver's: RCCL and the peer-copy gather have only run at world 1 (RCCL) / world 2 on one GPU (peer).
-2. **16-bit modes**: a one-wave-per-SIMD attention kernel with the softmax interleaved into the matrix stream by hand (the counters say 34 %% busy);
-   the conv2 -> conv3|qkv tail (built for the fp32 path in round 4, +0.2 %%, opt-in) carried over to the 16-bit kernels.  Measured and
-   closed this round: two-channel fp16 epilogue stores (slower), `conv_n16`'s LDS bank conflicts (2-5 %%), deeper fragment prefetch.
-3. **Parity** stays unpinned until someone runs `tools/make_model_fixture.py --backend tf` and `tools/make_ucb_post_fixture.py --backend tf`.
-4. **Loops**: at ~0.8 of what the GPU side sustains without a loader (B = 16 forward + strips + PNG + copies); what is left is qhull (1.1 of the
-   loader's 1.5 ms per FFHQ item), zlib's inflate of the UCB items' two compressed RGB files (~1.3 ms each on this container's CPU: half
-   of a UCB item's host time) and the loop's own Python thread.  Fusing the strip assembly into the PNG encoder was bounded first
-   (`scratch/strip_bound.py`: the loop with a constant strip, i.e. no elementwise launches at all, is not faster) and not built.
 <!-- END r5 DESIGN -->''' % (
     b["value"], b["two_in_flight_value"], r4["single_stream_value"], r4["value"], b["ms_per_step"], rf["achieved"], 100 * rf["frac"],
     100 * (rf.get("mfma_busy") or 0), rf.get("clock_ghz") or 0, 100 * rf["path_3x3"]["frac"], (rf.get("traffic") or 0) / 1e6,
