@@ -33,7 +33,7 @@ def loop_bench(kind: str, data_root: str, gen=None, items: int = 100, batch: int
     from .dataset import usable_cpus as _ucpu
     from .dist import rank_world
     rank, world = rank_world()
-    res = {"usable_cpus": _ucpu(), "rank": rank, "world": world, "loop": "FSRNet.test (UCB, batch %d, host post-processing + SSIM/PSNR)" % batch if ucb else "FSRNet.testFFHQ (batch %d)" % batch,
+    res = {"usable_cpus": _ucpu(), "rank": rank, "world": world, "loop": "FSRNet.test (UCB, batch %d, test_step's post-processing + SSIM/PSNR: on the host in the first three modes, on the device in device_post)" % batch if ucb else "FSRNet.testFFHQ (batch %d; device_png_batch32: %d)" % (batch, 2 * batch),
            "dtype": dtype}
     try:
         from .dataset import cpu_share
