@@ -245,19 +245,20 @@ int bsr_inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst, size_t ds
             else pair[i] = (e1 >> 16) | (l1 << 16) | (1u << 24);
         }
         for (;;) {                                              /* the symbols of one block */
-            refill(&b);
-            if (b.cnt < 56) return -2;
-            /* up to four look-ups of 11 bits from one refill, each worth one or two literals */
-            int fast = 1;
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t pr = pair[PEEK(&b, LROOT)];
-                if ((pr >> 24) == 0 || out + 2 > dst_len) { fast = 0; break; }
-                dst[out] = (uint8_t)pr;
-                dst[out + 1] = (uint8_t)(pr >> 8);                /* written even when it is not a symbol yet: the next symbol overwrites it */
-                out += pr >> 24;
-                DROP(&b, (pr >> 16) & 0xFF);
+            /* the literal loop: one branch-free refill (>= 56 bits), then up to four look-ups of 11 bits, each worth one or two literals
+             * written as one 16-bit store (the second byte is overwritten by the next symbol when it was not one yet) */
+            while (out + 10 <= dst_len && b.pos <= b.n + 8) {
+                uint64_t v;
+                memcpy(&v, b.src + b.pos, 8);
+                b.buf |= v << b.cnt;
+                b.pos += (size_t)((63 - b.cnt) >> 3);
+                b.cnt |= 56;
+                uint32_t pr;
+#define PAIR_STEP() pr = pair[b.buf & ((1u << LROOT) - 1u)]; if ((pr >> 24) == 0) break; \
+                    { const uint16_t two = (uint16_t)pr; memcpy(dst + out, &two, 2); } out += pr >> 24; b.buf >>= (pr >> 16) & 0xFF; b.cnt -= (int)((pr >> 16) & 0xFF)
+                PAIR_STEP(); PAIR_STEP(); PAIR_STEP(); PAIR_STEP();
+#undef PAIR_STEP
             }
-            if (fast) continue;
             refill(&b);                                         /* the look-ups above may have used 33 of the 56 bits */
             if (b.cnt < 56) return -2;
             uint32_t e = ltab[PEEK(&b, LROOT)];
