@@ -89,7 +89,7 @@ def _parse_8bit(b: bytes):
     n = h * (1 + w * c)
     lib = _HOST[0]
     if lib is not None:
-        # libbsr_host.so's inflate (hostsrc/inflate.c: 1.6x zlib's rate on photographs); it wants 16 readable bytes behind the stream and
+        # libbsr_host.so's inflate (hostsrc/inflate.c: 1.9x zlib's rate on photographs); it wants 16 readable bytes behind the stream and
         # 16 writable ones behind the output.  Whatever it refuses goes to zlib, whose verdict counts.
         z = b"".join(idat + [bytes(16)])
         raw = np.empty(n + 16, np.uint8)

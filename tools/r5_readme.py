@@ -190,7 +190,7 @@ What the round did (`profiles/README.md` has the tables, `profiles/HISTORY.md` w
 3. **Parity** stays unpinned until someone runs `tools/make_model_fixture.py --backend tf` and `tools/make_ucb_post_fixture.py --backend tf`.
 4. **Loops**: `testFFHQ` runs with its GPU 99 %% busy (`scratch/loop_trace.sh`: forward 2.74 of 3.1 ms per batch of 16; the strip
    assembly now happens inside the PNG encoder); `test` (UCB) waits about equally for its loader and for the GPU.  Left: qhull (1.1 of
-   the loader's 1.5 ms per FFHQ item), a faster inflate still (the C one is at 1.6x zlib; libdeflate-class decoders reach 3x), the PNG
+   the loader's 1.5 ms per FFHQ item), a faster inflate still (the C one is at 1.9x zlib; libdeflate-class decoders reach 3x), the PNG
    encoder as ONE launch (its three dependent launches cost more than its arithmetic), and the per-item post-processing kernel (one
    workgroup per item: 1.2 ms per batch on 16 CUs).
 <!-- END r5 DESIGN -->''' % (
