@@ -65,10 +65,8 @@ for _i in range(6):
 # Launches that compute SEVERAL reference layers (round 4: at full batches the `w` GEMM is the tail of the attention kernel): priced with
 # the sum of their parts; LAYER_MMAC stays the per-layer table of SURVEY Appendix C.
 FUSED_LAUNCHES = {"res%d.attw" % _i: ("res%d.attention" % _i, "res%d.w" % _i) for _i in range(6)}
-FUSED_LAUNCHES.update({"res%d.c2c3q" % _i: ("res%d.conv2" % _i, "res%d.c3q" % _i) for _i in range(6)})      # conv2 with conv3 | theta|phi|g as its tail
 for _i in range(6):
     LAYER_IO_ELEMS["res%d.attw" % _i] = _io(32, 384 + 288, 32, 264)          # qkv + y3x in, block output out (att never reaches HBM)
-    LAYER_IO_ELEMS["res%d.c2c3q" % _i] = _io(32, 128 + (99, 257, 257, 261, 261, 261)[_i], 32, 288 + 384)      # t1 + block input in, y3x + qkv out (t2 never reaches HBM)
 
 
 def launch_mmac(name):
@@ -138,7 +136,6 @@ def workload_tables(tsm, hw):
         n_out = 288 if tsm else 264                   # channels the `w` GEMM stores: the block output's stride (264), at most its 9 tiles
         io["res%d.w" % i] = (t * (128 + 288), t * n_out)
         io["res%d.attw" % i] = (t * (384 + 288), t * n_out)                          # qkv + y3x in, block output out (att never reaches HBM)
-        io["res%d.c2c3q" % i] = (t * (128 + min(cin, 288)), t * (288 + 384))        # t1 + block input in, y3x + qkv out (t2 never reaches HBM)
     return m, io, ex
 
 
@@ -161,7 +158,6 @@ KERNEL_GROUPS = {
     "igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=2,CC=32> (transposed 3x3: up2, up3, clr_up3)": ["up2", "up3", "clr_up3"],
     "igemm_conv_kernel<3,3,1,TR,...> other instantiations (up1, clr_up1, clr_up2)": ["up1", "clr_up1", "clr_up2"],
     "igemm_conv_kernel<3,3,1> (res*.conv2)": ["res%d.conv2" % i for i in range(6)],
-    "igemm_conv_kernel<3,3,1,..,WN=2,FUSE_TAIL> (res*.conv2 + conv3|theta|phi|g tail)": ["res%d.c2c3q" % i for i in range(6)],
     "igemm_conv_kernel<3,3,2> (down1-3)": ["down1", "down2", "down3"],
     "nonlocal_attention_kernel": ["res%d.attention" % i for i in range(6)],
     "nonlocal_attention_kernel<4, FUSEW> (res*.attention + res*.w tail)": ["res%d.attw" % i for i in range(6)],
@@ -182,13 +178,17 @@ def _free_port() -> int:
     return port
 
 
-def launch_ranks(n: int, argv, check_devices: bool) -> int:
+def launch_ranks(n: int, argv, check_devices: bool, one_device=None) -> int:
     """Start n rank processes of this script and relay rank 0's stdout.  Runs BEFORE this process touches the GPU
     (torch.cuda.device_count() does not initialise it); never exec()s."""
     if check_devices:
         import torch
         have = torch.cuda.device_count()
-        if have < n:
+        if one_device is not None:
+            if have <= one_device:
+                sys.stderr.write("bench.py: --device %d but only %d GPU(s) are visible\n" % (one_device, have))
+                return 2
+        elif have < n:
             sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible: refusing to fall back to fewer ranks\n" % (n, have))
             return 2
     port = _free_port()
@@ -392,8 +392,8 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
         label = gname
         if gpeak != PEAK_F32_MFMA_TFLOPS and "(res*.conv1)" in gname and B * 8 * 2 >= 256:
             label = "gemm_nloop_kernel<4,NCH,H=2,MINW=1> (res*.conv1)"      # round 5: the resident-activation GEMM at full batches (csrc/gemm_nloop.h)
-        elif gpeak != PEAK_F32_MFMA_TFLOPS:        # the 16-bit instantiations (csrc/igemm_h16.h, attention_x3.h, gemm_nloop / conv_n16 with H = 2)
-            label = (gname.replace("igemm_conv_kernel", "igemm_h16_kernel").replace("nonlocal_attention_kernel", "nonlocal_attention_x3_kernel")
+        elif gpeak != PEAK_F32_MFMA_TFLOPS:        # the 16-bit instantiations (csrc/igemm_h16.h, attention_h16.h, gemm_nloop / conv_n16 with H = 2)
+            label = (gname.replace("igemm_conv_kernel", "igemm_h16_kernel").replace("nonlocal_attention_kernel<4, FUSEW>", "nonlocal_attention_h16_kernel<FUSEW>").replace("nonlocal_attention_kernel", "nonlocal_attention_h16_kernel")
                      .replace("gemm_nloop_kernel", "gemm_nloop_kernel<..,H=2>").replace("conv_n16_kernel<", "conv_n16_kernel<H=2,")
                      .replace("stem7_kernel", "stem7_kernel<4,H=2>"))
         gbytes = 1e-9 * sum(layer_bytes(n, dtype) for n in layers) * B
@@ -411,8 +411,8 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
     dom_name = max(groups, key=lambda k: groups[k]["ms"])
     dom = groups[dom_name]
     peak = dom["peak"]
-    # the "3x3-conv path": every launch that computes a 3x3 layer.  A fused launch (res*.c2c3q = conv2 + the conv3 | theta|phi|g GEMM)
-    # cannot be split, so it enters with ALL its time and ALL its algorithmic work — the path's FLOPs grow by the GEMM's, never its rate
+    # the "3x3-conv path": every launch that computes a 3x3 layer.  A fused launch that contains one (none since the conv2 + GEMM-tail form
+    # was retired in round 6) cannot be split, so it would enter with ALL its time and ALL its algorithmic work
     t33 = sum(layer_ms.get(n, 0.0) for n in LAYERS_3X3)
     gflop33 = GFLOP_3X3_PER_IMAGE * B
     fused33 = [n for n, parts in FUSED_LAUNCHES.items() if n in layer_ms and any(p_ in LAYERS_3X3 for p_ in parts)]
@@ -445,6 +445,12 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
                        "note": ("%d of the launches are res*.conv2 fused with the conv3 | theta|phi|g GEMM: counted with their whole time and the GEMM's work "
                                 "(%.1f GFLOP beyond the path's %.1f)" % (len(fused33), gflop33 - GFLOP_3X3_PER_IMAGE * B, GFLOP_3X3_PER_IMAGE * B)) if fused33 else None},
           "all_kernels_tflops": round(GFLOP_PER_IMAGE * B / t_all, 2), "all_kernels_ms": round(t_all, 4),
+          "all_kernels_tflops_executed": round(2e-3 * sum(launch_mmac_executed(n) for n in layer_ms if n in LAYER_MMAC or n in FUSED_LAUNCHES) * B / t_all, 2),
+          "all_kernels_frac": (round(GFLOP_PER_IMAGE * B / t_all / PEAK_F32_MFMA_TFLOPS, 4) if dtype == "f32" else None),
+          "all_kernels_frac_executed": (round(2e-3 * sum(launch_mmac_executed(n) for n in layer_ms if n in LAYER_MMAC or n in FUSED_LAUNCHES) * B / t_all / PEAK_F32_MFMA_TFLOPS, 4)
+                                        if dtype == "f32" else None),
+          "all_kernels_note": ("whole forward, every launch incl. glue: `all_kernels_tflops` by the reference's op count (%.3f GFLOP per image), `_executed` by the "
+                               "matrix work the launches issue (conv3 and theta|phi|g are composed offline into one K = 128 GEMM: fewer MACs)" % GFLOP_PER_IMAGE),
           "kernel_groups": {k: {kk: vv for kk, vv in v.items() if kk != "gflop"} for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
           "glue_ms": round(glue_ms, 4)}
     return rf, dom_name
@@ -596,6 +602,60 @@ def attach_mfma(rf, dom_name, B, dtype):
                            "same kernel is in profiles/r3_clock_stamps.txt)" % (sfx, sha))
 
 
+def sustained_region(run_step, device_index, B, world, ms_per_step, warm_s=2.0, region_s=3.2):
+    """A timed region that lasts SECONDS (`value` is K steps = ~0.1 s: the reference times whole runs, train_test_GSC.py:852,860): >= warm_s
+    of back-to-back forwards untimed, then >= region_s timed, one forward at a time — with the clock the chip held during it, sampled from
+    INSIDE the chip by a one-wave kernel on a side stream (bsr_clock_trace: shader cycles against the 100-MHz real-time counter)."""
+    import torch
+    from blindshadowremoval_amd import _lib
+    lib = _lib.load()
+    n_warm = max(1, int(warm_s * 1e3 / ms_per_step) + 1)
+    n_reg = max(1, int(region_s * 1e3 / ms_per_step) + 1)
+    samples = int((warm_s + region_s) * 2.5e4) + 4096              # one pair per ~100 us, with slack: the kernel is stopped by the flag
+    dev = torch.device("cuda", device_index)
+    buf = torch.zeros(2 * samples, dtype=torch.int64, device=dev)
+    stop = torch.zeros(1, dtype=torch.int32, device=dev)
+    taken = torch.zeros(1, dtype=torch.int32, device=dev)
+    side, flag_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.bsr_clock_trace(device_index, buf.data_ptr(), samples, 30, stop.data_ptr(), taken.data_ptr(), side.cuda_stream), "bsr_clock_trace")
+    for i in range(n_warm):
+        run_step(i)
+    # the region is bracketed on the host like `value` (the stream is drained on both sides)
+    cur = torch.cuda.current_stream(dev)
+    cur.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_reg):
+        run_step(i)
+    cur.synchronize()
+    dt = time.perf_counter() - t0
+    with torch.cuda.stream(flag_stream):
+        stop.fill_(1)
+    flag_stream.synchronize()
+    side.synchronize()
+    n = int(taken.item())
+    tr = buf[:2 * n].cpu().view(n, 2).double()
+    clock = {"clock_ghz": None}
+    if n >= 64:
+        # the pairs that fall inside the timed region: the last dt seconds before the stop (100 MHz ticks)
+        ticks = tr[:, 1]
+        t_end = float(ticks[-1])
+        inside = (ticks >= t_end - dt * 1e8) & (ticks <= t_end)
+        seg = tr[inside]
+        if seg.shape[0] >= 32:
+            step_ = max(1, seg.shape[0] // 200)                     # ~200 intervals of >= 100 us
+            a, b_ = seg[:-step_:step_], seg[step_::step_]
+            ghz = ((b_[:, 0] - a[:, 0]) / (b_[:, 1] - a[:, 1]) * 0.1)
+            ghz = ghz[(b_[:, 1] - a[:, 1]) > 0]
+            g = sorted(float(x) for x in ghz)
+            clock = {"clock_ghz": round(g[len(g) // 2], 3), "clock_ghz_min": round(g[0], 3), "clock_ghz_max": round(g[-1], 3), "clock_intervals": len(g)}
+    res = {"value": round(world * B * n_reg / dt, 2), "unit": "images/sec", "seconds": round(dt, 3), "steps": n_reg, "warm_steps": n_warm,
+           "ms_per_step": round(dt / n_reg * 1e3, 4), "forwards_in_flight": 1,
+           "clock_source": "s_memtime / s_memrealtime pairs taken every ~100 us by a one-wave kernel on a side stream during the region (bsr_clock_trace)"}
+    res.update(clock)
+    return res
+
+
 def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_parity, lanes=None):
     """The same workload on the split-precision path, reported BESIDE the f32 line (never as `value`): per-GPU images/s of this
     rank, its own roofline object, and (N = 1) its parity against the oracle under the fp32 tolerances."""
@@ -628,8 +688,9 @@ def secondary_f32x3(weights, device, inp, uv, out, B, args, world, timed, with_p
     res = {"dtype": "f32x3", "value": round(B * args.steps / dt_serial, 2), "unit": "images/sec (this GPU, no collective)", "ms_per_step": round(dt_serial / args.steps * 1e3, 4),
            "steps": args.steps, "forwards_in_flight": 1, "value_mode": "one forward at a time",
            "two_in_flight": ({"value": round(B * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4)} if two else None), "roofline": rf,
-           "note": "3x3 / stride-2 / transposed 3x3 layers on v_mfma_f32_32x32x16_f16 with operands split into hi + lo fp16 planes at LDS staging "
-                   "(three instructions per K group, fp32 accumulate); every other kernel is the fp32 one; activations stay fp32 in HBM"}
+           "note": "EVERY matrix kernel of the forward runs on v_mfma_f32_32x32x16_f16 with both operands split into hi + lo fp16 planes (three "
+                   "instructions per K group: hi.hi + hi.lo + lo.hi, fp32 accumulate) — stem, 3x3 / stride-2 / transposed 3x3, the 1x1 GEMMs, "
+                   "attention, heads, colour tail; activations stay fp32 in HBM (theta|phi|g travel pre-split), glue kernels are the fp32 ones"}
     if with_parity:
         from oracle.gsc_oracle import GeneratorOracle
         torch.manual_seed(0)
@@ -684,6 +745,8 @@ def run_rank(args):
         raise SystemExit("bench.py: WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     on_gpu = not args.stub
     distributed = world > 1 or os.environ.get("BSR_BENCH_FORCE_DIST") == "1"      # the latter exercises the collective path on one rank
+    if args.device is not None:
+        local_rank = args.device                        # every rank on the same GPU (gloo control plane, peer-copy gather)
     if on_gpu:
         if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
             raise SystemExit("bench.py: rank %d has no GPU %d (visible: %d)" % (rank, local_rank, torch.cuda.device_count()))
@@ -710,6 +773,8 @@ def run_rank(args):
     def sync():
         if on_gpu:
             torch.cuda.synchronize()
+
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where the scalar reductions of the timing live (gloo: host tensors)
 
     B = args.batch
     tsm = args.workload == "tsm512"
@@ -821,7 +886,7 @@ def run_rank(args):
         own = time.perf_counter() - t0
         mx = own
         if distributed:
-            t = torch.tensor([own], device=dev, dtype=torch.float64)
+            t = torch.tensor([own], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             mx = float(t.item())
         return mx, own
@@ -836,6 +901,15 @@ def run_rank(args):
     elapsed, own = timed(args.steps, serial)                # THE timed region: exactly K steps
     reps = [elapsed] + [timed(args.steps, serial)[0] for _ in range(max(0, args.repeats - 1))]
     extra = {}
+    sustained = None
+    if on_gpu and not args.no_sustained:
+        sustained = sustained_region(serial if not distributed else (lambda i: step(i, gather=False, lane=0)), local_rank, B, 1, elapsed / args.steps * 1e3)
+        drain()
+        if distributed:                                 # every rank ran its own region: report the slowest rank's rate times the world
+            t = torch.tensor([sustained["value"]], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            sustained["value"] = round(float(t.item()) * world, 2)
+            sustained["note_dist"] = "no collective inside this region; value = world x the slowest rank's rate"
     if nlanes > 1:                                      # side measurement: consecutive steps alternate between two handles on two HIP streams
         for i in range(max(2, args.warmup)):
             step(i)
@@ -896,16 +970,20 @@ def run_rank(args):
             cfg["workload"] = ("BASELINE configs[4] per-rank shape: TSM generator (model_with_TSM.py), %d frames of 512x512 per GPU per step, "
                                "frame=2 groups, seeded random-init weights in the ckpt-110 variable layout" % B)
         elif args.dtype == "f32":
-            cfg["workload"] = ("BASELINE configs[1]: batch=32 synthetic 256x256x3 per GPU, full GSC generator fp32 "
-                               "(seeded random-init weights in the ckpt-94 variable layout)")
+            which = ("BASELINE configs[1]: batch=32" if B == 32 else "BASELINE configs[2]'s batch on synthetic images (forward only): batch=16" if B == 16
+                     else "BASELINE configs[1] shape at another batch: batch=%d" % B)
+            cfg["workload"] = ("%s synthetic 256x256x3 per GPU, full GSC generator fp32 (seeded random-init weights in the ckpt-94 variable layout)" % which)
         elif args.dtype == "f32x3":
-            cfg["workload"] = ("BASELINE configs[1] shape (batch=32 synthetic 256x256x3 per GPU, full GSC generator) with the 3x3-conv path on the fp16 matrix "
-                               "cores in split precision (hi.hi + hi.lo + lo.hi, fp32 accumulate, fp32 activations): fp32-class accuracy, NOT the headline dtype")
+            cfg["workload"] = ("BASELINE configs[1] shape (batch=%d synthetic 256x256x3 per GPU, full GSC generator) with every matrix kernel on the fp16 matrix "
+                               "cores in split precision (hi.hi + hi.lo + lo.hi, fp32 accumulate, fp32 activations): fp32-class accuracy, NOT the headline dtype" % B)
         else:
-            cfg["workload"] = ("BASELINE configs[3]: batch=32 synthetic 256x256x3 per GPU, fp16 MFMA (fp32 accumulate/storage) on the "
-                               "3x3-conv path, fp32 elsewhere; NOT the headline configuration")
+            cfg["workload"] = ("BASELINE configs[3] per-rank shape: batch=%d synthetic 256x256x3 per GPU, fp16 MFMA conv path (single-fp16 operands and fp16 "
+                               "activations on the 3x3-conv layers, split precision elsewhere, fp32 accumulate); NOT the headline configuration" % B)
         two = extra.pop("two_in_flight", None)
         cfg.update(extra)
+        if args.device is not None:
+            cfg["all_ranks_on_device"] = args.device
+            cfg["parallelism"] = "dp%d on ONE GPU (--device %d): the N > 1 step logic with the real generator; the ranks share a chip, `value` is not a scaling figure" % (world, args.device)
         result = {
             "metric": "images/sec at 256x256 batch inference (GSC generator forward)" if not tsm else "images/sec at 512x512 (TSM generator forward)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -915,6 +993,11 @@ def run_rank(args):
                         "ms_per_step_all": [round(r, 4) for r in rs], "note": "`value` is the FIRST timed region of exactly K steps; the others repeat it"},
         }
         result["value_mode"] = "one forward at a time"
+        if sustained is not None:
+            sustained["vs_value"] = round(sustained["value"] / result["value"], 4)
+            sustained["note"] = ("the same step repeated for seconds after seconds of warm-up: `value` is %d steps (%.0f ms) on a chip that may still be "
+                                 "settling its clock; a ratio under 0.98 means the short region flattered the rate" % (args.steps, elapsed * 1e3))
+            result["sustained"] = sustained
         result["single_stream_value"] = result["value"]            # the key rounds 3-4 carried the serial figure under: now `value` itself
         if two is not None:
             result["two_in_flight_value"] = two["value"]
@@ -987,6 +1070,7 @@ def parse_args(argv=None):
                     help="f32 = the measured path (BASELINE configs[1], fp32 matrix cores); f32x3 = split-precision fp32 on the fp16 matrix cores "
                          "(3x3-conv path; fp32-class accuracy); f16 = fp16 operands on the 3x3-conv path (configs[3])")
     ap.add_argument("--no-secondary", action="store_true", help="skip the f32x3 side measurement the default f32 run appends")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the seconds-long `sustained` region (and its clock trace)")
     ap.add_argument("--workload", choices=("gsc256", "tsm512"), default="gsc256",
                     help="gsc256 = BASELINE configs[1]/[3]; tsm512 = the per-rank shape of configs[4] (TSM generator, 512x512 frames)")
     ap.add_argument("--streams", type=int, choices=(1, 2), default=2,
@@ -998,15 +1082,22 @@ def parse_args(argv=None):
                     help="N>1: how the outputs are re-assembled on every rank.  rccl = one asynchronous all_gather_into_tensor per step (RCCL kernels over "
                          "xGMI); peer = full-mesh direct peer-to-peer copies of the shard into every rank's buffer (copy engines, no compute units; "
                          "blindshadowremoval_amd/peer_gather.py) — the fallback should RCCL's kernels contend with the forward's one-round launches")
-    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo only with --stub (CPU test of the rank logic)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: with --stub (CPU test of the rank logic), or with --device (all ranks on one GPU)")
+    ap.add_argument("--device", type=int, default=None,
+                    help="run ALL ranks on this one GPU (implies --backend gloo --gather peer): the N > 1 step — packed forward, double-buffered gather, "
+                         "verification — with the REAL generator where only one GPU exists; the rate it prints is N forwards sharing a chip, not a scaling figure")
     ap.add_argument("--stub", action="store_true", help="CPU stand-in generator: tests the launcher / sharding / JSON contract, measures nothing")
     ap.add_argument("--loop", choices=("ffhq", "ucb"), default=None,
                     help="also time the end-to-end FSRNet.testFFHQ / FSRNet.test loop (host prep + H2D + forward + post + PNG) on the shipped fixtures")
     args = ap.parse_args(argv)
     if args.batch is None:
         args.batch = 8 if args.workload == "tsm512" else 32
-    if args.backend == "gloo" and not args.stub:
-        ap.error("--backend gloo needs --stub: the product path has no CPU fallback")
+    if args.device is not None:
+        if args.stub:
+            ap.error("--device runs the real generator: not with --stub")
+        args.backend, args.gather = "gloo", "peer"      # RCCL cannot place two ranks on one device; the peer-copy gather can
+    if args.backend == "gloo" and not args.stub and args.device is None:
+        ap.error("--backend gloo needs --stub (the product path has no CPU fallback) or --device (all ranks on one GPU)")
     if args.stub and args.backend != "gloo":
         ap.error("--stub runs on CPU: pass --backend gloo")
     if args.gpus < 1:
@@ -1019,7 +1110,7 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launcher: nothing in this process has touched (or will touch) the GPU
-        sys.exit(launch_ranks(args.gpus, argv, check_devices=not args.stub))
+        sys.exit(launch_ranks(args.gpus, argv, check_devices=not args.stub, one_device=args.device))
     return run_rank(args)
 
 

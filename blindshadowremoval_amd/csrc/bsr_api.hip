@@ -14,13 +14,12 @@
 #include <vector>
 
 #include "attention.h"
-#include "attention_x3.h"
+#include "attention_h16.h"
 #include "conv_n16.h"
 #include "gemm_nloop.h"
 #include "glue_kernels.h"
 #include "igemm_conv.h"
 #include "igemm_h16.h"
-#include "igemm_s2p.h"
 #include "png_kernels.h"
 #include "prep_kernels.h"
 #include "stem7.h"
@@ -151,13 +150,8 @@ struct bsr_handle {
   // outside the fp16 range stores 1 to it (over PCIe, only when it happens).  Sticky until bsr_check_range().
   unsigned* range_flag = nullptr;
   bool fuse_heads = true;        // env BSR_FUSE_HEADS=0: always the two-launch heads (A/B measurements, bit-identity tests)
-  bool s2_persist = false;       // env BSR_S2_PERSIST=1: down1 / down2 on the persistent stride-2 kernel (igemm_s2p.h) — see profiles/HISTORY.md
-  bool tail_stagger = true;      // env BSR_TAIL_STAGGER=0: both wave groups of a fused GEMM tail walk their channel groups in the same order
-  bool fuse_c3q = false;         // env BSR_FUSE_C3Q=1: res*.conv2 with the conv3 | theta|phi|g GEMM as its tail (one launch).  Built, bit-identical, and
-                                 // OFF: one forward at a time it is 0.2 % faster, with two forwards in flight 0.8 % slower (its 150-KB, 8-wave workgroups
-                                 // leave the other lane's kernels no room on the CU) — profiles/HISTORY.md, round 4
-  bool conv1_gemm_f32 = false;   // env BSR_CONV1_GEMM=2: also on the fp32 path (measured: no gain)
   bool conv1_gemm = true;        // env BSR_CONV1_GEMM=0: res*.conv1 of the 16-bit modes on the implicit-GEMM kernel at every batch (A/B measurements, bit-identity tests)
+  bool att_pv1 = false;          // env BSR_ATT_PV1=1 (f16 mode only): P.V of the attention with the hi planes only (one matrix instruction per product)
   bool fuse_attw = true;         // env BSR_FUSE_ATTW=0: attention and the `w` GEMM as two launches (A/B measurements, bit-identity tests)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
@@ -267,10 +261,7 @@ struct Launcher {
     constexpr bool kTrunk = !TR && S == 1 && NI == 2 && (CC == 32 || (k11 && CC == 24));
     bool half_tile = false;
     if constexpr (kTrunk) half_tile = !h16 && mh % 2 == 0 && (long long)(mh / 4) * (mw / 32) * h->B * nb < bsr::device_cu_count();
-    constexpr bool kS2 = k33 && S == 2 && !TR && NI == 2 && CC == 16 && INB == 1;      // down1 / down2
-    if (kS2 && !h16 && h->s2_persist && (a.nchunk & 1) == 0) {
-      if constexpr (kS2) check(bsr::launch_igemm_s2p<2>(a, h->B, s), name);          // persistent workgroups with next-tile prefetch (igemm_s2p.h)
-    } else if (half_tile) {
+    if (half_tile) {
       if constexpr (kTrunk) check(bsr::launch_igemm_conv<KH, KW, S, TR, 2, 32, 2, 2, 1, 1, CC, INB>(a, h->B, s), name);
     } else if (!h16)
       check(bsr::launch_igemm_conv<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CC, INB>(a, h->B, s), name);
@@ -282,27 +273,6 @@ struct Launcher {
       else if (io == 1) check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1, 1>(a, h->B, s), name);
       else check(bsr::launch_igemm_h16<KH, KW, S, TR, 4, 32, 4, 1, 1, NI, CCH, INB, 1, 0>(a, h->B, s), name);
     }
-    end();
-  }
-  // res*.conv2 (3x3, 128 -> 128, + BN + LeakyReLU) with the conv3 | theta|phi|g GEMM (K = 128, N = 288 + 384, + the block skip) as its tail:
-  // one 8-wave workgroup per 4x32-pixel tile computes all 128 channels and runs the GEMM on them (igemm_conv.h FUSE_TAIL, gemm_tail.h)
-  void conv2_c3q(const char* name, const char* conv_name, const char* gemm_name, const float* in, int H, int W, float* y3, float* qkv,
-                 const float* x, int x_cs) {
-    if (rc != BSR_OK) return;
-    LayerW lc, lg;
-    rc = find_layer(h, conv_name, 4, 9, 36, 128, &lc);
-    if (rc == BSR_OK) rc = find_layer(h, gemm_name, 4, 1, 36, bsr::ConvTailCfg::BIAS_FLOATS, &lg);
-    if (rc != BSR_OK) return;
-    bsr::ConvArgs a{};
-    a.in = in; a.in_cs = 128; a.in_coff = 0; a.H = H; a.W = W; a.out = nullptr; a.out_cs = 128; a.out_coff = 0; a.Ho = H; a.Wo = W;
-    a.w = lc.w; a.bias = lc.b; a.nchunk = lc.nchunk; a.n_pad = lc.n_pad; a.n_store = 128; a.pad_t = 1; a.pad_l = 1; a.act = 1;
-    bsr::GemmTailArgs t{};
-    t.w = lg.w; t.bias = lg.b; t.n_pad = lg.n_pad;
-    t.res = x; t.res_cs = x_cs; t.res_c = x_cs < 288 ? x_cs : 288;
-    t.out = y3; t.out_cs = CS_Y3X; t.n_store1 = CS_Y3X;
-    t.out2 = qkv; t.out2_cs = 384; t.n_split = 288; t.n_store = 288 + 384; t.act = 0; t.stagger = h->tail_stagger ? 1 : 0;
-    begin(K_CONV3, name);
-    check(bsr::launch_igemm_conv<3, 3, 1, false, 4, 32, 4, 2, 1, 2, 32, 1, true>(a, h->B, s, &t), name);
     end();
   }
   // 1x1 conv as a resident-activation GEMM (K = NCH*32) over all N
@@ -332,6 +302,7 @@ struct Launcher {
     a.res1 = res1; a.res1_cs = res1_cs; a.res1_c = res1_c;
     a.out2 = out2; a.out2_cs = out2_cs; a.n_split = n_split; a.n_store1 = n_store1;
     a.range_flag = h->range_flag;
+    a.out2_split = (h->dtype != BSR_DTYPE_F32 && out2 != nullptr) ? 1 : 0;      // conv3 | theta|phi|g of the 16-bit modes: qkv in the split layout of attention_h16.h
     begin(cls, name);
     if (h->dtype == BSR_DTYPE_F32)
       check(bsr::launch_gemm_nloop<NI, NCH, 0>(a, pixels, kNSplit, s), name);
@@ -437,7 +408,7 @@ int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
 
 extern "C" {
 
-int bsr_abi_version(void) { return 6; }
+int bsr_abi_version(void) { return 7; }
 
 #ifndef BSR_SRC_SHA
 #define BSR_SRC_SHA "unhashed"
@@ -473,10 +444,8 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   h->dtype = dtype;
   if (const char* e_ = getenv("BSR_FUSE_HEADS")) h->fuse_heads = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_FUSE_ATTW")) h->fuse_attw = atoi(e_) != 0;
-  if (const char* e_ = getenv("BSR_CONV1_GEMM")) { h->conv1_gemm = atoi(e_) != 0; h->conv1_gemm_f32 = atoi(e_) == 2; }
-  if (const char* e_ = getenv("BSR_FUSE_C3Q")) h->fuse_c3q = atoi(e_) != 0;
-  if (const char* e_ = getenv("BSR_TAIL_STAGGER")) h->tail_stagger = atoi(e_) != 0;
-  if (const char* e_ = getenv("BSR_S2_PERSIST")) h->s2_persist = atoi(e_) != 0;
+  if (const char* e_ = getenv("BSR_ATT_PV1")) h->att_pv1 = atoi(e_) != 0 && dtype == BSR_DTYPE_F16;
+  if (const char* e_ = getenv("BSR_CONV1_GEMM")) h->conv1_gemm = atoi(e_) != 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -700,15 +669,11 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
   // implicit-GEMM kernels (igemm_h16_kernel<1,1,1,..,NSPLIT = 2> / igemm_conv_kernel<1,1,1,..,CC = 24>): the same bits
   auto conv1_gemm = [&](const char* nm, const float* x, int x_cs) -> bool {
     if (V.tsm || !h->conv1_gemm || L.rc != BSR_OK) return false;
-    // fp32 (opt-in, BSR_CONV1_GEMM=2): the same kernel over the layer's 24-channel chunks (K = 120 | 264), the same bits as
-    // igemm_conv_kernel<1,1,1,..,CC = 24> — built, bit-identical, and NOT faster (27.4 vs 27.1 us per launch: with fp32 matrix
-    // instructions one wave per SIMD has nobody to fill its LDS / wait slots; profiles/HISTORY.md round 5): off
-    const bool f32 = h->dtype == BSR_DTYPE_F32;
-    if (f32 && !h->conv1_gemm_f32) return false;
+    if (h->dtype == BSR_DTYPE_F32) return false;      // fp32: the implicit-GEMM kernel (the resident form over 24-channel chunks was built and is no faster: profiles/HISTORY.md round 5)
     if (ncell % 128 != 0 || (long long)(ncell / 128) * 2 < bsr::device_cu_count()) return false;
-    if (f32 ? (x_cs != 120 && x_cs != 264) : (x_cs != 128 && x_cs != 288)) return false;
+    if (x_cs != 128 && x_cs != 288) return false;
     LayerW l;
-    L.rc = f32 ? find_layer(h, nm, x_cs / 24, 1, 28, 128, &l) : find_layer(h, nm, x_cs / 32, 1, 36, 128, &l);
+    L.rc = find_layer(h, nm, x_cs / 32, 1, 36, 128, &l);
     if (L.rc != BSR_OK) return true;
     bsr::ConvArgs a{};
     a.in = x; a.in_cs = x_cs; a.in_coff = 0; a.out = ws + p.t1; a.out_cs = 128; a.out_coff = 0;
@@ -716,9 +681,7 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     a.range_flag = h->range_flag;
     L.begin(K_CONV1, nm);
     if (x_cs == 128) L.check(bsr::launch_gemm_nloop<4, 4, 2, 1>(a, ncell, 1, s), nm);
-    else if (x_cs == 288) L.check(bsr::launch_gemm_nloop<4, 9, 2, 1>(a, ncell, 1, s), nm);
-    else if (x_cs == 120) L.check((bsr::launch_gemm_nloop<4, 5, 0, 1, 24>(a, ncell, 1, s)), nm);
-    else L.check((bsr::launch_gemm_nloop<4, 11, 0, 1, 24>(a, ncell, 1, s)), nm);
+    else L.check(bsr::launch_gemm_nloop<4, 9, 2, 1>(a, ncell, 1, s), nm);
     L.end();
     return true;
   };
@@ -734,55 +697,48 @@ static int forward_impl(bsr_handle* h, const float* inputs, const float* uv, con
     // conv3+BN (128 -> 257 = y3) and theta|phi|g (257 -> 3x128, no activation in between: model.py:101,33-46) are ONE
     // K = 128 GEMM: the qkv weights are composed offline with conv3's (pack.py), N = [y3 288 | qkv 384].  The y3 output also absorbs
     // the block's skip: y3x = y3 + pad(x), so that the `w` GEMM below reads ONE residual.
-    // Opt-in (BSR_FUSE_C3Q=1; fp32, full batches): conv2 and that GEMM as ONE launch — the conv2 tile goes through LDS, never to HBM
-    // (igemm_conv.h FUSE_TAIL).  Same bits either way; see the note at bsr_handle::fuse_c3q for why it is off.
-    const bool fuse_c3q = h->dtype == BSR_DTYPE_F32 && h->fuse_c3q && H8 % 4 == 0 && W8 % 32 == 0 &&
-                          (long long)(H8 / 4) * (W8 / 32) * B >= bsr::device_cu_count();
-    if (fuse_c3q) {
-      char nc[32], ng[32];
-      snprintf(nm, sizeof nm, "res%d.c2c3q", i);
-      snprintf(nc, sizeof nc, "res%d.conv2", i);
-      snprintf(ng, sizeof ng, "res%d.c3q", i);
-      L.conv2_c3q(nm, nc, ng, ws + p.t1, H8, W8, y3, ws + p.qkv, x, x_cs);
-    } else {
-      snprintf(nm, sizeof nm, "res%d.conv2", i);
-      L.conv<3, 3, 1, false, 2, 32, 1>(K_CONV3, nm, ws + p.t1, 128, 0, 128, H8, W8, ws + p.t2, 128, 0, 128, 1);
-      snprintf(nm, sizeof nm, "res%d.c3q", i);
-      L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
-    }
+    // (The two as ONE launch — the conv2 tile through LDS into a GEMM tail — was built in round 4, bit-identical and no faster: profiles/HISTORY.md;
+    // sources at git e99927a.)
+    snprintf(nm, sizeof nm, "res%d.conv2", i);
+    L.conv<3, 3, 1, false, 2, 32, 1>(K_CONV3, nm, ws + p.t1, 128, 0, 128, H8, W8, ws + p.t2, 128, 0, 128, 1);
+    snprintf(nm, sizeof nm, "res%d.c3q", i);
+    L.gemm<3, 4>(K_CONV1, nm, ws + p.t2, 128, ncell, y3, CS_Y3X, 288 + 384, 0, x, x_cs, x_cs < 288 ? x_cs : 288, ws + p.qkv, 384, 288, CS_Y3X);
     // z = y3 + BN(w(att)); out = LeakyReLU(pad(x) + pad(z))  (model.py:56-59, 105-113) = LeakyReLU(y3x + BN(w(att))).
     // ONE launch — the `w` GEMM runs as the tail of the attention kernel on the workgroup's own 128 pixels (attention.h /
-    // attention_x3.h, FUSEW; the attention output never goes to HBM).  fp32 small batches (the 4- / 2-wave attention shapes) keep the
+    // attention_h16.h, FUSEW; the attention output never goes to HBM).  fp32 small batches (the 4- / 2-wave attention shapes) keep the
     // two launches; both forms give the same bits (tests/test_gpu_parity.py).
-    // 16-bit modes (round 5): the same fusion on the split-precision kernels (attention_x3.h FUSEW + gemm_tail_run<.., H = 2>), at every batch
-    // (that kernel has one workgroup shape).
-    const bool fuse_w = h->fuse_attw && (h->dtype != BSR_DTYPE_F32 || bsr::attention_auto_qw(B, H8 * W8) == 4);
+    // 16-bit modes: the one-wave-per-SIMD kernel of attention_h16.h (round 6), whose normalised O^T accumulators are the tail's A operand, at
+    // every batch (that kernel has one workgroup shape).
+    const bool h16 = h->dtype != BSR_DTYPE_F32;
+    const bool fuse_w = h->fuse_attw && (h16 || bsr::attention_auto_qw(B, H8 * W8) == 4);
     h->att_in_lds = fuse_w;
     if (fuse_w && L.rc == BSR_OK) {
       LayerW l;
-      snprintf(nm, sizeof nm, "res%d.w", i);
-      L.rc = find_layer(h, nm, 4, 1, 36, 12 * 32, &l);
+      // fp32: the [4][1][n_pad][36] image gemm_tail.h streams through its ring; 16-bit modes (round 6): the `w4` image of
+      // attention_h16.h — nine 16-KB tiles in the k order of the O^T accumulators, resident in LDS when the key loop ends
+      snprintf(nm, sizeof nm, h16 ? "res%d.w4" : "res%d.w", i);
+      L.rc = h16 ? find_layer(h, nm, 9, 1, 128, 32, &l) : find_layer(h, nm, 4, 1, 36, 12 * 32, &l);
       if (L.rc == BSR_OK) {
         bsr::AttWArgs wa{};
-        wa.w = l.w; wa.bias = l.b; wa.n_pad = l.n_pad;
+        wa.w = l.w; wa.bias = l.b; wa.n_pad = h16 ? 288 : l.n_pad;
         wa.res = y3; wa.res_cs = CS_Y3X; wa.res_c = CS_Y3X;
-        wa.out = r_out; wa.out_cs = o_cs; wa.n_store = o_cs < 288 ? o_cs : 288; wa.n_store1 = wa.n_store; wa.act = 1; wa.stagger = h->tail_stagger ? 1 : 0;
+        wa.out = r_out; wa.out_cs = o_cs; wa.n_store = o_cs < 288 ? o_cs : 288; wa.n_store1 = wa.n_store; wa.act = 1; wa.stagger = 1;
         snprintf(nm, sizeof nm, "res%d.attw", i);
         L.begin(K_ATT, nm);
-        if (h->dtype == BSR_DTYPE_F32)
+        if (!h16)
           L.check(bsr::launch_nonlocal_attention_w(ws + p.qkv, B, H8 * W8, wa, s), "attention+w");
         else
-          L.check(bsr::launch_nonlocal_attention_x3_w(ws + p.qkv, B, H8 * W8, wa, s, h->range_flag), "attention_x3+w");
+          L.check(bsr::launch_nonlocal_attention_h16_w(ws + p.qkv, B, H8 * W8, wa, s, h->att_pv1), "attention_h16+w");
         L.end();
       }
     } else {
       if (L.rc == BSR_OK) {
         snprintf(nm, sizeof nm, "res%d.attention", i);
         L.begin(K_ATT, nm);
-        if (h->dtype == BSR_DTYPE_F32)
+        if (!h16)
           L.check(bsr::launch_nonlocal_attention(ws + p.qkv, ws + p.att[i], B, H8 * W8, s), "attention");
         else
-          L.check(bsr::launch_nonlocal_attention_x3(ws + p.qkv, ws + p.att[i], B, H8 * W8, s, h->range_flag), "attention_x3");
+          L.check(bsr::launch_nonlocal_attention_h16(ws + p.qkv, ws + p.att[i], B, H8 * W8, s, h->att_pv1), "attention_h16");
         L.end();
       }
       snprintf(nm, sizeof nm, "res%d.w", i);
@@ -937,15 +893,50 @@ int bsr_ucb_post(int device, const float* rows10, const unsigned char* masks, co
   return BSR_OK;
 }
 
+int bsr_clock_trace(int device, unsigned long long* out, int samples, int spin, const int* stop, int* taken, void* stream) {
+  if (out == nullptr || stop == nullptr || taken == nullptr || samples <= 0 || spin < 0) return fail(BSR_ERR_ARG, "bsr_clock_trace: bad argument");
+  DeviceGuard guard(device);
+  HIP_TRY(guard.err);
+  hipLaunchKernelGGL(bsr::clock_trace_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out, samples, spin, stop, taken);
+  HIP_TRY(hipGetLastError());
+  return BSR_OK;
+}
+
+int bsr_debug_split_qkv(const float* qkv, void* qkv_split, int B, int tokens, void* stream) {
+  if (qkv == nullptr || qkv_split == nullptr || B <= 0 || tokens <= 0) return fail(BSR_ERR_ARG, "bsr_debug_split_qkv: bad argument");
+  const size_t pairs = (size_t)B * tokens * 192;
+  hipLaunchKernelGGL(bsr::a4_split_qkv_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), qkv,
+                     static_cast<char*>(qkv_split), pairs);
+  HIP_TRY(hipGetLastError());
+  return BSR_OK;
+}
+
+int bsr_debug_attention_split(const void* qkv_split, float* y, int B, int tokens, int pv1, void* stream) {
+  if (qkv_split == nullptr || y == nullptr) return fail(BSR_ERR_ARG, "bsr_debug_attention_split: null argument");
+  if (B <= 0 || tokens <= 0 || tokens % 128 != 0) return fail(BSR_ERR_ARG, "bsr_debug_attention_split: tokens must be a positive multiple of 128");
+  HIP_TRY(bsr::launch_nonlocal_attention_h16(static_cast<const float*>(qkv_split), y, B, tokens, static_cast<hipStream_t>(stream), pv1 != 0));
+  return BSR_OK;
+}
+
 int bsr_debug_attention_dtype(const float* qkv, float* y, int B, int tokens, int dtype, void* stream) {
   if (qkv == nullptr || y == nullptr) return fail(BSR_ERR_ARG, "bsr_debug_attention: null argument");
   if (B <= 0 || tokens <= 0 || tokens % 128 != 0) return fail(BSR_ERR_ARG, "bsr_debug_attention: tokens must be a positive multiple of 128");
-  if (dtype == BSR_DTYPE_F32)
+  if (dtype == BSR_DTYPE_F32) {
     HIP_TRY(bsr::launch_nonlocal_attention(qkv, y, B, tokens, static_cast<hipStream_t>(stream)));
-  else if (dtype == BSR_DTYPE_F32X3 || dtype == BSR_DTYPE_F16)
-    HIP_TRY(bsr::launch_nonlocal_attention_x3(qkv, y, B, tokens, static_cast<hipStream_t>(stream)));
-  else
+  } else if (dtype == BSR_DTYPE_F32X3 || dtype == BSR_DTYPE_F16) {
+    // the kernel of the 16-bit modes reads theta|phi|g as their producer leaves them (split into fp16 planes: attention_h16.h); this
+    // hook splits a scratch copy first (allocated and freed here: a test hook, not a hot path)
+    void* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)B * tokens * bsr::kA4TokBytes));
+    int rc = bsr_debug_split_qkv(qkv, tmp, B, tokens, stream);
+    if (rc == BSR_OK) rc = bsr_debug_attention_split(tmp, y, B, tokens, 0, stream);
+    hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    hipFree(tmp);
+    if (rc != BSR_OK) return rc;
+    HIP_TRY(e);
+  } else {
     return fail(BSR_ERR_ARG, "bsr_debug_attention: unknown dtype");
+  }
   return BSR_OK;
 }
 

@@ -250,6 +250,34 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
         for (int i = 0; i < 16; ++i) v[i] += r1[i];
       }
       leaky_relu_tile(v, act_alpha);
+      if constexpr (H == 2) {
+        if (second && p.out2_split) {
+          // theta | phi | g for attention_h16.h: the operand split happens HERE, once per value, instead of in every query block's key loop.
+          // Channel c of group g3 (0 theta, 1 phi, 2 g) -> halves at byte g3 * 512 + 2c (hi) and + 256 (lo) of the pixel's 1536-byte
+          // record; theta is pre-scaled by log2 e (the kernel's softmax is base 2), in fp32, before the split — the same values the
+          // attention kernel of rounds 2-5 computed from the fp32 buffer.  The range guard of what is converted moves here with it.
+          const int n2 = nt - p.n_split;                            // multiple of 32, uniform
+          const float pre = n2 < 128 ? 1.4426950408889634f : 1.f;
+          const unsigned vb2 = n_ok ? ((unsigned)(4 * h) * 1536u + (unsigned)r * 2u) : kLaneOff;
+          unsigned so = (unsigned)((n2 >> 7) * 512 + (n2 & 127) * 2);
+          float amax = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float x = v[4 * q + j] * pre;
+              amax = __builtin_fmaxf(__builtin_fabsf(x), amax);
+              const _Float16 xh = (_Float16)x;
+              const _Float16 xl = (_Float16)(x - (float)xh);
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, xh), rsrc_out2, vb2 + (unsigned)j * 1536u, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, xl), rsrc_out2, vb2 + (unsigned)j * 1536u + 256u, so, 0);
+            }
+            so += 8u * 1536u;
+          }
+          range_report(amax, p.range_flag);
+          continue;
+        }
+      }
       const unsigned vb = n_ok ? (second ? lane_out2 : lane_out) : kLaneOff;
       const unsigned cs4 = (second ? (unsigned)p.out2_cs : (unsigned)p.out_cs) * 4u;
       const unsigned vj[4] = {vb, vb + cs4, vb + 2u * cs4, vb + 3u * cs4};

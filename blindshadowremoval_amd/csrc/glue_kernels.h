@@ -202,4 +202,20 @@ __global__ void slice_copy_kernel(const float* __restrict__ src, int cs, int cof
   dst[gid] = src_is_f16 ? (float)reinterpret_cast<const _Float16*>(src)[pix * cs + coff + ch] : src[pix * cs + coff + ch];
 }
 
+// The clock the chip holds while something else runs (bench.py `sustained.clock_ghz`): ONE wave on a side stream samples the shader-cycle
+// counter and the constant 100-MHz real-time counter every `spin` x ~3.4 us until `stop` becomes non-zero (or `samples` are taken); the
+// host turns consecutive pairs into GHz = d(cycles) / d(ticks) x 0.1.  One wave on one CU: it takes nothing measurable from the forwards
+// it runs beside (MI355X_MICROARCH.md, DVFS: the clock under a matrix-dense load is well under the 2.4 GHz the idle chip shows).
+__global__ void clock_trace_kernel(unsigned long long* __restrict__ out, int samples, int spin, const int* stop, int* taken) {
+  if (threadIdx.x != 0) return;
+  int i = 0;
+  for (; i < samples; ++i) {
+    out[2 * i] = __builtin_amdgcn_s_memtime();
+    out[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+    if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ++i; break; }
+    for (int k = 0; k < spin; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+  *taken = i;
+}
+
 }  // namespace bsr

@@ -25,7 +25,6 @@
 #include <stdint.h>
 
 #include "mfma_common.h"
-#include "gemm_tail.h"
 
 
 namespace bsr {
@@ -72,17 +71,9 @@ struct ConvCfg {
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
-// FUSE_TAIL (round 4; the 8-wave 3x3 shape WM = 4, WN = 2, NI = 2: one workgroup = a 4x32-pixel tile x ALL 128 output channels):
-// the layer's output tile does not go to HBM — after bias + LeakyReLU it is written to LDS and becomes the activation tile of a
-// K = 128 GEMM that runs as the tail of this kernel (gemm_tail.h).  res*.conv2 followed by conv3 | theta|phi|g
-// (/root/reference/model.py:85-86,100-101,10-13) is ONE launch that way.
-typedef GemmTailCfg<11, 10> ConvTailCfg;                       // N = 288 + 384 = 21 channel tiles: wave group 0 takes [0, 11), group 1 [11, 21)
-
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, bool FUSE_TAIL = false>
-__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p, GemmTailArgs ta) {
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
-  static_assert(!FUSE_TAIL || (!TR && S == 1 && WM == 4 && WN == 2 && MI == 1 && NI == 2 && TH == 4 && TW == 32),
-                "the fused GEMM tail needs the whole 128-pixel x 128-channel tile in one 8-wave workgroup");
   constexpr bool PAIR = C::PAIR;
   constexpr int NT = C::NT;
   constexpr int T = C::T, IW = C::IW, LDP = C::LDP, BN = C::BN, NPH = C::NPH, G = C::G;
@@ -101,9 +92,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p,
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // tells the compiler the wave index is uniform: SGPR address math
   const int h = lane >> 5, r = lane & 31;
-  // FUSE_TAIL: waves w and w + 4 share a SIMD; giving them DIFFERENT channel halves (wn) puts them into different wave groups of the
-  // GEMM tail, whose schedules are staggered against each other (gemm_tail.h)
-  const int wm = FUSE_TAIL ? wave % WM : wave / WN, wn = FUSE_TAIL ? wave / WM : wave % WN;
+  const int wm = wave / WN, wn = wave % WN;
 
   int bid = blockIdx.x;
   const int tile_x = bid % p.tiles_x;
@@ -407,28 +396,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p,
 #ifdef BSR_STAMPS
   st2 = __builtin_amdgcn_s_memtime();
 #endif
-  if constexpr (FUSE_TAIL) {
-    // The main loop's last barrier has passed: every LDS byte of this kernel is dead.  Request the tail's first weight images, park
-    // the activation tile (bias is already in the accumulators; LeakyReLU here) as [pixel][128 + 4], and run the GEMM on it.
-    float* s_a = smem;
-    float* s_ring = smem + kTailAFloats;
-    float* s_bias = s_ring + 3 * kTailSlot;
-    GemmTailState<11, 10> tail;
-    gemm_tail_prefetch(tail, ta, s_bias, tid);
-    const float alpha = p.act ? kLeakyAlpha : 1.f;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      f32x16 v = acc[0][0][ni];
-      leaky_relu_tile(v, alpha);
-      float* col = s_a + (wm * 32 + 4 * h) * kTailLdA + (wn * NI + ni) * 32 + r;      // register i = pixel (i & 3) + 8 (i >> 2) + 4 h of the wave's row, channel r of tile ni
-#pragma unroll
-      for (int i = 0; i < 16; ++i) col[((i & 3) + 8 * (i >> 2)) * kTailLdA] = v[i];
-    }
-    __builtin_amdgcn_s_setprio(0);
-    const size_t row_pix = (size_t)img * p.Ho * p.Wo + (size_t)(y0 + wm) * p.Wo + x0;      // the wave's 32 consecutive output pixels
-    gemm_tail_run(tail, ta, s_a, s_ring, s_bias, wn, wm, row_pix, lane);
-    return;
-  }
   // ---- epilogue: bias (+ residuals) + LeakyReLU, NHWC store (32 consecutive channels per half-wave) ----
   // With TW == 32 a wave's 32 pixels are one tile row, so every element address is a wave-uniform base plus a
   // 32-bit lane offset plus a compile-time multiple of the pixel stride: no 64-bit per-element arithmetic.
@@ -492,13 +459,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_conv_kernel(ConvArgs p,
 #endif
 }
 
-template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB, bool FUSE_TAIL = false>
-inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream, const GemmTailArgs* tail = nullptr) {
+template <int KH, int KW, int S, bool TR, int TH, int TW, int WM, int WN, int MI, int NI, int CC, int INB>
+inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream) {
   using C = ConvCfg<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
-  auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB, FUSE_TAIL>;
-  constexpr int kSmem = FUSE_TAIL && ConvTailCfg::SMEM_FLOATS * 4 > C::SMEM_BYTES ? ConvTailCfg::SMEM_FLOATS * 4 : C::SMEM_BYTES;
-  static_assert(kSmem <= 160 * 1024, "LDS budget");
-  if (FUSE_TAIL && (tail == nullptr || a.n_store != C::BN || tail->n_pad * 32 < ConvTailCfg::BIAS_FLOATS * 32 || tail->n_store > 21 * 32)) return hipErrorInvalidValue;
+  auto kern = igemm_conv_kernel<KH, KW, S, TR, TH, TW, WM, WN, MI, NI, CC, INB>;
+  constexpr int kSmem = C::SMEM_BYTES;
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (kSmem > 48 * 1024 && (dev < 0 || !once.done[dev])) {
@@ -510,7 +475,7 @@ inline hipError_t launch_igemm_conv(ConvArgs a, int batch, hipStream_t stream, c
   a.tiles_x = mw / TW;
   a.tiles_y = mh / TH;
   dim3 grid(a.tiles_x * a.tiles_y * batch, (a.n_store + C::BN - 1) / C::BN);
-  hipLaunchKernelGGL(kern, grid, dim3(C::NT), kSmem, stream, a, tail != nullptr ? *tail : GemmTailArgs{});
+  hipLaunchKernelGGL(kern, grid, dim3(C::NT), kSmem, stream, a);
   return hipGetLastError();
 }
 

@@ -152,6 +152,7 @@ struct ConvArgs {
   int tiles_x, tiles_y; // M tiles per image
   int n_blocks;         // igemm_h16_kernel: > 0 = 1-D grid with the N block as the FASTEST index (the N blocks of a tile share its input through L2)
   unsigned* range_flag; // 16-bit kernels: set to 1 when a staged activation does not fit fp16 (|x| >= 65520); may be null
+  int out2_split;       // gemm_nloop_kernel<.., H = 2>: out2 is the SPLIT qkv buffer of attention_h16.h — per pixel 3 x [128 hi halves | 128 lo halves], theta x log2 e
 #ifdef BSR_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [block][wave][4] s_memtime stamps
   unsigned long long* stamps3;  // diagnostic build only: where the prologue's cycles go, [block][wave][6] = entry, addresses set up, loads issued, loads landed + LDS written, barrier passed, accumulators + first fragments ready

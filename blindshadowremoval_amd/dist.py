@@ -107,41 +107,65 @@ class ShardedGenerator:
         return old
 
     def submit(self, inputs: torch.Tensor, uv: torch.Tensor, want_gs_mask22: bool = False) -> _Ticket:
-        """inputs / uv: the GLOBAL batch (the same tensors on every rank).  Runs the local shard and starts the gather(s)."""
-        n = inputs.shape[0]
-        bounds = shard_bounds(n, self.world)
+        """inputs / uv: the GLOBAL batch (the same tensors on every rank).  Runs the local shard and starts the gather(s).  Every rank
+        pays for the whole batch's host-to-device traffic this way: a loader that produces only its rank's rows uses `submit_shard`."""
+        bounds = shard_bounds(inputs.shape[0], self.world)
         lo, hi = bounds[self.rank]
-        counts = [b - a for a, b in bounds]
-        cmax = max(counts)
+        return self._submit_rows(inputs[lo:hi], uv[lo:hi], [b - a for a, b in bounds], want_gs_mask22)
+
+    def submit_shard(self, inputs: torch.Tensor, uv: torch.Tensor, global_n: Optional[int] = None, want_gs_mask22: bool = False) -> _Ticket:
+        """inputs / uv: THIS RANK'S rows only — rows `shard_bounds(global_n, world)[rank]` of the global batch (what a per-rank loader, e.g.
+        `Dataset.shard`, hands over: 1 / world of `submit`'s input traffic per rank; the reference's loop feeds one device the whole batch,
+        /root/reference/train_test_GSC.py:854-858).  `global_n`: the global row count when every rank knows it (the split must then be
+        `shard_bounds`'); None = the ranks exchange their row counts first (one small object all-gather; any split, empty shards included).
+        The result is the same global tensors `submit` gives, in rank order."""
+        if global_n is not None:
+            bounds = shard_bounds(global_n, self.world)
+            counts = [b - a for a, b in bounds]
+            if inputs.shape[0] != counts[self.rank]:
+                raise ValueError("submit_shard: rank %d holds %d rows, shard_bounds(%d, %d) gives it %d" % (self.rank, inputs.shape[0], global_n, self.world, counts[self.rank]))
+        elif self.world > 1:
+            counts = [None] * self.world
+            dist.all_gather_object(counts, int(inputs.shape[0]), group=self.group)
+        else:
+            counts = [int(inputs.shape[0])]
+        if uv.shape[0] != inputs.shape[0]:
+            raise ValueError("submit_shard: inputs and uv differ in their row count")
+        return self._submit_rows(inputs, uv, counts, want_gs_mask22)
+
+    def _submit_rows(self, x: torch.Tensor, u: torch.Tensor, counts: List[int], want_gs_mask22: bool) -> _Ticket:
+        """x / u: this rank's rows (counts[rank] of them; may be none); counts: every rank's row count."""
+        rows = counts[self.rank]
+        cmax = max(max(counts), 1)
         slot = self._turn
         self._turn ^= 1
         old = self._pending[slot]
         if old is not None and not old.done:            # the buffers of two submissions ago: free once their gather completed
             self._wait(old)
-        H, W = inputs.shape[1], inputs.shape[2]
-        pay = self._payload[slot] = self._buf(self._payload[slot], (cmax, H, W, 4), inputs)
+        H, W = x.shape[1], x.shape[2]
+        pay = self._payload[slot] = self._buf(self._payload[slot], (cmax, H, W, 4), x)
         pay2 = None
         if want_gs_mask22:
-            pay2 = self._payload2[slot] = self._buf(self._payload2[slot], (cmax, H, W, 4), inputs)
-        if hi > lo:
-            x, u = inputs[lo:hi].contiguous(), uv[lo:hi].contiguous()
+            pay2 = self._payload2[slot] = self._buf(self._payload2[slot], (cmax, H, W, 4), x)
+        if rows > 0:
+            x, u = x.contiguous(), u.contiguous()
             if self.packed:
-                gs, _, mask22, _ = self.gen(x, u, packed_out=pay[:hi - lo])
+                gs, _, mask22, _ = self.gen(x, u, packed_out=pay[:rows])
             else:
                 gs, con_rgb, mask22, dif = self.gen(x, u)
-                torch.cat([con_rgb, dif], dim=3, out=pay[:hi - lo])
+                torch.cat([con_rgb, dif], dim=3, out=pay[:rows])
             if pay2 is not None:
-                torch.cat([gs, mask22], dim=3, out=pay2[:hi - lo])
-        if hi - lo < cmax:                              # ragged split: the pad rows travel as zeros
-            pay[hi - lo:].zero_()
+                torch.cat([gs, mask22], dim=3, out=pay2[:rows])
+        if rows < cmax:                                 # ragged split: the pad rows travel as zeros
+            pay[rows:].zero_()
             if pay2 is not None:
-                pay2[hi - lo:].zero_()
+                pay2[rows:].zero_()
         work = work2 = None
         if self.world > 1:
-            g = self._gathered[slot] = self._buf(self._gathered[slot], (self.world * cmax, H, W, 4), inputs)
+            g = self._gathered[slot] = self._buf(self._gathered[slot], (self.world * cmax, H, W, 4), x)
             work = dist.all_gather_into_tensor(g, pay, group=self.group, async_op=True)
             if pay2 is not None:
-                g2 = self._gathered2[slot] = self._buf(self._gathered2[slot], (self.world * cmax, H, W, 4), inputs)
+                g2 = self._gathered2[slot] = self._buf(self._gathered2[slot], (self.world * cmax, H, W, 4), x)
                 work2 = dist.all_gather_into_tensor(g2, pay2, group=self.group, async_op=True)
         t = _Ticket(slot, counts, cmax, work, work2, pay2 is not None)
         self._pending[slot] = t

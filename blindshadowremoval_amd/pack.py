@@ -123,6 +123,34 @@ def pack_taps_h16(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int,
     return arr, b
 
 
+def pack_w4(kernel_tkn: np.ndarray, bias: np.ndarray):
+    """The NonLocalBlock's `w` conv ([1, 128, N <= 288] folded) as the LDS image of the attention kernel's fused tail
+    (csrc/attention_h16.h): 9 tiles of 32 output channels, row n = 512 bytes = 16 chunks of 8 halves hi | 16 chunks lo.  Chunk
+    c = 4 dt + 2 p + h holds k = 32 dt + 16 p + 4 h + (j & 3) + 8 (j >> 2), j = 0..7 — the order in which registers 8p .. 8p + 7 of the
+    O^T accumulator tile dt present the attention output as the A operand — and sits at chunk position c ^ (n & 15) (conflict-free
+    ds_read_b128 over 16 different rows; the image goes to LDS by DMA as it lies).  Returns ([9, 1, 32, 128] float32 words, [288] bias)."""
+    taps, k, n = kernel_tkn.shape
+    assert taps == 1 and k == 128 and n <= 288
+    full = np.zeros((128, 288), np.float64)
+    full[:, :n] = kernel_tkn[0].astype(np.float32)
+    hi = full.astype(np.float16)
+    if not np.all(np.isfinite(hi)):
+        raise ValueError("a folded weight exceeds the fp16 range (65504): this layer cannot run in the 16-bit modes")
+    lo = (full - hi.astype(np.float64)).astype(np.float16)
+    korder = np.array([[32 * dt + 16 * p + 4 * h + (j & 3) + 8 * (j >> 2) for j in range(8)]
+                       for dt in range(4) for p in range(2) for h in range(2)])                      # [16 chunks, 8]
+    img = np.zeros((288, 32, 8), np.float16)
+    for row in range(288):
+        sw = row & 15
+        for c in range(16):
+            img[row, c ^ sw] = hi[korder[c], row]
+            img[row, 16 + (c ^ sw)] = lo[korder[c], row]
+    arr = np.ascontiguousarray(img.reshape(9, 1, 32, 256)).view(np.float32)                          # [9, 1, 32, 128] words
+    b = np.zeros(288, np.float32)
+    b[:n] = bias
+    return arr, b
+
+
 def layer_matrices(w: Dict[str, np.ndarray]) -> "Dict[str, Tuple[np.ndarray, np.ndarray]]":
     """Folded [taps, K, N] kernels + biases (float64) of every MFMA layer, in kernel K/N order."""
     out: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
@@ -201,6 +229,10 @@ def pack_generator(weights: Dict[str, np.ndarray], dtype: str = "f32") -> bytes:
             arr, bias = pack_taps(k, b, cc, k_pad, n_pad)
         entries.append((name + ".w", arr, tuple(arr.shape)))
         entries.append((name + ".b", bias, (n_pad, 0, 0, 0)))
+        if dtype != "f32" and name.startswith("res") and name.endswith(".w"):
+            arr4, bias4 = pack_w4(k, b)
+            entries.append((name + "4.w", arr4, tuple(arr4.shape)))
+            entries.append((name + "4.b", bias4, (288, 0, 0, 0)))
     entries.append(("heads.bias", np.array([weights["conv2/conv/bias"][0], weights["conv3/conv/bias"][0]], np.float32), (2, 0, 0, 0)))
     entries.append(("clr_conv1.gs", clr_gs_weights(weights), (16, 16, 0, 0)))
     entries.append(("tail.w", tail_weights(weights), (323, 0, 0, 0)))

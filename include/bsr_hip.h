@@ -174,9 +174,21 @@ int bsr_debug_attention(const float* qkv, float* y, int B, int tokens, void* str
 /* The same with the kernel of a given BSR_DTYPE_*: F32 = fp32 matrix cores; F32X3 / F16 = the split-precision kernel (attention is
  * split-precision in both 16-bit modes). */
 int bsr_debug_attention_dtype(const float* qkv, float* y, int B, int tokens, int dtype, void* stream);
+/* The two steps of the F32X3 / F16 case above, separately (ABI 7): the kernel of the 16-bit modes (csrc/attention_h16.h) reads theta | phi | g
+ * as the conv3|theta|phi|g GEMM leaves them in those modes — per token 3 x [128 fp16 hi | 128 fp16 lo] (1536 bytes, hi = fp16(x),
+ * lo = fp16(x - hi), theta pre-scaled by log2 e).  bsr_debug_split_qkv converts an fp32 [B,tokens,384] tensor to that layout (same size
+ * in bytes), bsr_debug_attention_split runs the attention kernel on it; pv1 != 0 = the P.V product with the hi planes only. */
+int bsr_debug_split_qkv(const float* qkv, void* qkv_split, int B, int tokens, void* stream);
+int bsr_debug_attention_split(const void* qkv_split, float* y, int B, int tokens, int pv1, void* stream);
 /* The fp32 kernel with a given workgroup shape: qw = query waves per workgroup (4 = 128 queries, 2 = 64, 1 = 32; 0 = what the
  * forward picks for this batch: the largest block that still gives every CU a workgroup).  All shapes give bit-identical outputs. */
 int bsr_debug_attention_qw(const float* qkv, float* y, int B, int tokens, int qw, void* stream);
+
+/* Measurement hook (ABI 7): one wave on `stream` writes (shader cycle counter, 100-MHz real-time counter) pairs to out[2 * samples] every
+ * spin x ~3.4 us until *stop (device memory, written from another stream) is non-zero or `samples` pairs are taken; *taken receives the
+ * count.  GHz over an interval = d(cycles) / d(ticks) x 0.1.  bench.py runs it beside its `sustained` region: the clock the chip holds
+ * under the forward's load, from inside the chip. */
+int bsr_clock_trace(int device, unsigned long long* out, int samples, int spin, const int* stop, int* taken, void* stream);
 
 void bsr_destroy(bsr_handle* h);
 

@@ -53,6 +53,10 @@ def test_world_size_mismatch_is_rejected():
 def test_stub_needs_gloo_and_gloo_needs_stub():
     assert _run(["--backend", "gloo"]).returncode != 0
     assert _run(["--stub"]).returncode != 0
+    r = _run(["--gpus", "2", "--device", "0", "--stub", "--backend", "gloo"])          # --device runs the real generator
+    assert r.returncode != 0 and "not with --stub" in r.stderr
+    r = _run(["--gpus", "2", "--device", "0"])                                         # no GPU here: the launcher says so before starting ranks
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
 
 
 def test_roofline_tables_are_consistent():

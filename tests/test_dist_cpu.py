@@ -67,9 +67,22 @@ def _worker(rank, world, port, n, q):
         t3 = sg.submit(inp, uv, want_gs_mask22=True)
         r3 = sg.result(t3)
         ok = ok and all(torch.equal(a, b) for a, b in zip(r3, (want_rgb, want_dif, want_gs, want_m22)))
+        # the per-rank-shard form: every rank hands over ITS rows only (a per-rank loader) — the same global result; with the global row
+        # count known, and with the ranks exchanging their counts (any split: here rank 0 takes all but one row)
+        lo, hi = shard_bounds(n, world)[rank]
+        r4 = sg.result(sg.submit_shard(inp[lo:hi], uv[lo:hi], global_n=n, want_gs_mask22=True))
+        ok = ok and all(torch.equal(a, b) for a, b in zip(r4, (want_rgb, want_dif, want_gs, want_m22)))
+        cut = max(n - 1, 0)
+        mine = slice(0, cut) if rank == 0 else slice(cut, n)
+        r5 = sg.result(sg.submit_shard(inp[mine], uv[mine]))
+        ok = ok and torch.equal(r5[0], want_rgb) and torch.equal(r5[1], want_dif)
+        try:
+            sg.submit_shard(inp[:0] if hi > lo else inp[:1], uv[:0] if hi > lo else uv[:1], global_n=n)
+            ok = False
+        except ValueError:
+            pass
         # async ragged gather
         counts = [hi - lo for lo, hi in shard_bounds(n, world)]
-        lo, hi = shard_bounds(n, world)[rank]
         finish, work = all_gather_rows(inp[lo:hi], counts, async_op=True)
         ok = ok and torch.equal(finish(), inp)
         q.put((rank, bool(ok)))

@@ -53,7 +53,7 @@ def test_library_is_the_in_tree_hip_extension():
     from blindshadowremoval_amd import _lib
     from blindshadowremoval_amd.build import LIB_PATH
     lib = _lib.load()
-    assert lib._name == LIB_PATH and lib.bsr_abi_version() == _lib.ABI_VERSION == 6
+    assert lib._name == LIB_PATH and lib.bsr_abi_version() == _lib.ABI_VERSION == 7
 
 
 @pytest.mark.parametrize("seed,B", [(0, 2), (7, 3)])
@@ -172,7 +172,7 @@ def test_full_batch_properties(gen_w):
 def test_attention_kernel_forced_rescale(dtype_code):
     """Online-softmax rescale branch (cdna guide rule 26): spike late keys so the running max jumps in the
     last tiles; compare with an fp64 softmax on the full tensor.  dtype_code 0 = the fp32 matrix-core kernel (attention.h),
-    2 = the split-precision fp16 matrix-core kernel of the f32x3 / f16 modes (attention_x3.h) — same tolerance."""
+    2 = the split-precision fp16 matrix-core kernel of the f32x3 / f16 modes (attention_h16.h, fed through bsr_debug_split_qkv) — same tolerance."""
     from blindshadowremoval_amd import _lib
     lib = _lib.load()
     torch.manual_seed(2)
@@ -682,6 +682,35 @@ def test_peer_gather_world2_on_one_gpu_and_in_bench():
     assert ag["verified"] is True and ag["form"].startswith("peer") and ag["bytes_per_rank"] == 33554432 and j["value"] > 0
 
 
+def test_bench_gpus2_real_generator_on_one_gpu():
+    """Round 6: `bench.py --gpus 2 --device 0` — the N > 1 step of the headline bench with the REAL generator where only one GPU exists: two
+    rank processes (started by bench.py itself, before anything touches the GPU) share GPU 0, gloo is the control plane, every step is
+    bsr_forward_packed -> the double-buffered peer-copy gather of con_rgb | dif into every rank's IPC-mapped buffer -> the next step's
+    forward beside it; at the end every rank checks its own shard bit for bit and the other rank's by checksum (`allgather.verified`).
+    The rate it prints is two forwards sharing a chip, not a scaling figure: the line says so.  (The reference's loop is single-device:
+    /root/reference/train_test_GSC.py:854-858.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BSR_BENCH_FORCE_DIST")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--device", "0", "--steps", "4", "--warmup", "2", "--repeats", "1",
+                        "--batch", "8", "--no-cpu-baseline", "--no-secondary", "--no-sustained", "--streams", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "stub" not in j and j["roofline"] is not None
+    cfg = j["config"]
+    assert cfg["global_batch"] == 16 and cfg["all_ranks_on_device"] == 0 and "ONE GPU" in cfg["parallelism"]
+    ag = cfg["allgather"]
+    assert ag["verified"] is True and ag["form"].startswith("peer") and ag["backend"] == "gloo" and ag["bytes_per_rank"] == 8 * 256 * 256 * 4 * 4
+    assert len(cfg["per_rank_images_per_sec"]) == 2 and all(v > 0 for v in cfg["per_rank_images_per_sec"])
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Range guard of the 16-bit modes (include/bsr_hip.h: BSR_ERR_RANGE, bsr_check_range)
 
@@ -798,20 +827,16 @@ def test_fused_heads_epilogue_is_bit_identical_to_the_two_launch_form(dtype, mon
 
 
 def test_fused_gemm_tails_are_bit_identical_to_the_separate_launches(monkeypatch):
-    """Round 4: at full batches two K = 128 GEMMs of every bottleneck block run as the TAIL of the kernel that produces their input
-    (csrc/gemm_tail.h): the NonLocalBlock's `w` conv + residual + LeakyReLU behind the attention kernel (its 128 queries = 128 pixels),
-    and conv3 | theta|phi|g behind res*.conv2 (an 8-wave workgroup = a 4x32 tile x all 128 channels) — the same MFMA order per output
-    element as the separate gemm_nloop launches => the same bits on every probe and output.  BSR_FUSE_ATTW=0 / BSR_FUSE_C3Q=0 at
-    handle creation force the separate launches (the conv2 tail is off by default: profiles/HISTORY.md)."""
+    """Round 4: at full fp32 batches the NonLocalBlock's `w` conv + residual + LeakyReLU runs as the TAIL of the attention kernel (its 128
+    queries = 128 pixels of the K = 128 GEMM; csrc/gemm_tail.h) — the same MFMA order per output element as the separate gemm_nloop
+    launch => the same bits on every probe and output.  BSR_FUSE_ATTW=0 at handle creation forces the two launches small batches use.
+    (The same tail behind res*.conv2 was built too and retired in round 6: no faster; profiles/HISTORY.md.)"""
     from blindshadowremoval_amd import Generator
     w = init_weights(1)
-    monkeypatch.setenv("BSR_FUSE_C3Q", "1")             # the conv2 tail is opt-in (slower with two forwards in flight); the attention tail is the default
     fused = Generator().load_weights(w)
     monkeypatch.setenv("BSR_FUSE_ATTW", "0")
-    monkeypatch.setenv("BSR_FUSE_C3Q", "0")
     plain = Generator().load_weights(w)
     monkeypatch.delenv("BSR_FUSE_ATTW")
-    monkeypatch.delenv("BSR_FUSE_C3Q")
     g = torch.Generator().manual_seed(72)
     # (33, ...): 264 query blocks of 128 = two rounds of the 8-wave shape — the launcher prefers three rounds of the 4-wave one there,
     # and that shape keeps the two launches: still the same bits
@@ -824,7 +849,7 @@ def test_fused_gemm_tails_are_bit_identical_to_the_separate_launches(monkeypatch
         fused.set_timing(False)
         if want_fused:
             assert "res0.attw" in names and "res5.attw" in names and "res0.w" not in names and "res0.attention" not in names, (B, H, W)
-            assert "res0.c2c3q" in names and "res5.c2c3q" in names and "res0.conv2" not in names and "res0.c3q" not in names, (B, H, W)
+            assert "res0.conv2" in names and "res0.c3q" in names, (B, H, W)
         else:
             assert "res0.attention" in names and "res0.w" in names, (B, H, W)
         b = plain(inp, uv)
@@ -833,30 +858,6 @@ def test_fused_gemm_tails_are_bit_identical_to_the_separate_launches(monkeypatch
         for pr in ("res0", "res2", "res3", "res5", "y3x0", "y3x4"):
             assert torch.equal(fused.probe(pr), plain.probe(pr)), (B, H, W, pr)
     fused.close()
-    plain.close()
-
-
-def test_persistent_stride2_kernel_is_bit_identical(monkeypatch):
-    """igemm_s2p_kernel (round 4, opt-in BSR_S2_PERSIST=1): down1 / down2 on persistent workgroups that request the next tile's input
-    during the current tile's last chunk and keep the weight ring running across tiles — the same accumulation order as
-    igemm_conv_kernel<3,3,2>: same bits on x2, x3 and every output, for one and for several tiles per workgroup (B = 1: 128 tiles on 512
-    resident workgroups; B = 32: 8 tiles per workgroup; B = 3: a ragged walk)."""
-    from blindshadowremoval_amd import Generator
-    w = init_weights(1)
-    plain = Generator().load_weights(w)
-    monkeypatch.setenv("BSR_S2_PERSIST", "1")
-    pers = Generator().load_weights(w)
-    monkeypatch.delenv("BSR_S2_PERSIST")
-    g = torch.Generator().manual_seed(73)
-    for (B, H, W) in ((1, 256, 256), (3, 256, 256), (32, 256, 256), (2, 512, 512)):
-        inp, uv = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
-        a = [t.clone() for t in pers(inp, uv)]
-        b = plain(inp, uv)
-        for pr in ("x2", "x3"):
-            assert torch.equal(pers.probe(pr), plain.probe(pr)), (B, H, W, pr)
-        for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
-            assert torch.equal(x, y), (B, H, W, name)
-    pers.close()
     plain.close()
 
 
@@ -888,11 +889,15 @@ def test_smallest_accepted_image(gen_w):
 
 
 @pytest.mark.parametrize("dtype", ["f32x3", "f16"])
-def test_fused_attention_w_tail_is_bit_identical_in_the_16_bit_modes(dtype, monkeypatch):
-    """Round 5: the split-precision attention kernel runs the `w` GEMM as its tail too (attention_x3.h FUSEW, gemm_tail_run<.., H = 2>):
-    the normalised attention tile goes through LDS in fp32 and is split into hi / lo fp16 planes exactly as gemm_nloop_kernel<3,4,2>
-    splits what it loads from HBM, same matrix-instruction order per output element => the same bits as the two-launch form on every
-    output and probe — at every batch (this kernel has one workgroup shape), GSC and the wider TSM trunk alike."""
+def test_fused_attention_w_tail_agrees_with_the_two_launch_form_in_the_16_bit_modes(dtype, monkeypatch):
+    """Round 6: the one-wave-per-SIMD attention kernel of the 16-bit modes (attention_h16.h) runs the `w` GEMM as its tail with the normalised
+    O^T accumulators as the A operand — no LDS round trip, the K order of the accumulator registers (pack.py `w4`), the residual as the C
+    operand of each tile's first matrix instruction.  That is the arithmetic of the two-launch form (attention output to HBM, then
+    gemm_nloop_kernel<3, 4, 2>) in another summation order, so the two agree to rounding, not to the bit: block outputs to 2e-5, the
+    forward's outputs to 1e-4 whenever both forms take the same threshold decisions (model.py:256) — at every batch (this kernel has one
+    workgroup shape), GSC and the wider TSM trunk alike.  In the f16 mode a last-bit difference of a block output can flip the fp16
+    rounding of an activation the next 3x3 layer reads (2^-11 relative), so the bounds there are that mode's own scale: 5e-4 on the block
+    outputs, F16_TOL on the outputs.  The round-5 kernel's test here was bit-identity; it went with that kernel."""
     from blindshadowremoval_amd import Generator, GeneratorTSM
     w = init_weights(1)
     fused = Generator(dtype=dtype).load_weights(w)
@@ -900,7 +905,12 @@ def test_fused_attention_w_tail_is_bit_identical_in_the_16_bit_modes(dtype, monk
     plain = Generator(dtype=dtype).load_weights(w)
     monkeypatch.delenv("BSR_FUSE_ATTW")
     g = torch.Generator().manual_seed(73)
-    for (B, H, W) in ((32, 256, 256), (3, 256, 256), (2, 512, 512)):
+
+    def close(x, y, tol):
+        return float((x.double() - y.double()).abs().max()) <= tol
+    tol_blk, tol_blk2, tol_out = (2e-5, 5e-5, 1e-4) if dtype == "f32x3" else (5e-4, 1e-3, F16_TOL)
+
+    for (B, H, W) in ((32, 256, 256), (3, 256, 256), (2, 512, 512), (2, 32, 256)):
         inp, uv = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
         fused.set_timing(True)
         a = [t.clone() for t in fused(inp, uv)]
@@ -908,6 +918,7 @@ def test_fused_attention_w_tail_is_bit_identical_in_the_16_bit_modes(dtype, monk
         names = [n for n, _, _ in fused.get_launch_timing()]
         fused.set_timing(False)
         assert "res0.attw" in names and "res5.attw" in names and "res0.w" not in names and "res0.attention" not in names, (B, H, W)
+        fa = {pr: fused.probe(pr).clone() for pr in ("res0", "res2", "res3", "res5", "bmask")}
         plain.set_timing(True)
         b = plain(inp, uv)
         torch.cuda.synchronize()
@@ -915,10 +926,13 @@ def test_fused_attention_w_tail_is_bit_identical_in_the_16_bit_modes(dtype, monk
         plain.set_timing(False)
         assert "res0.attention" in names_p and "res0.w" in names_p and "res0.attw" not in names_p
         fused.check_range()
-        for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
-            assert torch.equal(x, y), (dtype, B, H, W, name)
-        for pr in ("res0", "res2", "res3", "res5"):
-            assert torch.equal(fused.probe(pr), plain.probe(pr)), (dtype, B, H, W, pr)
+        for pr in ("res0", "res2"):
+            assert close(fa[pr], plain.probe(pr), tol_blk), (dtype, B, H, W, pr, float((fa[pr] - plain.probe(pr)).abs().max()))
+        if torch.equal(fa["bmask"], plain.probe("bmask")):
+            for pr in ("res3", "res5"):
+                assert close(fa[pr], plain.probe(pr), tol_blk2), (dtype, B, H, W, pr, float((fa[pr] - plain.probe(pr)).abs().max()))
+            for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
+                assert close(x, y, tol_out), (dtype, B, H, W, name, float((x - y).abs().max()))
         with pytest.raises(RuntimeError, match="never left LDS"):
             fused.probe("att0")
         assert plain.probe("att0").shape == (B, H // 8, W // 8, 128)
@@ -933,24 +947,26 @@ def test_fused_attention_w_tail_is_bit_identical_in_the_16_bit_modes(dtype, monk
         inp, uv = torch.rand(4, 256, 256, 3, generator=g).cuda(), torch.rand(4, 256, 256, 3, generator=g).cuda()
         reg = ((torch.rand(4, 256, 256, 6, generator=g) - 0.5) * 0.2).cuda()
         a = [t.clone() for t in ft(inp, uv, reg, 2, True)]
+        fa = {pr: ft.probe(pr).clone() for pr in ("res2", "res5", "bmask")}
         b = pt(inp, uv, reg, 2, True)
-        for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
-            assert torch.equal(x, y), ("tsm", name)
-        for pr in ("res2", "res5"):
-            assert torch.equal(ft.probe(pr), pt.probe(pr)), ("tsm", pr)
+        assert close(fa["res2"], pt.probe("res2"), 2e-5), ("tsm", "res2")
+        if torch.equal(fa["bmask"], pt.probe("bmask")):
+            assert close(fa["res5"], pt.probe("res5"), 5e-5), ("tsm", "res5")
+            for x, y, name in zip(a, b, ("gs", "con_rgb", "mask22", "dif")):
+                assert close(x, y, 1e-4), ("tsm", name)
         ft.close()
         pt.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32x3", "f16"])
+@pytest.mark.parametrize("dtype", ["f32x3", "f16"])
 def test_conv1_resident_gemm_is_bit_identical_to_the_implicit_gemm_form(dtype, monkeypatch):
     """Round 5: at full batches res*.conv1 (1x1, 99 | 257 | 261 -> 128) runs as gemm_nloop_kernel<4, NCH, H, MINW = 1> — one workgroup per
     CU, the whole input tile resident in registers, all of N per workgroup — instead of the implicit-GEMM kernels (igemm_conv_kernel<1,1,1,
-    CC = 24> / igemm_h16_kernel<1,1,1>).  Same operands (fp32: the layer's 24-channel chunks; 16-bit: the same hi / lo split) and the same
-    matrix-instruction order per output element => the same bits; small batches keep the implicit-GEMM form."""
+    CC = 24> / igemm_h16_kernel<1,1,1>) in the 16-bit modes.  Same operands (the same hi / lo split) and the same matrix-instruction order
+    per output element => the same bits; small batches keep the implicit-GEMM form.  (On the fp32 path the resident form was built too,
+    bit-identical and no faster: retired in round 6.)"""
     from blindshadowremoval_amd import Generator
     w = init_weights(1)
-    monkeypatch.setenv("BSR_CONV1_GEMM", "2")          # 2: on the fp32 path too (there it is opt-in: bit-identical but no faster)
     new = Generator(dtype=dtype).load_weights(w)
     monkeypatch.setenv("BSR_CONV1_GEMM", "0")
     old = Generator(dtype=dtype).load_weights(w)

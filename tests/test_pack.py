@@ -188,3 +188,42 @@ def test_h16_pack_planes_reproduce_the_fp32_weights():
     assert struct.unpack_from("<4I", pack.pack_generator(init_weights(1, variant="tsm"), "f32x3"))[3] == pack.DTYPES["f32x3"]      # TSM packs in every dtype
     with pytest.raises(ValueError):
         pack.pack_taps_h16(k * 1e7, b, 32, 64, 96, 2)
+
+
+def test_w4_image_is_the_attention_tails_operand(w):
+    """pack_w4 (round 6): the NonLocalBlock's `w` conv as the LDS image of csrc/attention_h16.h's fused tail.  Emulate the kernel's reads: lane
+    (r = n & 31, h) of K step ks reads the 16-byte chunk at position (2 ks + h) ^ (n & 15) of row n (hi plane; lo plane 16 chunks further) and
+    multiplies it with registers 8p .. 8p + 7 of O^T tile dt (ks = 2 dt + p), i.e. channels 32 dt + 16 p + 4 h + (j & 3) + 8 (j >> 2): summed over
+    ks, h, j that must be the plain GEMM with the folded weights, to the 2^-22 of the hi + lo split."""
+    k, b = pack.layer_matrices(w)["res2.w"]
+    arr, bias = pack.pack_w4(k, b)
+    assert arr.shape == (9, 1, 32, 128) and bias.shape == (288,) and np.array_equal(bias[:257], b.astype(np.float32)) and not bias[257:].any()
+    img = np.ascontiguousarray(arr).view(np.float16).reshape(288, 32, 8).astype(np.float64)          # [row n][chunk position][8 halves]
+    rng = np.random.default_rng(3)
+    att = rng.standard_normal(128)
+    got = np.zeros(288)
+    for n in range(288):
+        for ks in range(8):
+            dt, p = ks >> 1, ks & 1
+            for h in range(2):
+                pos = (2 * ks + h) ^ (n & 15)
+                wk = img[n, pos] + img[n, 16 + pos]                                                   # hi + lo
+                ch = [32 * dt + 16 * p + 4 * h + (j & 3) + 8 * (j >> 2) for j in range(8)]
+                got[n] += float(np.dot(wk, att[ch]))
+    want = np.zeros(288)
+    want[:257] = att @ k[0].astype(np.float32).astype(np.float64)
+    assert np.abs(got - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+    # every 16-lane group of a ds_read_b128 (16 different rows, one K step) touches 16 different chunk positions mod 16: conflict-free
+    for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+        for c in range(16):
+            assert len({(c ^ (r & 15)) & 15 for r in grp}) == 16
+
+
+def test_16_bit_blobs_carry_the_w4_images(w):
+    blob = pack.pack_generator(w, "f32x3")
+    _, _, n_entries, _ = struct.unpack_from("<4I", blob, 0)
+    names = [struct.unpack_from("<40sQQ4i", blob, 16 + 72 * i)[0].split(b"\0")[0].decode() for i in range(n_entries)]
+    for i in range(6):
+        assert "res%d.w4.w" % i in names and "res%d.w4.b" % i in names and "res%d.w.w" % i in names
+    names32 = pack.pack_generator(w, "f32")
+    assert b"res0.w4.w" not in names32
