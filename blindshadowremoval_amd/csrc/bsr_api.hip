@@ -15,6 +15,7 @@
 
 #include "attention.h"
 #include "attention_h16.h"
+#include "conv3_f16.h"
 #include "conv_n16.h"
 #include "gemm_nloop.h"
 #include "glue_kernels.h"
@@ -151,7 +152,11 @@ struct bsr_handle {
   unsigned* range_flag = nullptr;
   bool fuse_heads = true;        // env BSR_FUSE_HEADS=0: always the two-launch heads (A/B measurements, bit-identity tests)
   bool conv1_gemm = true;        // env BSR_CONV1_GEMM=0: res*.conv1 of the 16-bit modes on the implicit-GEMM kernel at every batch (A/B measurements, bit-identity tests)
-  bool att_pv1 = false;          // env BSR_ATT_PV1=1 (f16 mode only): P.V of the attention with the hi planes only (one matrix instruction per product)
+  bool att_pv1 = false;          // f16 mode: P.V of the attention with the hi planes only (one matrix instruction per product instead of three).  Measured on
+                                 // the f16 parity tests: margins 60 / 75 / 65 % of F16_TOL used against 64 / 69 / 75 % with the split product — the mode's
+                                 // error is set by its fp16 activations, not by this — and 1.4 % of the forward (profiles/HISTORY.md round 6); f32x3 keeps the split
+  bool conv3_f16 = true;         // env BSR_CONV3_F16=0: the f16 mode's 3x3 / transposed 3x3 layers on igemm_h16_kernel<.., NSPLIT = 1> (the form small test shapes
+                                 // and A/B measurements compare against; same operands, another summation order)
   bool fuse_attw = true;         // env BSR_FUSE_ATTW=0: attention and the `w` GEMM as two launches (A/B measurements, bit-identity tests)
   bool timing = false;
   std::vector<hipEvent_t> ev;    // event pool, pairs
@@ -252,6 +257,25 @@ struct Launcher {
     if (mh % 4 != 0 || mw % 32 != 0) {
       rc = fail(BSR_ERR_ARG, std::string("layer '") + name + "': feature map is not a multiple of the 4x32 tile");
       return;
+    }
+    // f16 mode, stride-1 3x3 and transposed 3x3: the trio-stepped kernel of conv3_f16.h from the layer's `w3` image (pack.py)
+    if constexpr (k33 && S == 1) {
+      if (h->dtype == BSR_DTYPE_F16 && h->conv3_f16) {
+        char nm3[48];
+        snprintf(nm3, sizeof nm3, "%s.w3", name);
+        LayerW l3;
+        const int nblk = (n_store + 63) / 64;
+        rc = find_layer(h, nm3, nblk * (k_pad / 32), 9, 16, 64, &l3);
+        if (rc != BSR_OK) return;
+        a.w = l3.w; a.bias = l3.b; a.nchunk = k_pad / 32; a.n_pad = nblk * 64;
+        begin(cls, name);
+        if (io == 3) check(bsr::launch_conv3_f16<TR, 3>(a, h->B, s), name);
+        else if (io == 2) check(bsr::launch_conv3_f16<TR, 2>(a, h->B, s), name);
+        else if (io == 1) check(bsr::launch_conv3_f16<TR, 1>(a, h->B, s), name);
+        else check(bsr::launch_conv3_f16<TR, 0>(a, h->B, s), name);
+        end();
+        return;
+      }
     }
     begin(cls, name);
     static_assert(k33 || k11, "igemm layers are 3x3 or 1x1");
@@ -444,7 +468,8 @@ int bsr_create(bsr_handle** out, int device, const void* packed_weights, size_t 
   h->dtype = dtype;
   if (const char* e_ = getenv("BSR_FUSE_HEADS")) h->fuse_heads = atoi(e_) != 0;
   if (const char* e_ = getenv("BSR_FUSE_ATTW")) h->fuse_attw = atoi(e_) != 0;
-  if (const char* e_ = getenv("BSR_ATT_PV1")) h->att_pv1 = atoi(e_) != 0 && dtype == BSR_DTYPE_F16;
+  if (const char* e_ = getenv("BSR_CONV3_F16")) h->conv3_f16 = atoi(e_) != 0;
+  h->att_pv1 = dtype == BSR_DTYPE_F16;
   if (const char* e_ = getenv("BSR_CONV1_GEMM")) h->conv1_gemm = atoi(e_) != 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), nbytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob, nbytes, hipMemcpyHostToDevice);

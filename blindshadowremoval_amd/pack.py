@@ -29,6 +29,8 @@ TRANSPOSED = ("up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3")
 DTYPES = {"f32": 0, "f16": 1, "f32x3": 2}     # BSR_DTYPE_* of include/bsr_hip.h
 # layers the 16-bit modes run on igemm_h16_kernel (csrc/igemm_h16.h): every 3x3 / stride-2 3x3 / transposed 3x3 igemm layer
 H16_LAYERS = ("down1", "down2", "down3", "up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3") + tuple("res%d.conv2" % i for i in range(6))
+# f16 mode: the stride-1 3x3 and the transposed 3x3 layers run on conv3_f16_kernel (csrc/conv3_f16.h) from their `w3` images
+W3_LAYERS = ("up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3") + tuple("res%d.conv2" % i for i in range(6))
 # 1x1 layers (igemm_h16_kernel<1,1> / gemm_nloop_kernel<.., H = 2>): split-precision (hi + lo planes) in BOTH 16-bit modes
 X3_LAYERS = tuple("res%d.%s" % (i, n) for i in range(6) for n in ("conv1", "c3q", "w")) + ("heads", "clr_conv1", "conv1")      # + conv_n16_kernel / stem7_kernel<.., H = 2>
 
@@ -119,6 +121,31 @@ def pack_taps_h16(kernel_tkn: np.ndarray, bias: np.ndarray, cc: int, k_pad: int,
         img = np.ascontiguousarray(np.concatenate(planes, axis=3))                    # [chunk, tap, n, nsplit*cc + 8] halves
     arr = img.view(np.float32)                                                         # two halves per 32-bit word, little endian
     b = np.zeros(n_pad, np.float32)
+    b[:n] = bias
+    return arr, b
+
+
+def pack_w3(kernel_tkn: np.ndarray, bias: np.ndarray, k_pad: int):
+    """A 3x3 / transposed 3x3 layer ([9, K, N] folded) as the weight stream of csrc/conv3_f16.h (f16 mode): per 64-channel output block and
+    32-channel K chunk one 36-KB run of nine tap images [64 rows n][32 halves k] — three 12-KB trios, each moved by LDS-DMA as it lies.
+    Rows are unpadded (64 bytes); the 16-byte unit u = k / 8 of row n sits at position u ^ ((n >> 2) & 3), which makes a ds_read_b128 over
+    16 different rows conflict-free.  Returns ([nblk * nchunk, 9, 64, 16] float32 words, [nblk * 64] bias)."""
+    taps, k, n = kernel_tkn.shape
+    assert taps == 9 and k <= k_pad and k_pad % 32 == 0
+    nblk, nchunk = (n + 63) // 64, k_pad // 32
+    full = np.zeros((9, k_pad, nblk * 64), np.float64)
+    full[:, :k, :n] = kernel_tkn.astype(np.float32)
+    hi = full.astype(np.float16)
+    if not np.all(np.isfinite(hi)):
+        raise ValueError("a folded weight exceeds the fp16 range (65504): this layer cannot run in the 16-bit modes")
+    rows = hi.reshape(9, nchunk, 4, 8, nblk, 64).transpose(4, 1, 0, 5, 2, 3)          # [blk, chunk, tap, row, unit, 8 halves]
+    img = np.empty_like(rows)
+    for row in range(64):
+        sw = (row >> 2) & 3
+        for u in range(4):
+            img[:, :, :, row, u ^ sw] = rows[:, :, :, row, u]
+    arr = np.ascontiguousarray(img.reshape(nblk * nchunk, 9, 64, 32)).view(np.float32)     # [.., 16] words
+    b = np.zeros(nblk * 64, np.float32)
     b[:n] = bias
     return arr, b
 
@@ -229,6 +256,10 @@ def pack_generator(weights: Dict[str, np.ndarray], dtype: str = "f32") -> bytes:
             arr, bias = pack_taps(k, b, cc, k_pad, n_pad)
         entries.append((name + ".w", arr, tuple(arr.shape)))
         entries.append((name + ".b", bias, (n_pad, 0, 0, 0)))
+        if dtype == "f16" and name in W3_LAYERS:
+            arr3, bias3 = pack_w3(k, b, k_pad)
+            entries.append((name + ".w3.w", arr3, tuple(arr3.shape)))
+            entries.append((name + ".w3.b", bias3, (bias3.shape[0], 0, 0, 0)))
         if dtype != "f32" and name.startswith("res") and name.endswith(".w"):
             arr4, bias4 = pack_w4(k, b)
             entries.append((name + "4.w", arr4, tuple(arr4.shape)))

@@ -227,3 +227,28 @@ def test_16_bit_blobs_carry_the_w4_images(w):
         assert "res%d.w4.w" % i in names and "res%d.w4.b" % i in names and "res%d.w.w" % i in names
     names32 = pack.pack_generator(w, "f32")
     assert b"res0.w4.w" not in names32
+
+
+def test_w3_stream_is_the_f16_conv_kernels_operand(w):
+    """pack_w3 (round 6): a 3x3 / transposed 3x3 layer as the weight stream of csrc/conv3_f16.h.  Emulate the kernel's B-fragment read — lane
+    (r, h) of block row ni * 32 + r reads the 16-byte unit at position (2 g + h) ^ ((r >> 2) & 3) of its 64-byte row and uses it as
+    k = 16 g + 8 h + j — and check it returns fp16(W[tap][32 chunk + k][64 blk + row]) for every (block, chunk, tap, row, k); the padded
+    block of a 96-channel layer is zero."""
+    k, b = pack.layer_matrices(w)["clr_up2"]                      # [9, 128, 96]
+    arr, bias = pack.pack_w3(k, b, 128)
+    assert arr.shape == (2 * 4, 9, 64, 16) and bias.shape == (128,) and not bias[96:].any()
+    img = np.ascontiguousarray(arr).view(np.float16).reshape(2, 4, 9, 64, 4, 8)
+    want = np.zeros((9, 128, 128), np.float16)
+    want[:, :, :96] = k.astype(np.float32).astype(np.float16)
+    for blk in range(2):
+        for row in (0, 1, 5, 31, 32, 47, 63):
+            sw = (row >> 2) & 3
+            for g in range(2):
+                for h in range(2):
+                    got = img[blk, :, :, row, (2 * g + h) ^ sw]                              # [chunk, tap, 8]
+                    ks = 16 * g + 8 * h + np.arange(8)
+                    exp = np.stack([want[:, 32 * c + ks, 64 * blk + row] for c in range(4)])  # [chunk, tap, 8]
+                    assert np.array_equal(got, exp)
+    for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+        for u in range(4):                                             # 16 rows of 64 bytes, one unit each: 16 different 16-byte bank groups
+            assert len({(r * 4 + (u ^ ((r >> 2) & 3))) & 15 for r in grp}) == 16
