@@ -42,6 +42,9 @@
 #ifndef BSR_H16_PACK_STORES
 #define BSR_H16_PACK_STORES 0          // 1: the fp16 epilogues trade values between neighbouring lanes and store two channels (4 bytes) per lane — measured: transposed convs 370 vs 359 us, stem 85 vs 88 (the permutes and selects cost more than the halved store count saves): off
 #endif
+#ifndef BSR_H16_WIDE_STORES
+#define BSR_H16_WIDE_STORES 1   // fp32 outputs leave through LDS as 16-byte stores (round 6; 0 = 16 dword stores per accumulator tile)
+#endif
 #ifndef BSR_H16_BDEEP
 #define BSR_H16_BDEEP 0     // 1: f16 transposed convs read the B fragments of a whole step one step ahead (measured: 355.9 vs 358.1 us, nothing — off)
 #endif
@@ -667,6 +670,43 @@ __global__ __launch_bounds__(256, 2) void igemm_h16_kernel(ConvArgs p) {
   const bool pk = OUT16 && BSR_H16_PACK_STORES && ((p.out_cs | p.out_coff) & 1) == 0;
   const unsigned lane_out_pk = ((unsigned)(SX * (4 * h + (odd ? 1 : 0))) * (unsigned)p.out_cs + (unsigned)(r & ~1)) * 2u;
   const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.out) + (blk_pix * p.out_cs + p.out_coff) * OB));
+  // fp32 output as 16-byte stores (round 6): in the accumulator layout a lane holds ONE channel of 16 pixels — 16 dword stores per 32x32
+  // tile, 128 per wave for the four parities of a transposed conv, ~60 cycles each at the issue (in-kernel stamps: 8-9 k of a
+  // workgroup's 52 k cycles).  The tile goes through LDS ([32 pixels][32 channels] floats, 128-byte rows: a half-wave's dword writes and
+  // the 16-byte reads of two rows are both conflict-free) and leaves as 4 instructions of 16 bytes per lane, eight lanes per pixel.  The
+  // loop's LDS is dead behind its last barrier; a wave uses its own 4-KB region and LDS executes a wave's accesses in order.  Same values.
+  if constexpr (!OUT16 && BSR_H16_WIDE_STORES && MI == 1 && WN == 1 && WM == 4 && C::SMEM_BYTES >= 4 * 4096) {
+    if (((p.out_cs | p.out_coff | p.n_store) & 3) == 0) {
+      float* reg = smem + wave * 1024;
+      const int piece = lane & 7, pc = lane >> 3;                     // this lane's 16-byte piece (4 channels) of pixel column pc + 8 q
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int nt = n0 + ni * 32;
+          f32x16 v = acc[ph][0][ni];
+          if (p.act) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+              const f32x2 y = leaky_relu2(f32x2{v[i], v[i + 1]});
+              v[i] = y[0];
+              v[i + 1] = y[1];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) reg[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = v[i];
+          const unsigned v16 = nt + piece * 4 < p.n_store ? (unsigned)((SX * pc) * p.out_cs + piece * 4) * 4u : kLaneOff;
+          const unsigned tile_off = (unsigned)((SX * wm + (TR ? (ph >> 1) : 0)) * p.Wo + (TR ? (ph & 1) : 0)) * (unsigned)p.out_cs + (unsigned)nt;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            typedef unsigned h16_u4 __attribute__((ext_vector_type(4)));
+            const h16_u4 d = *reinterpret_cast<const h16_u4*>(reg + (8 * q + pc) * 32 + piece * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(d, orsrc, v16, (tile_off + (unsigned)(SX * 8 * q) * (unsigned)p.out_cs) * 4u, 0);
+          }
+        }
+      return;
+    }
+  }
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll

@@ -166,8 +166,17 @@ class Logging(object):
             os.makedirs(os.path.join(self.config.CHECKPOINT_DIR, 'test'), exist_ok=True)
 
         def put(path, row):
+            # unbuffered (the file is one ~0.6-1.4 MB write), but a raw write may be SHORT (disk filling up, a signal): loop until every byte is
+            # out, and raise — through the future, in flush() — when the device stops taking bytes.  The stored-deflate files are raw size + 0.3 %:
+            # at 3-4.5 k files/s the loops emit 3-4 GB/s, so a full disk is a real way for this to fail.
+            mv = memoryview(row).cast("B")
             with open(path, "wb", buffering=0) as f:
-                f.write(memoryview(row))
+                done = 0
+                while done < len(mv):
+                    n = f.write(mv[done:])
+                    if not n:
+                        raise OSError("short write: %d of %d bytes of %s" % (done, len(mv), path))
+                    done += n
         futs = []
         for j, name in enumerate(names):
             out = self._png_path(name)

@@ -43,7 +43,7 @@ class StripEncoder:
         lib = _lib.load()
         need = int(lib.bsr_png_scratch_bytes(b))
         if self._scratch is None or self._scratch.numel() * 8 < need:
-            self._scratch = torch.empty((max(need, 4096) + 7) // 8, dtype=torch.int64, device=strips.device)
+            self._scratch = torch.zeros((max(need, 4096) + 7) // 8, dtype=torch.int64, device=strips.device)      # zero ONCE: every call leaves it zero (ABI 7)
         with torch.cuda.device(self.device):
             rc = lib.bsr_png_encode(self.device, ctypes.c_void_p(strips.data_ptr()), b, h, w, ctypes.c_void_p(out.data_ptr()), n,
                                     ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -91,7 +91,7 @@ class StripEncoder:
         lib = _lib.load()
         need = int(lib.bsr_png_scratch_bytes(b))
         if self._scratch is None or self._scratch.numel() * 8 < need:
-            self._scratch = torch.empty((max(need, 4096) + 7) // 8, dtype=torch.int64, device=t0.device)
+            self._scratch = torch.zeros((max(need, 4096) + 7) // 8, dtype=torch.int64, device=t0.device)           # zero ONCE: every call leaves it zero (ABI 7)
         P = (ctypes.c_void_p * n)
         with torch.cuda.device(self.device):
             rc = lib.bsr_png_encode_figs(self.device, n, P(*ptrs), P(*muls), (ctypes.c_float * n)(*scales), (ctypes.c_int * n)(*chans), (ctypes.c_int * n)(*pss),

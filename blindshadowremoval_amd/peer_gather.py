@@ -57,6 +57,7 @@ class PeerGather:
             self.peers.append(t)
         self.stream = torch.cuda.Stream(device=self.device)
         self._done: Optional[torch.cuda.Event] = None
+        self._reads: list = []                              # events behind this rank's asynchronous reads of gathered buffers (consumed())
         dist.barrier(group=control_group)                  # every mapping exists before anyone writes
 
     def push(self, slot: int, payload: torch.Tensor) -> None:
@@ -77,15 +78,27 @@ class PeerGather:
         payload.record_stream(self.stream)
 
     def finish(self) -> None:
-        """Blocks until EVERY rank's last push has landed everywhere: this rank's copies have completed, then the control barrier."""
+        """Blocks until EVERY rank's last push has landed everywhere: this rank's copies have completed, then the control barrier.  Also waits
+        for this rank's recorded READS of gathered buffers (`consumed()`): after the barrier a peer may push into a slot again, and GPU work
+        of this rank that still reads it would race with those writes — the barrier orders hosts, not this rank's compute stream."""
         if self._done is not None:
             self._done.synchronize()
             self._done = None
+        for ev in self._reads:
+            ev.synchronize()
+        self._reads = []
         dist.barrier(group=self.group)
 
     def gathered(self, slot: int) -> torch.Tensor:
-        """[world * n, ...]: valid between the finish() after its push and the finish() before the next push into this slot."""
+        """[world * n, ...]: valid between the finish() after its push and the finish() before the next push into this slot.  A caller
+        whose GPU work reads it asynchronously calls `consumed()` after enqueueing that work (host-side reads — .cpu(), .item() — need not)."""
         return self.local[slot]
+
+    def consumed(self) -> None:
+        """Record, on the CURRENT stream, that every read of gathered buffers enqueued so far is what the next finish() must wait for."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self._reads.append(ev)
 
     def close(self) -> None:
         dist.barrier(group=self.group)                     # nobody unmaps while a peer may still write
@@ -115,7 +128,10 @@ def _selftest(argv=None) -> int:
         mine = torch.rand(shape, generator=g).cuda(dev)
         pg.push(slot, mine)
         pg.finish()
+        chk = pg.gathered(slot).double().sum()            # an asynchronous GPU-side reader of the gathered buffer ...
+        pg.consumed()                                     # ... which the next finish() must wait for before peers may overwrite the slot
         got = pg.gathered(slot).cpu()
+        ok = ok and abs(float(chk) - float(got.double().sum())) < 1e-6
         for r in range(world):
             want = torch.rand(shape, generator=torch.Generator(device="cpu").manual_seed(1000 * step + r))
             ok = ok and bool(torch.equal(got[r * shape[0]:(r + 1) * shape[0]], want))

@@ -95,8 +95,11 @@ def _parse_8bit(b: bytes):
         raw = np.empty(n + 16, np.uint8)
         if lib.bsr_inflate_zlib(z, len(z) - 16, raw.ctypes.data, n) == 0:
             return w, h, c, raw[:n]
-    data = zlib.decompress(b"".join(idat) if len(idat) != 1 else idat[0], 15, n)     # the size is known: no buffer regrowth (3x faster)
-    if len(data) != n:
+    # the size is known: ask for at most n + 1 bytes — a crafted stream that inflates far beyond h * (1 + w * c) is cut off there instead of
+    # being materialised whole before the length check (zlib.decompress's third argument is only an initial buffer size)
+    d = zlib.decompressobj(15)
+    data = d.decompress(b"".join(idat) if len(idat) != 1 else idat[0], n + 1)
+    if len(data) != n or d.unconsumed_tail or not d.eof:
         raise ValueError
     return w, h, c, np.frombuffer(data, np.uint8)
 

@@ -134,8 +134,12 @@ int bsr_prep_rows(int device, const void* d_blob, size_t blob_bytes, size_t rows
  * pixels: [B,H,W,3] uint8 RGB strips (device).  out: B complete PNG FILE images, out_stride bytes apart (device or device-mapped
  * pinned memory), each exactly bsr_png_file_bytes(H, W) long: 8-bit truecolour, filter type 0, the zlib stream as stored deflate
  * blocks (lossless: any decoder returns `pixels`; size = raw size + 0.3 %), Adler-32 and chunk CRC-32s computed on the device.
- * scratch: bsr_png_scratch_bytes(B) bytes of device memory, 8-byte aligned (the per-file checksum accumulators).  W <= 5461.
- * Asynchronous on `stream`.  ABI 5. */
+ * scratch: bsr_png_scratch_bytes(B) bytes of device memory, 8-byte aligned (the per-file checksum accumulators and arrival tickets).
+ * ABI 7: the scratch must be ZERO when it is first used (one hipMemset when it is allocated) and every call leaves it zero again — the
+ * encoder is ONE launch whose last workgroup per file finishes the file and clears its accumulators (ABI 5-6 cleared them with a memset per
+ * call and finished with a third launch).  A scratch that is not zero gives files with wrong checksums.  One call at a time per scratch.
+ * W <= 5461; the Adler-32 sums are reduced per workgroup, so every admitted size (up to 65535 x 5461 pixels) checksums correctly.
+ * Asynchronous on `stream`. */
 size_t bsr_png_file_bytes(int H, int W);
 size_t bsr_png_scratch_bytes(int B);
 int bsr_png_encode(int device, const unsigned char* pixels, int B, int H, int W, unsigned char* out, size_t out_stride, void* scratch,

@@ -17,3 +17,12 @@ figs = [rows[..., 0:3], pk[..., 0:3], (pk[..., 3:4], rows[..., 15:16], 2.0)]
 s3 = (torch.rand(16, 256, 768, 3, device="cuda") * 255).to(torch.uint8)
 s7 = (torch.rand(16, 256, 1792, 3, device="cuda") * 255).to(torch.uint8)
 print("encode_figs 16 x (3 x 256): %.3f ms;  encode u8 16 x 768: %.3f ms;  encode u8 16 x 1792: %.3f ms" % (t(lambda: enc.encode_figs(figs)), t(lambda: enc.encode(s3)), t(lambda: enc.encode(s7))))
+def tb(fn, n=50):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+print("back to back (50 calls between two events): encode_figs %.3f ms;  u8 16 x 768 %.3f ms;  u8 16 x 1792 %.3f ms" % (tb(lambda: enc.encode_figs(figs)), tb(lambda: enc.encode(s3)), tb(lambda: enc.encode(s7))))
