@@ -380,8 +380,13 @@ def roofline_from_events(gen, run_once, B, dtype, n_rep=3):
         oth_key = [k for k in kgroups if "other instantiations" in k][0]
         kgroups.pop(dom_key)
         kgroups.pop(oth_key)
-        kgroups["igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=2,CC=32> (transposed 3x3: up2, up3, clr_up3, clr_up1)"] = ["up2", "up3", "clr_up3", "clr_up1"]
-        kgroups["igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=1,CC=32> (transposed 3x3: up1, clr_up2)"] = ["up1", "clr_up2"]
+        if dtype == "f16":       # round 6: the f16 mode's stride-1 and transposed 3x3 layers run on conv3_f16_kernel (csrc/conv3_f16.h), all six transposed layers on ONE instantiation
+            kgroups.pop([k for k in kgroups if "(res*.conv2)" in k][0])
+            kgroups["conv3_f16_kernel<TR> (transposed 3x3: up1, up2, up3, clr_up1, clr_up2, clr_up3)"] = ["up1", "up2", "up3", "clr_up1", "clr_up2", "clr_up3"]
+            kgroups["conv3_f16_kernel<S1> (res*.conv2)"] = ["res%d.conv2" % i for i in range(6)]
+        else:
+            kgroups["igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=2,CC=32> (transposed 3x3: up2, up3, clr_up3, clr_up1)"] = ["up2", "up3", "clr_up3", "clr_up1"]
+            kgroups["igemm_conv_kernel<3,3,1,TR,4,32,4,1,1,NI=1,CC=32> (transposed 3x3: up1, clr_up2)"] = ["up1", "clr_up2"]
     for gname, layers in kgroups.items():
         layers = [n for n in layers if n in layer_ms]        # a group's layers that ran as their own launch in this forward (others: a fused launch's group)
         ms = sum(layer_ms[n] for n in layers)
@@ -497,7 +502,8 @@ def roofline_in_flight(gens, lanes, run_on, B, dtype, dom_name, ms_per_step, n_r
 
 
 # kernel-group label (KERNEL_GROUPS / the 16-bit relabelling) -> substring of the rocprofv3 kernel names of that group
-GROUP_KERNEL_KEY = (("up2, up3, clr_up3", "<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32"), ("(res*.c3q", "gemm_nloop_kernel<3,"), ("attention", "attention"),
+GROUP_KERNEL_KEY = (("conv3_f16_kernel<TR>", "conv3_f16_kernel<true"), ("conv3_f16_kernel<S1>", "conv3_f16_kernel<false"),
+                    ("up2, up3, clr_up3", "<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32"), ("(res*.c3q", "gemm_nloop_kernel<3,"), ("attention", "attention"),
                     ("(res*.conv2)", "<3, 3, 1, false"), ("(down1-3)", "<3, 3, 2, false"), ("clr_conv1", "conv_n16_kernel<3, 3"),
                     ("heads", "conv_n16_kernel<7, 1"), ("stem7", "stem7_kernel"), ("(res*.conv1)", "<1, 1, 1, false"), ("(res*.conv1)", "gemm_nloop_kernel<4,"),
                     ("up1, clr_up2", "<3, 3, 1, true, 4, 32, 4, 1, 1, 1, 32"), ("other instantiations", "<3, 3, 1, true, 4, 32, 4, 1, 1, 1,"),
@@ -511,7 +517,7 @@ def attach_traffic(rf, dom_name, B, dtype):
     from blindshadowremoval_amd.build import source_sha16
     sha = source_sha16()
     sfx = "" if dtype == "f32" else "_" + dtype
-    for tag in ("r5", "r4", "r3", "r2", "r1"):
+    for tag in ("r6", "r5", "r4", "r3", "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx))
         if not os.path.isfile(tpath):
             continue
@@ -541,7 +547,7 @@ def attach_group_traffic(rf, B, dtype):
     the passes ran on."""
     from blindshadowremoval_amd.build import source_sha16
     sfx = "" if dtype == "f32" else "_" + dtype
-    tpath = next((os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx)) for tag in ("r5", "r4")
+    tpath = next((os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx)) for tag in ("r6", "r5", "r4")
                   if os.path.isfile(os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, sfx)))), None)
     if tpath is None:
         return
@@ -577,7 +583,7 @@ def attach_mfma(rf, dom_name, B, dtype):
     sha = source_sha16()
     sfx = "" if dtype == "f32" else "_" + dtype
     rf["mfma_busy"] = rf["clock_ghz"] = None
-    mtag = next((t for t in ("r5", "r4", "r3") if os.path.isfile(os.path.join(ROOT, "profiles", "%s_pmc_mfma%s.json" % (t, sfx)))), None)
+    mtag = next((t for t in ("r6", "r5", "r4", "r3") if os.path.isfile(os.path.join(ROOT, "profiles", "%s_pmc_mfma%s.json" % (t, sfx)))), None)
     if mtag is None:
         rf["mfma_note"] = "no profiles/r*_pmc_mfma%s.json" % sfx
         return

@@ -60,8 +60,8 @@ if hit is not None and miss is not None:
     cols.append("l2_hit_rate")
 out = m[cols].round(3)
 out.to_csv(os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.csv" % (tag, sfx)))
-is33 = out.index.str.contains("<3, 3")          # the 3x3 / stride-2 3x3 / transposed 3x3 launches (roofline kernel class)
-dom = out[out.index.str.contains("<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32")]           # igemm_{conv,h16}_kernel<3,3,1,TR,...,NI=2,CC=32>: up2, up3, clr_up3
+is33 = out.index.str.contains("<3, 3") | out.index.str.contains("conv3_f16_kernel")          # the 3x3 / stride-2 3x3 / transposed 3x3 launches (roofline kernel class)
+dom = out[out.index.str.contains("<3, 3, 1, true, 4, 32, 4, 1, 1, 2, 32") | out.index.str.contains("conv3_f16_kernel<true")]      # igemm_{conv,h16}_kernel<3,3,1,TR,...,NI=2,CC=32>: up2, up3, clr_up3; f16 (round 6): conv3_f16_kernel<TR>
 alg = sum(LAYER_IO_MB.values()) * 32 * 1e6 / len(LAYER_IO_MB)
 per_kernel = {k: {"launches_per_forward": int(r["launches_per_forward"]), "hbm_bytes_per_forward": float(r["hbm_MB_per_forward"] * 1e6)}
               for k, r in out.iterrows()}
