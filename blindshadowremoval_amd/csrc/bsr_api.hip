@@ -316,6 +316,9 @@ struct Launcher {
       const int want = (int)((2LL * bsr::device_cu_count() + mblocks - 1) / (mblocks > 0 ? mblocks : 1));
       const int most = (tiles + NI - 1) / NI;
       kNSplit = want < 2 ? 2 : (want > most ? most : want);
+#ifdef BSR_NL_NSPLIT
+      kNSplit = BSR_NL_NSPLIT > most ? most : BSR_NL_NSPLIT;
+#endif
     }
     rc = find_layer(h, name, NCH, 1, 36, (tiles + NI - 1) * 32, &l);   // the last group of a range may read (zero) rows past its tiles
     if (rc != BSR_OK) return;

@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
     for (int ch = 0; ch < NCH; ++ch) {
       const int s = ng * NCH + ch;
       const bool has1 = s + 1 < nsteps, has2 = s + 2 < nsteps;
+#if defined(BSR_NL_DIAG) && (BSR_NL_DIAG == 6 || BSR_NL_DIAG == 7)
+      if (has2 && p.act == 77) fetch_w(s + 2, w_regs);       // diagnostic: the loop without its weight traffic (stale LDS contents)
+#else
       if (has2) fetch_w(s + 2, w_regs);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -183,7 +187,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
         } else if (has1) {
           read_frags(nxt, w_n1);
         }
+#if defined(BSR_NL_DIAG) && BSR_NL_DIAG == 7
+        if (g == G - 1 && has2 && p.act == 77) store_w(w_n2, w_regs);
+#else
         if (g == G - 1 && has2) store_w(w_n2, w_regs);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (H == 0) {
           const f32x4 a = afr[ch * G + g];
@@ -234,7 +242,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
       f32x16 v = acc[ni];
       // Addressing as in igemm_conv_kernel's epilogue: the four pixel rows of a register quad are four per-lane offsets, the quad's
       // base one SGPR that moves by eight pixels — one scalar add per four loads / stores instead of three per element.
+#if defined(BSR_NL_DIAG) && (BSR_NL_DIAG == 1 || BSR_NL_DIAG == 4 || BSR_NL_DIAG == 6 || BSR_NL_DIAG == 7)
+      if (has_res && nt < p.res1_c && p.act == 77) {
+#else
       if (has_res && nt < p.res1_c) {                        // ONE residual (res1, channels [0, res1_c)); uniform per tile
+#endif
         const unsigned rcs4 = (unsigned)p.res1_cs * 4u;
         const unsigned l1 = n < p.res1_c ? lane_res + (unsigned)r * 4u : kLaneOff;      // out-of-range lanes read 0
         const unsigned lj[4] = {l1, l1 + rcs4, l1 + 2u * rcs4, l1 + 3u * rcs4};          // (0x80000000 + a few KB is still outside the buffer)
@@ -269,8 +281,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
               amax = __builtin_fmaxf(__builtin_fabsf(x), amax);
               const _Float16 xh = (_Float16)x;
               const _Float16 xl = (_Float16)(x - (float)xh);
+#if defined(BSR_NL_DIAG) && (BSR_NL_DIAG == 2 || BSR_NL_DIAG >= 4)
+              if (x == 12345.678f)
+#endif
+              {
               __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, xh), rsrc_out2, vb2 + (unsigned)j * 1536u, so, 0);
               __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, xl), rsrc_out2, vb2 + (unsigned)j * 1536u + 256u, so, 0);
+              }
             }
             so += 8u * 1536u;
           }
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nloop_kernel(ConvArgs p) {
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#if defined(BSR_EPI_SKIP)
+#if defined(BSR_EPI_SKIP) || (defined(BSR_NL_DIAG) && (BSR_NL_DIAG == 3 || BSR_NL_DIAG >= 4))
           if (v[4 * q + j] == 12345.678f)        // diagnostic build only (scratch/bench_igemm.hip): the kernel without its output traffic
 #endif
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[4 * q + j]), second ? rsrc_out2 : rsrc_out, vj[j], so, 0);
