@@ -34,7 +34,7 @@ def source_sha16() -> str:
 
 
 def extra_flags():
-    """Extra hipcc flags of an EXPERIMENT build (env BSR_EXTRA_FLAGS, e.g. "-DBSR_AX3_PRIO=1"): part of the source hash, so a library
+    """Extra hipcc flags of an EXPERIMENT build (env BSR_EXTRA_FLAGS, e.g. "-DBSR_NL_DIAG=4"): part of the source hash, so a library
     built with them only loads while the variable still says so (scratch/ab_build.sh); empty for every product build."""
     return os.environ.get("BSR_EXTRA_FLAGS", "").split()
 

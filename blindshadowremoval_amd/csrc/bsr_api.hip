@@ -435,7 +435,7 @@ int ensure_workspace(bsr_handle* h, int B, int H, int W, hipStream_t s) {
 
 extern "C" {
 
-int bsr_abi_version(void) { return 7; }
+int bsr_abi_version(void) { return 8; }
 
 #ifndef BSR_SRC_SHA
 #define BSR_SRC_SHA "unhashed"
@@ -848,6 +848,21 @@ int bsr_prep_rows(int device, const void* d_blob, size_t blob_bytes, size_t rows
                      reinterpret_cast<const double*>(blob + grid_off), S, out, hull_tmp);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(bsr::prep_blur_kernel, grid, dim3(256), 0, s, hull_tmp, S, out);
+  HIP_TRY(hipGetLastError());
+  return BSR_OK;
+}
+
+int bsr_png_unfilter(int device, void* d_blob, size_t blob_bytes, size_t items_off, int n, void* stream) {
+  if (d_blob == nullptr) return fail(BSR_ERR_ARG, "bsr_png_unfilter: null argument");
+  if (n <= 0 || items_off % 8 != 0) return fail(BSR_ERR_ARG, "bsr_png_unfilter: n must be positive and items_off 8-byte aligned");
+  // the item table must lie inside the blob; what its records point to is validated by the caller before the upload (prep.py), as for bsr_prep_rows
+  if (items_off > blob_bytes || (size_t)n * sizeof(bsr::UnfilterItem) > blob_bytes - items_off)
+    return fail(BSR_ERR_ARG, "bsr_png_unfilter: the item table does not fit in blob_bytes");
+  DeviceGuard guard(device);
+  HIP_TRY(guard.err);
+  unsigned char* blob = static_cast<unsigned char*>(d_blob);
+  hipLaunchKernelGGL(bsr::png_unfilter_kernel, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), blob,
+                     reinterpret_cast<const bsr::UnfilterItem*>(blob + items_off));
   HIP_TRY(hipGetLastError());
   return BSR_OK;
 }

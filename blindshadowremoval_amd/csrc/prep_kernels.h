@@ -180,4 +180,83 @@ __global__ __launch_bounds__(256) void prep_blur_kernel(const float* __restrict_
   out[((size_t)blockIdx.y * S * S + pix) * 16 + 15] = (float)acc;
 }
 
+// ---- PNG scanline reconstruction on the device (round 6) ----
+// The loaders' workers inflate a PNG file and stop there: the FILTERED scanlines (RFC 2083 section 6: per row one filter-type byte, then
+// w * c bytes, each the difference to a predictor built from the pixel to the left, the pixel above and the one above-left) travel in the
+// item's ring slot as they are, and this kernel reconstructs the RGB8 image the preparation kernel reads — what hostsrc/png_unfilter.c
+// did in the worker (17 % of a worker's time per item).  A row depends on the row above and, for the Average / Paeth filters, a pixel on
+// its left neighbour, so the parallelism is the anti-diagonal: thread y owns row y and at step t reconstructs pixel x = t - y; the pixel
+// above (thread y - 1, step t - 1) comes through a double-buffered LDS word per thread, left and above-left are the thread's own registers.
+// One workgroup per image, rows in bands of 256; c = 1 (grey: replicated), 3 or 4 (alpha dropped: channels never mix).
+struct UnfilterItem {
+  int64_t raw_off, out_off;   // bytes from the blob start: h x (1 + w c) filtered scanlines -> RGB8 [h][w][3]
+  int32_t h, w, c, pad;
+};
+
+__device__ __forceinline__ int png_paeth(int a, int b, int c) {      // a = left, b = above, c = above-left
+  const int p = a + b - c;
+  const int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+__global__ __launch_bounds__(256) void png_unfilter_kernel(unsigned char* __restrict__ blob, const UnfilterItem* __restrict__ items) {
+  __shared__ unsigned s_px[2][256];
+  const UnfilterItem it = items[blockIdx.x];
+  const int tid = threadIdx.x, h = it.h, w = it.w, c = it.c;
+  const int nch = c == 1 ? 1 : 3;                               // channels reconstructed (alpha is never needed: channels do not mix)
+  const size_t rb = 1 + (size_t)w * c;
+  const unsigned char* raw = blob + it.raw_off;
+  unsigned char* out = blob + it.out_off;
+  for (int y0 = 0; y0 < h; y0 += 256) {
+    const int y = y0 + tid, nrows = min(256, h - y0);
+    const bool row = y < h;
+    const unsigned char* rp = raw + (size_t)(row ? y : 0) * rb;
+    unsigned char* op = out + (size_t)(row ? y : 0) * w * 3;
+    const int ft = row ? rp[0] : 0;
+    rp += 1;
+    const unsigned char* upg = (tid == 0 && y0 > 0) ? op - (size_t)w * 3 : nullptr;     // the band's first row: the row above is in `out` already
+    int left[3] = {0, 0, 0}, upl[3] = {0, 0, 0}, nxt[3] = {0, 0, 0};
+    if (row && tid == 0)
+      for (int k = 0; k < nch; ++k) nxt[k] = rp[k];
+    const int steps = w + nrows - 1;
+    for (int t = 0; t < steps; ++t) {
+      const int x = t - tid;
+      const bool act = row && x >= 0 && x < w;
+      if (act) {
+        int up[3] = {0, 0, 0};
+        if (tid > 0) {
+          const unsigned v = s_px[(t - 1) & 1][tid - 1];
+          up[0] = v & 255; up[1] = (v >> 8) & 255; up[2] = (v >> 16) & 255;
+        } else if (upg != nullptr) {
+          up[0] = upg[3 * x]; up[1] = upg[3 * x + 1]; up[2] = upg[3 * x + 2];
+        }
+        int o[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (k < nch) {
+            int pred = 0;
+            if (ft == 1) pred = left[k];
+            else if (ft == 2) pred = up[k];
+            else if (ft == 3) pred = (left[k] + up[k]) >> 1;
+            else if (ft == 4) pred = png_paeth(left[k], up[k], upl[k]);
+            o[k] = (nxt[k] + pred) & 255;
+            left[k] = o[k];
+            upl[k] = up[k];
+          }
+        }
+        if (nch == 1) { o[1] = o[0]; o[2] = o[0]; }
+        s_px[t & 1][tid] = (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16);
+        op[3 * x] = (unsigned char)o[0]; op[3 * x + 1] = (unsigned char)o[1]; op[3 * x + 2] = (unsigned char)o[2];
+      }
+      // the next step's filtered bytes are requested before the barrier (this thread's row: x + 1, or x = 0 when its turn begins)
+      const int xn = t + 1 - tid;
+      if (row && xn >= 0 && xn < w)
+        for (int k = 0; k < nch; ++k) nxt[k] = rp[(size_t)xn * c + k];
+      __syncthreads();
+    }
+    __threadfence_block();                                      // the band's last row is the next band's "above", read from `out`
+    __syncthreads();
+  }
+}
+
 }  // namespace bsr
