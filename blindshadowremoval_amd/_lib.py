@@ -9,7 +9,7 @@ from typing import Optional
 from . import build as _build
 from .build import LIB_PATH
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 NUM_CLASSES = 7
 CLASS_NAMES = ("conv3x3", "convT3x3", "conv1x1", "attention", "conv7", "glue", "convT3x3_ni2")
 
@@ -17,7 +17,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 # every symbol include/bsr_hip.h declares
 EXPORTS = ("bsr_create", "bsr_forward", "bsr_forward_tsm", "bsr_workspace_bytes", "bsr_reserve", "bsr_probe", "bsr_set_timing",
-           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_debug_split_qkv", "bsr_clock_trace", "bsr_debug_attention_split", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_forward_packed", "bsr_source_sha", "bsr_peek_range", "bsr_png_file_bytes", "bsr_png_scratch_bytes", "bsr_png_encode", "bsr_png_encode_figs", "bsr_ucb_post_scratch_bytes", "bsr_ucb_post")
+           "bsr_get_timing", "bsr_timing_launches", "bsr_timing_entry", "bsr_handle_workspace_bytes", "bsr_debug_attention", "bsr_debug_attention_dtype", "bsr_debug_attention_qw", "bsr_debug_split_qkv", "bsr_clock_trace", "bsr_debug_attention_split", "bsr_destroy", "bsr_last_error", "bsr_abi_version", "bsr_check_range", "bsr_prep_rows", "bsr_png_unfilter", "bsr_forward_packed", "bsr_source_sha", "bsr_peek_range", "bsr_png_file_bytes", "bsr_png_scratch_bytes", "bsr_png_encode", "bsr_png_encode_figs", "bsr_ucb_post_scratch_bytes", "bsr_ucb_post")
 
 
 def load() -> ctypes.CDLL:
@@ -86,6 +86,8 @@ def load() -> ctypes.CDLL:
     lib.bsr_debug_attention_qw.restype = c_i
     lib.bsr_prep_rows.argtypes = [c_i, c_v, c_sz, c_sz, c_sz, c_i, c_i, c_v, c_v, c_v]
     lib.bsr_prep_rows.restype = c_i
+    lib.bsr_png_unfilter.argtypes = [c_i, c_v, c_sz, c_sz, c_i, c_v]
+    lib.bsr_png_unfilter.restype = c_i
     lib.bsr_check_range.argtypes = [c_v, c_v]
     lib.bsr_check_range.restype = c_i
     lib.bsr_png_file_bytes.argtypes = [c_i, c_i]

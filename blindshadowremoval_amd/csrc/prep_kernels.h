@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void prep_blur_kernel(const float* __restrict_
 // did in the worker (17 % of a worker's time per item).  A row depends on the row above and, for the Average / Paeth filters, a pixel on
 // its left neighbour, so the parallelism is the anti-diagonal: thread y owns row y and at step t reconstructs pixel x = t - y; the pixel
 // above (thread y - 1, step t - 1) comes through a double-buffered LDS word per thread, left and above-left are the thread's own registers.
-// One workgroup per image, rows in bands of 256; c = 1 (grey: replicated), 3 or 4 (alpha dropped: channels never mix).
+// One workgroup per image of at most 256 rows; c = 1 (grey: replicated), 3 or 4 (alpha dropped: channels never mix).
 struct UnfilterItem {
   int64_t raw_off, out_off;   // bytes from the blob start: h x (1 + w c) filtered scanlines -> RGB8 [h][w][3]
   int32_t h, w, c, pad;
@@ -199,64 +199,97 @@ __device__ __forceinline__ int png_paeth(int a, int b, int c) {      // a = left
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+constexpr int kUnfilterMaxRows = 256;    // one workgroup, one thread per row (the reference's images are 256 x 256; taller ones are reconstructed by the worker)
+constexpr int kUnfilterSlack = 16;       // readable bytes the caller guarantees in front of and behind every filtered image (inside the blob)
+
+// One image.  A thread walks its row in GROUPS of four pixels: the 4 C filtered bytes of a group are ONE unaligned load (global memory
+// takes any byte address on gfx950) requested four groups = sixteen steps before their turn, the group's 12 output bytes ONE store —
+// vmcnt retires in order, loads behind stores, so every memory instruction between a request and its use delays it: with a load and
+// two byte stores per STEP the kernel waited for a memory round trip per step (0.45-0.58 ms per batch of 16 images).  No load stands
+// inside a divergent branch (behind one the compiler drains vmcnt at the join), and the step's barrier waits for the wave's LDS word only.
+template <int C>
+__device__ __forceinline__ void png_unfilter_image(unsigned char* __restrict__ blob, const UnfilterItem& it, unsigned (*s_px)[256]) {
+  constexpr int NCH = C == 1 ? 1 : 3;                           // channels reconstructed (alpha is never needed: channels do not mix)
+  const int tid = threadIdx.x, h = min(it.h, kUnfilterMaxRows), w = it.w;
+  const size_t rb = 1 + (size_t)w * C;
+  const bool row = tid < h;
+  const unsigned char* rp = blob + it.raw_off + (size_t)(row ? tid : 0) * rb;
+  unsigned char* op = blob + it.out_off + (size_t)(row ? tid : 0) * w * 3;
+  const int ft = row ? rp[0] : 0;
+  rp += 1;
+  struct Group { unsigned d[C]; };
+  auto fetch = [&](int x0) -> Group {                           // pixels x0 .. x0 + 3 (a group without a pixel of the row: any readable address)
+    const unsigned char* q = rp + ((x0 <= -4 || x0 >= w) ? 0 : x0 * C);
+    Group g;
+    __builtin_memcpy(g.d, q, 4 * C);
+    return g;
+  };
+  int left[3] = {0, 0, 0}, upl[3] = {0, 0, 0};
+  const int m1 = -(int)(ft == 1), m2 = -(int)(ft == 2), m3 = -(int)(ft == 3), m4 = -(int)(ft == 4);      // all ones for the row's filter type
+  Group win[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) win[i] = fetch(4 * i - tid);
+  const int steps = (w + h - 1 + 15) & ~15;
+  for (int t = 0; t < steps; t += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x0 = t + 4 * i - tid;
+      const Group g = win[i];
+      unsigned od[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = x0 + k;
+        const bool act = row && x >= 0 && x < w;
+        const unsigned above = s_px[(k + 1) & 1][tid > 0 ? tid - 1 : 0];      // thread tid - 1 wrote its pixel x one step ago (step parity = k & 1: t + 4 i is even)
+        int up[3];
+        up[0] = tid > 0 ? (int)(above & 255u) : 0; up[1] = tid > 0 ? (int)((above >> 8) & 255u) : 0; up[2] = tid > 0 ? (int)((above >> 16) & 255u) : 0;
+        // branch-free: rows of one wave carry different filter types, and every `if` on them costs the wave all its sides plus the exec-mask
+        // bookkeeping (the first version: ~250 instructions per step); an idle thread computes on and keeps its state by the selects
+        int o[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          if (ch < NCH) {
+            const int bi = k * C + ch;                          // byte of the group
+            const int a = left[ch], b = up[ch], c0 = upl[ch];
+            const int pa = abs(b - c0), pb = abs(a - c0), pc = abs(a + b - 2 * c0);
+            const int paeth = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c0);
+            const int pred = (a & m1) | (b & m2) | (((a + b) >> 1) & m3) | (paeth & m4);      // (masks, not selects: the compiler turns a select chain on the filter type back into branches)
+            o[ch] = (int)(((g.d[bi >> 2] >> (8 * (bi & 3))) & 255u) + (unsigned)pred) & 255;
+            left[ch] = act ? o[ch] : left[ch];
+            upl[ch] = act ? b : upl[ch];
+          }
+        }
+        if (NCH == 1) { o[1] = o[0]; o[2] = o[0]; }
+        const unsigned px = (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16);
+        if (act) s_px[k & 1][tid] = px;
+        {
+          const int sh = 8 * ((3 * k) & 3), dw = (3 * k) >> 2;          // the pixel's 24 bits into the group's 96 (static: k is unrolled)
+          od[dw] |= px << sh;
+          if (sh > 8) od[dw + 1] |= px >> (32 - sh);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      // the group's output: one 12-byte store; a group that straddles an end of the row goes bytewise
+      if (row && x0 >= 0 && x0 + 3 < w) {
+        __builtin_memcpy(op + 3 * (size_t)x0, od, 12);
+      } else if (row && x0 > -4 && x0 < w) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (x0 + k >= 0 && x0 + k < w)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) op[3 * (x0 + k) + ch] = (unsigned char)(od[(3 * k + ch) >> 2] >> (8 * ((3 * k + ch) & 3)));
+      }
+      win[i] = fetch(x0 + 16);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void png_unfilter_kernel(unsigned char* __restrict__ blob, const UnfilterItem* __restrict__ items) {
   __shared__ unsigned s_px[2][256];
   const UnfilterItem it = items[blockIdx.x];
-  const int tid = threadIdx.x, h = it.h, w = it.w, c = it.c;
-  const int nch = c == 1 ? 1 : 3;                               // channels reconstructed (alpha is never needed: channels do not mix)
-  const size_t rb = 1 + (size_t)w * c;
-  const unsigned char* raw = blob + it.raw_off;
-  unsigned char* out = blob + it.out_off;
-  for (int y0 = 0; y0 < h; y0 += 256) {
-    const int y = y0 + tid, nrows = min(256, h - y0);
-    const bool row = y < h;
-    const unsigned char* rp = raw + (size_t)(row ? y : 0) * rb;
-    unsigned char* op = out + (size_t)(row ? y : 0) * w * 3;
-    const int ft = row ? rp[0] : 0;
-    rp += 1;
-    const unsigned char* upg = (tid == 0 && y0 > 0) ? op - (size_t)w * 3 : nullptr;     // the band's first row: the row above is in `out` already
-    int left[3] = {0, 0, 0}, upl[3] = {0, 0, 0}, nxt[3] = {0, 0, 0};
-    if (row && tid == 0)
-      for (int k = 0; k < nch; ++k) nxt[k] = rp[k];
-    const int steps = w + nrows - 1;
-    for (int t = 0; t < steps; ++t) {
-      const int x = t - tid;
-      const bool act = row && x >= 0 && x < w;
-      if (act) {
-        int up[3] = {0, 0, 0};
-        if (tid > 0) {
-          const unsigned v = s_px[(t - 1) & 1][tid - 1];
-          up[0] = v & 255; up[1] = (v >> 8) & 255; up[2] = (v >> 16) & 255;
-        } else if (upg != nullptr) {
-          up[0] = upg[3 * x]; up[1] = upg[3 * x + 1]; up[2] = upg[3 * x + 2];
-        }
-        int o[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          if (k < nch) {
-            int pred = 0;
-            if (ft == 1) pred = left[k];
-            else if (ft == 2) pred = up[k];
-            else if (ft == 3) pred = (left[k] + up[k]) >> 1;
-            else if (ft == 4) pred = png_paeth(left[k], up[k], upl[k]);
-            o[k] = (nxt[k] + pred) & 255;
-            left[k] = o[k];
-            upl[k] = up[k];
-          }
-        }
-        if (nch == 1) { o[1] = o[0]; o[2] = o[0]; }
-        s_px[t & 1][tid] = (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16);
-        op[3 * x] = (unsigned char)o[0]; op[3 * x + 1] = (unsigned char)o[1]; op[3 * x + 2] = (unsigned char)o[2];
-      }
-      // the next step's filtered bytes are requested before the barrier (this thread's row: x + 1, or x = 0 when its turn begins)
-      const int xn = t + 1 - tid;
-      if (row && xn >= 0 && xn < w)
-        for (int k = 0; k < nch; ++k) nxt[k] = rp[(size_t)xn * c + k];
-      __syncthreads();
-    }
-    __threadfence_block();                                      // the band's last row is the next band's "above", read from `out`
-    __syncthreads();
-  }
+  if (it.c == 3) png_unfilter_image<3>(blob, it, s_px);
+  else if (it.c == 4) png_unfilter_image<4>(blob, it, s_px);
+  else png_unfilter_image<1>(blob, it, s_px);
 }
 
 }  // namespace bsr

@@ -336,6 +336,11 @@ class Dataset:
         if device_prep is not None and (rows != 1 or dset is not None):
             raise NotImplementedError("device_prep prepares row 0 of the GSC loaders (rows=1, dset=None)")
         self.ucb_mask_files: Optional[List[Dict[str, str]]] = None       # per item of name_list: the seven mask paths (FSRNet.test sets it; device_prep only)
+        # round 6: PNG scanline reconstruction on the device (prep.host_part_ring / bsr_png_unfilter) instead of in the workers.  None =
+        # where it pays: the UCB loop (two photographs and seven masks per item: the loop waits for its loader; +5-10 % measured) and not
+        # the FFHQ one (one photograph per item: the GPU side is the longer one there, and the kernel is 0.17 ms per batch of it; -3 %).
+        # BSR_DEVICE_UNFILTER=0 / 1 overrides.
+        self.device_unfilter: Optional[bool] = None
         self.name_list: List[str] = []
         pattern = "*.npy" if dset is None else "*_label.png"               # dataset.py:55-61 | dataset_with_TSM.py:63
         for d in config.DATA_DIR_TEST:
@@ -398,7 +403,9 @@ class Dataset:
                         if not self._ring_copies[0][2]:
                             self._ring_copies[0][1].synchronize()
                             self._ring_copies[0][2] = True
-                    job = job + ((ring.path_for_workers, k % ring.nslots, ring.cap),)
+                    unf = self.device_unfilter if self.device_unfilter is not None else (self.ucb and masks is not None)
+                    unf = {"0": False, "1": True}.get(os.environ.get("BSR_DEVICE_UNFILTER", ""), unf)
+                    job = job + ((ring.path_for_workers, k % ring.nslots, ring.cap, bool(unf)),)
                 yield job
             else:
                 yield (lm_path, gt, sibs, size)

@@ -130,9 +130,88 @@ def read_rgb_u8(path: str) -> np.ndarray:
         import io
         from PIL import Image
         return np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(b)).convert("RGB"), np.uint8))
+    return _to_rgb(a)
+
+
+class RawScanlines:
+    """An inflated, still FILTERED 8-bit PNG image: `raw` = h x (1 + w c) bytes (filter-type byte first), c = 1 | 3 | 4.  What a
+    loader's worker hands over when the scanline reconstruction runs on the device (csrc/prep_kernels.h png_unfilter_kernel)."""
+    __slots__ = ("h", "w", "c", "raw")
+
+    def __init__(self, h: int, w: int, c: int, raw: np.ndarray):
+        self.h, self.w, self.c, self.raw = int(h), int(w), int(c), raw
+
+    @property
+    def shape(self):                       # of the RGB image it reconstructs to
+        return (self.h, self.w, 3)
+
+    @property
+    def nbytes(self) -> int:
+        return int(self.raw.nbytes)
+
+    def decode(self) -> np.ndarray:
+        """The RGB8 image on the host (= read_rgb_u8 of the file): the C reconstruction, or PIL's arithmetic restated in numpy without it."""
+        return _to_rgb(unfilter_host(self.raw, self.h, self.w, self.c))
+
+
+def _to_rgb(a: np.ndarray) -> np.ndarray:
     if a.shape[2] == 3:
         return a
     return np.repeat(a, 3, axis=2) if a.shape[2] == 1 else np.ascontiguousarray(a[:, :, :3])
+
+
+def unfilter_host(raw: np.ndarray, h: int, w: int, c: int) -> np.ndarray:
+    """Filtered scanlines -> uint8 [h,w,c] on the host: libbsr_host.so, or (no C compiler) a plain numpy statement of RFC 2083 section 6."""
+    raw = np.ascontiguousarray(raw, np.uint8).reshape(-1)
+    if raw.size != h * (1 + w * c):
+        raise ValueError("unfilter_host: %d bytes for a %dx%dx%d image" % (raw.size, h, w, c))
+    lib = _host_lib()
+    if lib is not None:
+        out = np.empty((h, w, c), np.uint8)
+        if lib.bsr_png_unfilter(raw.ctypes.data, h, w * c, c, out.ctypes.data) == 0:
+            return out
+        raise ValueError("unfilter_host: a scanline has a filter type above 4")
+    rows = raw.reshape(h, 1 + w * c)
+    out = np.zeros((h, w * c), np.int32)
+    for y in range(h):
+        ft, f = int(rows[y, 0]), rows[y, 1:].astype(np.int32)
+        up = out[y - 1] if y > 0 else np.zeros(w * c, np.int32)
+        if ft == 0:
+            out[y] = f
+        elif ft == 2:
+            out[y] = (f + up) & 255
+        elif ft in (1, 3, 4):
+            for i in range(w * c):
+                a = out[y, i - c] if i >= c else 0
+                b = up[i]
+                cc = up[i - c] if i >= c else 0
+                if ft == 1:
+                    pr = a
+                elif ft == 3:
+                    pr = (a + b) >> 1
+                else:
+                    p0 = a + b - cc
+                    pa, pb, pc = abs(p0 - a), abs(p0 - b), abs(p0 - cc)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)
+                out[y, i] = (f[i] + pr) & 255
+        else:
+            raise ValueError("unfilter_host: filter type %d" % ft)
+    return out.astype(np.uint8).reshape(h, w, c)
+
+
+def read_rgb_raw(path: str):
+    """An image file for the DEVICE reconstruction: RawScanlines (the inflated stream of a plain 8-bit grey / RGB / RGBA PNG — the
+    worker stops after the inflate) or, for every other file, the decoded uint8 [H,W,3] image exactly as read_rgb_u8 returns it."""
+    with open(path, "rb") as f:
+        b = f.read()
+    try:
+        _host_lib()                                            # (its inflate, when there is one)
+        w, h, c, raw = _parse_8bit(b)
+        return RawScanlines(h, w, c, raw)
+    except (ValueError, TypeError, struct.error, zlib.error):
+        import io
+        from PIL import Image
+        return np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(b)).convert("RGB"), np.uint8))
 
 
 def read_grey_u8(path: str) -> np.ndarray:

@@ -32,6 +32,16 @@ def _imread_u8(path: str) -> np.ndarray:
     return read_rgb_u8(path)
 
 
+def _imread_raw(path: str):
+    from .pngio import read_rgb_raw           # round 6: the worker stops after the inflate, the scanlines are reconstructed on the device
+    return read_rgb_raw(path)
+
+
+UNFILTER_DTYPE = np.dtype([("raw_off", "<i8"), ("out_off", "<i8"), ("h", "<i4"), ("w", "<i4"), ("c", "<i4"), ("pad", "<i4")], align=True)
+assert UNFILTER_DTYPE.itemsize == 32          # csrc/prep_kernels.h UnfilterItem
+UNFILTER_MAX_ROWS = 256                       # csrc/prep_kernels.h kUnfilterMaxRows: one workgroup, one thread per row
+
+
 def _tri_table(tri, zs: Sequence[np.ndarray]) -> np.ndarray:
     """[ntri, 18] float64: three edge functions (normalised barycentrics l_i = A_i x + B_i y + C_i) + up to three channels of
     plane coefficients (a, b, c), the latter from matplotlib's own `calculate_plane_coefficients` (what LinearTriInterpolator uses)."""
@@ -134,16 +144,18 @@ def unpack_masks(packed: Sequence[tuple], device):
     return torch.from_numpy(np.stack(full, axis=0)).to(device, non_blocking=True)
 
 
-def host_part(job):
-    """(lm_path, gt_path, size[, mask paths]) -> the host half of one row: (img u8, gt u8 | None, box, [4 triangle tables], name[, packed masks])."""
+def host_part(job, raw: bool = False):
+    """(lm_path, gt_path, size[, mask paths]) -> the host half of one row: (img u8, gt u8 | None, box, [4 triangle tables], name[, packed masks]).
+    raw = True (the ring path, round 6): img / gt may be pngio.RawScanlines — inflated, still filtered; the device reconstructs them."""
     masks = None
     if len(job) > 3:
         masks = pack_masks(job[3])
         job = job[:3]
     lm_path, gt_path, size = job
     img_path = os.path.splitext(lm_path)[0] + ".png"
-    img = _imread_u8(img_path)
-    gt = _imread_u8(gt_path) if gt_path else None
+    read = _imread_raw if raw else _imread_u8
+    img = read(img_path)
+    gt = read(gt_path) if gt_path else None
     if gt is not None and gt.shape != img.shape:
         raise ValueError("ground truth %s and image %s differ in size" % (gt_path, img_path))
     box, lm = crop_box(np.load(lm_path))
@@ -164,18 +176,27 @@ def host_part_ring(job, ring):
     the worker's pipe: -> ("ring", slot, (h, w), has_gt, image offsets, table offsets, table lengths, box, name, mask record | None,
     bytes used) — a few hundred bytes.  The loop's own thread then neither reads, unpickles nor repacks the ~0.5 MB of an item (0.1 ms
     per item of the one thread every batch goes through): the slot goes to the device as it lies, by one copy per batch.  An item that
-    does not fit a slot comes back the old way."""
-    path, slot, cap = ring
-    part = host_part(job)
+    does not fit a slot comes back the old way.  Round 6: images that are plain 8-bit PNG files lie in the slot as their inflated,
+    still FILTERED scanlines (the last tuple element: channels per image, 0 = decoded RGB) and are reconstructed on the device
+    (bsr_png_unfilter) when the job's ring tuple says so (its 4th element: dataset.Dataset.device_unfilter)."""
+    path, slot, cap = ring[:3]
+    use_raw = bool(ring[3]) if len(ring) > 3 else False       # dataset.Dataset.device_unfilter decides
+    part = host_part(job, raw=use_raw)
     img, gt, box, tabs, name = part[:5]
+    # the device kernel takes images of at most UNFILTER_MAX_ROWS rows whose scanlines hold at least one dword; anything else is decoded here
+    fits = lambda a: not hasattr(a, "raw") or (a.h <= UNFILTER_MAX_ROWS and a.w * a.c >= 4)
+    if not (fits(img) and (gt is None or fits(gt))):
+        img, gt = (img.decode() if hasattr(img, "raw") else img), (gt.decode() if gt is not None and hasattr(gt, "raw") else gt)
     masks = part[5] if len(part) > 5 else None
-    arrays = [img] + ([gt] if gt is not None else []) + list(tabs) + ([masks[1]] if masks is not None else [])
+    rawc = tuple(int(getattr(a, "c", 0)) if hasattr(a, "raw") else 0 for a in ([img] + ([gt] if gt is not None else [])))
+    arrays = [getattr(a, "raw", a) for a in ([img] + ([gt] if gt is not None else []))] + list(tabs) + ([masks[1]] if masks is not None else [])
     offs, off = [], 0
     for a in arrays:
         offs.append(off)
         off = (off + a.nbytes + 7) & ~7
-    if off > cap:
-        return part
+    if off > cap:                                  # through the pipe after all: decoded here
+        dec = lambda a: a.decode() if hasattr(a, "raw") else a
+        return (dec(img), dec(gt) if gt is not None else None) + tuple(part[2:])
     view = _RING_VIEWS.get(path)
     if view is None:
         view = _RING_VIEWS[path] = np.memmap(path, np.uint8, "r+")
@@ -186,7 +207,7 @@ def host_part_ring(job, ring):
     k = 2 if gt is not None else 1
     mrec = None if masks is None else (masks[0], int(masks[2]), offs[k + 4], int(masks[1].nbytes))
     return ("ring", int(slot), (int(img.shape[0]), int(img.shape[1])), gt is not None, tuple(offs[:k]), tuple(offs[k:k + 4]),
-            tuple(int(t.shape[0]) for t in tabs), np.asarray(box, np.int32), name, mrec, off)
+            tuple(int(t.shape[0]) for t in tabs), np.asarray(box, np.int32), name, mrec, off, rawc)
 
 
 class SlotRing:
@@ -246,7 +267,7 @@ class SlotRing:
 
 def _layout(parts, size: int):
     """The blob of a batch of `host_part` results that all came through the pipe: see _layout_ex."""
-    total, rows_off, grid_off, pieces, _, cells = _layout_ex(parts, size, RING_CAP)
+    total, rows_off, grid_off, pieces, _, cells, _ = _layout_ex(parts, size, RING_CAP)
     if cells:
         raise ValueError("_layout: ring items need DevicePrep.rows_ex")
     return total, rows_off, grid_off, pieces
@@ -254,9 +275,10 @@ def _layout(parts, size: int):
 
 def _layout_ex(parts, size: int, cap: int):
     """Offsets of every section of the blob (all 8-byte aligned): -> (total bytes, rows_off, grid_off, [(offset, array)], head bytes,
-    ring cells).  Items that came through the pipe are packed behind the records (the `head`, staged by the caller); every ring item
-    gets one `cap`-byte cell behind the head, in batch order — cells = [(part index, slot, cell offset)] — which the caller fills
-    with the slot's bytes."""
+    ring cells, (unfilter table offset, records)).  Items that came through the pipe are packed behind the records (the `head`, staged
+    by the caller); every ring item gets one `cap`-byte cell behind the head, in batch order — cells = [(part index, slot, cell
+    offset)] — which the caller fills with the slot's bytes.  Ring images that lie in their slot as filtered scanlines (round 6) get
+    a record in the unfilter table (in the head) and an output area behind the cells, where the row records then point."""
     B = len(parts)
     rows = np.zeros(B, ROW_DTYPE)
     pieces = []
@@ -289,8 +311,13 @@ def _layout_ex(parts, size: int, cap: int):
             r["ntri"][m] = t.shape[0]
             pieces.append((int(r["tri_off"][m]), t))
     pieces.append((rows_off, rows))
-    head, cells = off, []
     ring_idx = [i for i, part in enumerate(parts) if _is_ring(part)]
+    n_unf = sum(sum(1 for c in (parts[i][11] if len(parts[i]) > 11 else ()) if c) for i in ring_idx)
+    unf = np.zeros(n_unf, UNFILTER_DTYPE)
+    unf_off = take(max(n_unf, 1) * UNFILTER_DTYPE.itemsize)
+    if n_unf:
+        pieces.append((unf_off, unf))
+    head, cells = off, []
     if ring_idx:
         # the records of the ring items in whole columns (per-field assignments on a structured array cost ~15 us each: 0.3 ms per batch
         # of the loop's own thread when done item by item)
@@ -305,15 +332,36 @@ def _layout_ex(parts, size: int, cap: int):
         toff = np.array([p[5] for p in rp], np.int64).reshape(n, 4)
         ntri = np.array([p[6] for p in rp], np.int64).reshape(n, 4)
         used = np.array([p[10] for p in rp], np.int64)
+        rawc = np.array([(tuple(p[11]) + (0, 0))[:2] if len(p) > 11 else (0, 0) for p in rp], np.int64).reshape(n, 2)
+        rawc[:, 1] = np.where(has_gt, rawc[:, 1], rawc[:, 0])
+        if ((rawc != 0) & (rawc != 1) & (rawc != 3) & (rawc != 4)).any():
+            raise ValueError("prep blob: a ring item names %s channels per filtered pixel" % sorted(set(rawc.reshape(-1).tolist())))
+        if ((rawc > 0) & ((hw[:, :1] > UNFILTER_MAX_ROWS) | (hw[:, 1:2] * rawc < 4))).any():
+            raise ValueError("prep blob: a filtered ring image has more than %d rows or scanlines under 4 bytes" % UNFILTER_MAX_ROWS)
+        nb = np.where(rawc > 0, hw[:, :1] * (1 + hw[:, 1:2] * rawc), hw[:, :1] * hw[:, 1:2] * 3)      # bytes of each image as it lies in the slot
         npx = hw[:, 0] * hw[:, 1] * 3
-        ends = np.maximum(np.maximum(io0, io1) + npx, (toff + ntri * (TRI_DOUBLES * 8)).max(axis=1))
+        ends = np.maximum(np.maximum(io0 + nb[:, 0], io1 + nb[:, 1]), (toff + ntri * (TRI_DOUBLES * 8)).max(axis=1))
         bad = (used > cap) | (np.minimum(np.minimum(io0, io1), toff.min(axis=1)) < 0) | (ends > cap) | (hw.min(axis=1) < 0) | (ntri.min(axis=1) < 0)
         if bad.any():
             raise ValueError("prep blob: ring item %d points outside its slot (%d-byte slots)" % (ring_idx[int(np.argmax(bad))], cap))
         sel = np.array(ring_idx)
         rows["h"][sel], rows["w"][sel] = hw[:, 0], hw[:, 1]
-        rows["img_off"][sel] = bases + io0
-        rows["gt_off"][sel] = bases + io1
+        img_at, gt_at = bases + io0, bases + io1
+        if n_unf:
+            # filtered images: reconstructed into their own area behind the cells (bsr_png_unfilter), the row record points there.  Whole
+            # columns again (a Python loop over the images of a batch of 32 cost the loop's thread ~1 ms per batch)
+            sel01 = np.stack([rawc[:, 0] > 0, has_gt & (rawc[:, 1] > 0)], axis=1).reshape(-1)
+            jj, ww = np.repeat(np.arange(n), 2)[sel01], np.tile(np.array([0, 1]), n)[sel01]
+            sizes = (npx[jj] + 7) & ~7
+            outs = off + np.cumsum(sizes) - sizes
+            off += int(sizes.sum())
+            unf["raw_off"] = np.where(ww == 0, img_at[jj], gt_at[jj])
+            unf["out_off"], unf["h"], unf["w"], unf["c"] = outs, hw[jj, 0], hw[jj, 1], rawc[jj, ww]
+            img_at[jj[ww == 0]] = outs[ww == 0]
+            gt_at[jj[ww == 1]] = outs[ww == 1]
+            gt_at = np.where(has_gt, gt_at, img_at)
+        rows["img_off"][sel] = img_at
+        rows["gt_off"][sel] = gt_at
         rows["box"][sel] = np.stack([np.asarray(p[7], np.int32).reshape(4) for p in rp])
         rows["tri_off"][sel] = bases[:, None] + toff
         rows["ntri"][sel] = ntri
@@ -325,7 +373,7 @@ def _layout_ex(parts, size: int, cap: int):
     bad = (lows < 0) | (ends > off) | (rows["ntri"].max(axis=1) > MAX_TRI) | (rows["ntri"].min(axis=1) < 0) | (h64 < 0) | (w64 < 0)
     if bad.any():
         raise ValueError("prep blob: row %d points outside the %d-byte blob" % (int(np.argmax(bad)), off))
-    return off, rows_off, grid_off, pieces, head, cells
+    return off, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf)
 
 
 def pack_into(buf: np.ndarray, pieces) -> None:
@@ -372,7 +420,7 @@ class DevicePrep:
         B, S = len(parts), self.size
         ring = getattr(self, "ring", None)
         cap = ring.cap if ring is not None else RING_CAP
-        total, rows_off, grid_off, pieces, head, cells = _layout_ex(parts, S, cap)
+        total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf) = _layout_ex(parts, S, cap)
         if cells and ring is None:
             raise RuntimeError("DevicePrep.rows_ex: ring records without a ring")
         dev = "cuda:%d" % self.device
@@ -411,6 +459,8 @@ class DevicePrep:
                 if side:
                     out = torch.empty((B, S, S, 16), dtype=torch.float32, device=dev)
                     tmp = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+                    if n_unf:                      # the filtered images of the ring items become RGB8 where their row records point
+                        self._check(self._lib.bsr_png_unfilter(self.device, d_blob.data_ptr(), total, unf_off, n_unf, self._h2d.cuda_stream), "bsr_png_unfilter")
                     rc = self._lib.bsr_prep_rows(self.device, d_blob.data_ptr(), total, rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
                                                  self._h2d.cuda_stream)
                     done = torch.cuda.Event()
@@ -424,6 +474,8 @@ class DevicePrep:
             if not side:
                 out = torch.empty((B, S, S, 16), dtype=torch.float32, device=dev)
                 tmp = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+                if n_unf:
+                    self._check(self._lib.bsr_png_unfilter(self.device, d_blob.data_ptr(), total, unf_off, n_unf, main.cuda_stream), "bsr_png_unfilter")
                 rc = self._lib.bsr_prep_rows(self.device, d_blob.data_ptr(), total, rows_off, grid_off, B, S, out.data_ptr(), tmp.data_ptr(),
                                              main.cuda_stream)
         self._check(rc, "bsr_prep_rows")

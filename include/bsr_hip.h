@@ -129,6 +129,16 @@ int bsr_timing_entry(bsr_handle* h, int i, char* name, size_t name_cap, float* m
 int bsr_prep_rows(int device, const void* d_blob, size_t blob_bytes, size_t rows_off, size_t grid_off, int B, int S, float* out, float* hull_tmp,
                   void* stream);
 
+/* PNG scanline reconstruction (RFC 2083 section 6) of n images on the device — what cv2.imread / PIL do after inflating a file
+ * (/root/reference/dataset.py:151,622: the images parse_fn_test / parse_fn_test_FFHQ read), moved behind the copy to the device so that a
+ * loader's worker stops at the inflated stream.  d_blob (device, blob_bytes): at items_off (8-byte aligned) n records
+ * { int64 raw_off, out_off; int32 h, w, c, pad } — raw_off: h x (1 + w c) bytes of FILTERED scanlines (filter-type byte first; c = 1
+ * grey, 3 RGB, 4 RGBA of an 8-bit non-interlaced file), out_off: where the RGB8 image [h][w][3] is written (grey replicated, alpha
+ * dropped — PIL's convert("RGB")); both inside the blob, validated by the caller like bsr_prep_rows' records: h <= 256 (one workgroup
+ * per image, one thread per row, pixels on the anti-diagonal), w c >= 4, and 16 readable bytes of the blob in front of and behind every
+ * filtered image (a thread reads its row four pixels at a time).  ABI 8. */
+int bsr_png_unfilter(int device, void* d_blob, size_t blob_bytes, size_t items_off, int n, void* stream);
+
 /* The output sink of the reference's loops on the device: replaces `cv2.imwrite(fname, strip)` of Logging.save_img
  * (/root/reference/utils.py:196-204; called per item from train_test_GSC.py:744-746 and :889-890) up to the write() itself.
  * pixels: [B,H,W,3] uint8 RGB strips (device).  out: B complete PNG FILE images, out_stride bytes apart (device or device-mapped

@@ -354,13 +354,36 @@ def test_loader_ring_slot_holds_what_the_pipe_would_carry(tmp_path, golden_dir):
     with open(path, "wb") as f:
         f.truncate(nslots * cap)
     slots = [2, 3, 0]                                                      # a batch that wraps around the end of the ring
-    recs = [D.build_element(j + ((path, s, cap),)) for j, s in zip(jobs, slots)]
     pipe = [D.build_element(j) for j in jobs]
-    assert all(r[0] == "ring" and r[1] == s and r[10] <= cap for r, s in zip(recs, slots))
+    # round 6: the images lie in the slot as inflated, still FILTERED scanlines; the blob gets an unfilter table (where the filtered bytes
+    # are, where the RGB image goes) and the row records point at the output areas behind the cells
+    recs = [D.build_element(j + ((path, s, cap, True),)) for j, s in zip(jobs, slots)]
+    assert all(r[11] == (3, 3) for r in recs)
+    ring = np.fromfile(path, np.uint8)
+    total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf) = prep._layout_ex(recs, 256, cap)
+    assert n_unf == 6 and unf_off + 6 * prep.UNFILTER_DTYPE.itemsize <= head and total == head + 3 * cap + 6 * ((256 * 256 * 3 + 7) & ~7)
+    blob = np.zeros(total, np.uint8)
+    prep.pack_into(blob, pieces)
+    for i, slot, base in cells:
+        blob[base:base + cap] = ring[slot * cap:(slot + 1) * cap]
+    unf = blob[unf_off:unf_off + 6 * prep.UNFILTER_DTYPE.itemsize].view(prep.UNFILTER_DTYPE)
+    rows = blob[rows_off:rows_off + 3 * prep.ROW_DTYPE.itemsize].view(prep.ROW_DTYPE)
+    from blindshadowremoval_amd import pngio
+    for k, u in enumerate(unf):
+        assert (u["h"], u["w"], u["c"]) == (256, 256, 3) and head + 3 * cap <= u["out_off"] and u["out_off"] + 256 * 256 * 3 <= total
+        img = pngio.unfilter_host(blob[u["raw_off"]:u["raw_off"] + 256 * 769], 256, 256, 3)
+        assert np.array_equal(img, pipe[k // 2][k % 2]) and u["out_off"] == rows[k // 2][("img_off", "gt_off")[k % 2]]
+    assert len(set(int(u["out_off"]) for u in unf)) == 6
+    bad = list(recs[0]); bad[11] = (2, 3)
+    with pytest.raises(ValueError, match="channels per filtered pixel"):
+        prep._layout_ex([tuple(bad)], 256, cap)
+    # without the flag (round 5's form, the FFHQ loop's): decoded images in the slot, byte for byte what the pipe carries
+    recs = [D.build_element(j + ((path, s, cap),)) for j, s in zip(jobs, slots)]
+    assert all(r[0] == "ring" and r[1] == s and r[10] <= cap and r[11] == (0, 0) for r, s in zip(recs, slots))
     assert all(len(pickle_bytes(r)) < 1000 for r in recs) and all(len(pickle_bytes(p)) > 400000 for p in pipe)
     ring = np.fromfile(path, np.uint8)
-    total, rows_off, grid_off, pieces, head, cells = prep._layout_ex(recs, 256, cap)
-    assert [c[:2] for c in cells] == [(0, 2), (1, 3), (2, 0)] and total == head + 3 * cap
+    total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf) = prep._layout_ex(recs, 256, cap)
+    assert [c[:2] for c in cells] == [(0, 2), (1, 3), (2, 0)] and total == head + 3 * cap and n_unf == 0
     blob = np.zeros(total, np.uint8)
     prep.pack_into(blob, pieces)
     for i, slot, base in cells:                                            # what DevicePrep.rows_ex's copies do
@@ -406,7 +429,8 @@ def pickle_bytes(x) -> bytes:
 @pytest.mark.gpu
 def test_loader_ring_and_pipe_give_identical_rows(golden_dir, monkeypatch):
     """The device-prepared loader through the page-locked shared-memory ring against the same loader through the workers' pipes
-    (BSR_LOADER_RING=0): identical rows, boxes, names and masks, over a list long enough for every slot to be reused several times."""
+    (BSR_LOADER_RING=0): identical rows, boxes, names and masks, over a list long enough for every slot to be reused several times —
+    with the photographs' scanlines reconstructed on the device (round 6: the UCB loop's default), in the workers, and through the pipe."""
     import torch
     from blindshadowremoval_amd import prep
     from blindshadowremoval_amd.fsrnet import Config, FSRNet
@@ -418,9 +442,10 @@ def test_loader_ring_and_pipe_give_identical_rows(golden_dir, monkeypatch):
     mf = fsr._ucb_masks()
     n = 150
 
-    def run(ring: bool):
+    def run(ring: bool, unfilter=None):
         monkeypatch.setenv("BSR_LOADER_RING", "1" if ring else "0")
         ds = D.Dataset(cfg, "test", ucb=True, workers=3, prefetch=6, device_prep=0, device_batch=8)
+        ds.device_unfilter = unfilter                      # None: the UCB loop reconstructs the PNG scanlines on the device (round 6)
         base = list(ds.name_list)
         ds.name_list = (base * 2)[:n]
         ds.ucb_mask_files = (mf * 2)[:n]
@@ -436,9 +461,9 @@ def test_loader_ring_and_pipe_give_identical_rows(golden_dir, monkeypatch):
             msum.append(prep.unpack_masks([el[3]], torch.device("cuda", 0)).double().sum(dim=(2, 3)).cpu())
         ds.close()
         return torch.stack(sums), np.concatenate(boxes), names, torch.cat(msum)
-    a, b = run(True), run(False)
-    assert len(a[2]) == n and a[2] == b[2] and np.array_equal(a[1], b[1])
-    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+    a, b, c = run(True), run(False), run(True, unfilter=False)
+    assert len(a[2]) == n and a[2] == b[2] == c[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[1], c[1])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[0], c[0]) and torch.equal(a[3], c[3])
 
 
 def test_slot_ring_file_lifecycle_and_small_tmpfs(monkeypatch):

@@ -53,7 +53,7 @@ def test_library_is_the_in_tree_hip_extension():
     from blindshadowremoval_amd import _lib
     from blindshadowremoval_amd.build import LIB_PATH
     lib = _lib.load()
-    assert lib._name == LIB_PATH and lib.bsr_abi_version() == _lib.ABI_VERSION == 7
+    assert lib._name == LIB_PATH and lib.bsr_abi_version() == _lib.ABI_VERSION == 8
 
 
 @pytest.mark.parametrize("seed,B", [(0, 2), (7, 3)])
