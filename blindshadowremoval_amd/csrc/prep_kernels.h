@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void prep_blur_kernel(const float* __restrict_
 // above (thread y - 1, step t - 1) comes through a double-buffered LDS word per thread, left and above-left are the thread's own registers.
 // One workgroup per image of at most 256 rows; c = 1 (grey: replicated), 3 or 4 (alpha dropped: channels never mix).
 struct UnfilterItem {
-  int64_t raw_off, out_off;   // bytes from the blob start: h x (1 + w c) filtered scanlines -> RGB8 [h][w][3]
-  int32_t h, w, c, pad;
+  int64_t raw_off, out_off;   // bytes from the blob start: h x (1 + w c) filtered scanlines -> RGB8 [h][w][3] (grey8 [h][w] with grey_out)
+  int32_t h, w, c, grey_out;  // grey_out != 0 (c = 1 only): the segmentation masks, one byte per pixel
 };
 
 __device__ __forceinline__ int png_paeth(int a, int b, int c) {      // a = left, b = above, c = above-left
@@ -207,14 +207,15 @@ constexpr int kUnfilterSlack = 16;       // readable bytes the caller guarantees
 // vmcnt retires in order, loads behind stores, so every memory instruction between a request and its use delays it: with a load and
 // two byte stores per STEP the kernel waited for a memory round trip per step (0.45-0.58 ms per batch of 16 images).  No load stands
 // inside a divergent branch (behind one the compiler drains vmcnt at the join), and the step's barrier waits for the wave's LDS word only.
-template <int C>
+template <int C, bool GREY = false>
 __device__ __forceinline__ void png_unfilter_image(unsigned char* __restrict__ blob, const UnfilterItem& it, unsigned (*s_px)[256]) {
   constexpr int NCH = C == 1 ? 1 : 3;                           // channels reconstructed (alpha is never needed: channels do not mix)
   const int tid = threadIdx.x, h = min(it.h, kUnfilterMaxRows), w = it.w;
   const size_t rb = 1 + (size_t)w * C;
   const bool row = tid < h;
   const unsigned char* rp = blob + it.raw_off + (size_t)(row ? tid : 0) * rb;
-  unsigned char* op = blob + it.out_off + (size_t)(row ? tid : 0) * w * 3;
+  constexpr int OB = GREY ? 1 : 3;                              // output bytes per pixel
+  unsigned char* op = blob + it.out_off + (size_t)(row ? tid : 0) * w * OB;
   const int ft = row ? rp[0] : 0;
   rp += 1;
   struct Group { unsigned d[C]; };
@@ -262,22 +263,24 @@ __device__ __forceinline__ void png_unfilter_image(unsigned char* __restrict__ b
         if (NCH == 1) { o[1] = o[0]; o[2] = o[0]; }
         const unsigned px = (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16);
         if (act) s_px[k & 1][tid] = px;
-        {
+        if constexpr (GREY) {
+          od[0] |= (px & 255u) << (8 * k);
+        } else {
           const int sh = 8 * ((3 * k) & 3), dw = (3 * k) >> 2;          // the pixel's 24 bits into the group's 96 (static: k is unrolled)
           od[dw] |= px << sh;
           if (sh > 8) od[dw + 1] |= px >> (32 - sh);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
-      // the group's output: one 12-byte store; a group that straddles an end of the row goes bytewise
+      // the group's output: one 12-byte (grey: 4-byte) store; a group that straddles an end of the row goes bytewise
       if (row && x0 >= 0 && x0 + 3 < w) {
-        __builtin_memcpy(op + 3 * (size_t)x0, od, 12);
+        __builtin_memcpy(op + OB * (size_t)x0, od, 4 * OB);
       } else if (row && x0 > -4 && x0 < w) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (x0 + k >= 0 && x0 + k < w)
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) op[3 * (x0 + k) + ch] = (unsigned char)(od[(3 * k + ch) >> 2] >> (8 * ((3 * k + ch) & 3)));
+            for (int ch = 0; ch < OB; ++ch) op[OB * (x0 + k) + ch] = (unsigned char)(od[(OB * k + ch) >> 2] >> (8 * ((OB * k + ch) & 3)));
       }
       win[i] = fetch(x0 + 16);
     }
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(256) void png_unfilter_kernel(unsigned char* __rest
   const UnfilterItem it = items[blockIdx.x];
   if (it.c == 3) png_unfilter_image<3>(blob, it, s_px);
   else if (it.c == 4) png_unfilter_image<4>(blob, it, s_px);
+  else if (it.grey_out) png_unfilter_image<1, true>(blob, it, s_px);
   else png_unfilter_image<1>(blob, it, s_px);
 }
 

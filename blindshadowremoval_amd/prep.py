@@ -37,7 +37,7 @@ def _imread_raw(path: str):
     return read_rgb_raw(path)
 
 
-UNFILTER_DTYPE = np.dtype([("raw_off", "<i8"), ("out_off", "<i8"), ("h", "<i4"), ("w", "<i4"), ("c", "<i4"), ("pad", "<i4")], align=True)
+UNFILTER_DTYPE = np.dtype([("raw_off", "<i8"), ("out_off", "<i8"), ("h", "<i4"), ("w", "<i4"), ("c", "<i4"), ("grey_out", "<i4")], align=True)
 assert UNFILTER_DTYPE.itemsize == 32          # csrc/prep_kernels.h UnfilterItem
 UNFILTER_MAX_ROWS = 256                       # csrc/prep_kernels.h kUnfilterMaxRows: one workgroup, one thread per row
 
@@ -113,11 +113,47 @@ def read_masks_u8(paths) -> np.ndarray:
     return np.stack([read_grey_u8(paths[k]) for k in MASK_ORDER], axis=0)
 
 
-def pack_masks(paths) -> tuple:
+def _masks_raw(paths):
+    """("raw8", the seven masks' inflated, still filtered scanlines back to back, S) when every mask is a plain 8-bit grey S x S PNG
+    the device kernel takes (bsr_png_unfilter, grey output), else None: the worker then neither reconstructs, compares nor packs."""
+    from . import pngio
+    raws, S = [], None
+    try:
+        pngio._host_lib()
+        for k in MASK_ORDER:
+            with open(paths[k], "rb") as f:
+                w, h, c, raw = pngio._parse_8bit(f.read())
+            if c != 1 or w != h or h > UNFILTER_MAX_ROWS or w < 4 or (S is not None and h != S):
+                return None
+            S = h
+            raws.append(raw)
+    except (ValueError, TypeError, KeyError, OSError, __import__("struct").error, __import__("zlib").error):
+        return None
+    return ("raw8", np.concatenate(raws), S)
+
+
+def masks_from_raw(packed: tuple) -> tuple:
+    """A "raw8" record decoded on the host into the form pack_masks gives without `raw` (an item that went through the pipe after all)."""
+    from .pngio import unfilter_host
+    _, raw, S = packed
+    n = S * (1 + S)
+    return _pack_levels(np.stack([unfilter_host(raw[i * n:(i + 1) * n], S, S, 1)[:, :, 0] for i in range(7)], axis=0))
+
+
+def pack_masks(paths, raw: bool = False) -> tuple:
     """The seven UCB segmentation masks of one item (dict in MASK_ORDER -> path) as grey levels, for the device post-processing
     (ucb_post_gpu): ("bits", [7, S*S/8] uint8) when every level is 0 or 255 — what the reference's masks are; an eighth of the bytes
-    through the worker's pipe — else ("u8", [7,S,S] uint8)."""
+    through the worker's pipe — else ("u8", [7,S,S] uint8).  raw = True (the ring path with the reconstruction on the device, round 6):
+    ("raw8", ...) of _masks_raw where the files allow it."""
+    if raw:
+        r = _masks_raw(paths)
+        if r is not None:
+            return r
     m = read_masks_u8(paths)
+    return _pack_levels(m)
+
+
+def _pack_levels(m: np.ndarray) -> tuple:
     if m.shape[1] * m.shape[2] % 8 == 0 and bool(np.all((m == 0) | (m == 255))):
         return ("bits", np.packbits((m != 0).reshape(7, -1), axis=1), m.shape[1])
     return ("u8", m, m.shape[1])
@@ -149,7 +185,7 @@ def host_part(job, raw: bool = False):
     raw = True (the ring path, round 6): img / gt may be pngio.RawScanlines — inflated, still filtered; the device reconstructs them."""
     masks = None
     if len(job) > 3:
-        masks = pack_masks(job[3])
+        masks = pack_masks(job[3], raw=raw)
         job = job[:3]
     lm_path, gt_path, size = job
     img_path = os.path.splitext(lm_path)[0] + ".png"
@@ -187,6 +223,8 @@ def host_part_ring(job, ring):
     fits = lambda a: not hasattr(a, "raw") or (a.h <= UNFILTER_MAX_ROWS and a.w * a.c >= 4)
     if not (fits(img) and (gt is None or fits(gt))):
         img, gt = (img.decode() if hasattr(img, "raw") else img), (gt.decode() if gt is not None and hasattr(gt, "raw") else gt)
+        if masks is not None and masks[0] == "raw8":
+            masks = masks_from_raw(masks)
     masks = part[5] if len(part) > 5 else None
     rawc = tuple(int(getattr(a, "c", 0)) if hasattr(a, "raw") else 0 for a in ([img] + ([gt] if gt is not None else [])))
     arrays = [getattr(a, "raw", a) for a in ([img] + ([gt] if gt is not None else []))] + list(tabs) + ([masks[1]] if masks is not None else [])
@@ -196,7 +234,8 @@ def host_part_ring(job, ring):
         off = (off + a.nbytes + 7) & ~7
     if off > cap:                                  # through the pipe after all: decoded here
         dec = lambda a: a.decode() if hasattr(a, "raw") else a
-        return (dec(img), dec(gt) if gt is not None else None) + tuple(part[2:])
+        rest = tuple(part[2:5]) + ((masks_from_raw(masks) if masks[0] == "raw8" else masks,) if masks is not None else ())
+        return (dec(img), dec(gt) if gt is not None else None) + rest
     view = _RING_VIEWS.get(path)
     if view is None:
         view = _RING_VIEWS[path] = np.memmap(path, np.uint8, "r+")
@@ -312,12 +351,13 @@ def _layout_ex(parts, size: int, cap: int):
             pieces.append((int(r["tri_off"][m]), t))
     pieces.append((rows_off, rows))
     ring_idx = [i for i, part in enumerate(parts) if _is_ring(part)]
-    n_unf = sum(sum(1 for c in (parts[i][11] if len(parts[i]) > 11 else ()) if c) for i in ring_idx)
+    n_unf = sum(sum(1 for c in (parts[i][11] if len(parts[i]) > 11 else ()) if c) + (7 if parts[i][9] is not None and parts[i][9][0] == "raw8" else 0)
+                for i in ring_idx)
     unf = np.zeros(n_unf, UNFILTER_DTYPE)
     unf_off = take(max(n_unf, 1) * UNFILTER_DTYPE.itemsize)
     if n_unf:
         pieces.append((unf_off, unf))
-    head, cells = off, []
+    head, cells, mask_out = off, [], {}
     if ring_idx:
         # the records of the ring items in whole columns (per-field assignments on a structured array cost ~15 us each: 0.3 ms per batch
         # of the loop's own thread when done item by item)
@@ -355,11 +395,31 @@ def _layout_ex(parts, size: int, cap: int):
             sizes = (npx[jj] + 7) & ~7
             outs = off + np.cumsum(sizes) - sizes
             off += int(sizes.sum())
-            unf["raw_off"] = np.where(ww == 0, img_at[jj], gt_at[jj])
-            unf["out_off"], unf["h"], unf["w"], unf["c"] = outs, hw[jj, 0], hw[jj, 1], rawc[jj, ww]
+            ni = len(jj)
+            unf["raw_off"][:ni] = np.where(ww == 0, img_at[jj], gt_at[jj])
+            unf["out_off"][:ni], unf["h"][:ni], unf["w"][:ni], unf["c"][:ni] = outs, hw[jj, 0], hw[jj, 1], rawc[jj, ww]
             img_at[jj[ww == 0]] = outs[ww == 0]
             gt_at[jj[ww == 1]] = outs[ww == 1]
             gt_at = np.where(has_gt, gt_at, img_at)
+            # the seven masks of an item that lie in its slot as filtered scanlines ("raw8"): seven records, grey output, one area
+            mj = [j for j in range(n) if rp[j][9] is not None and rp[j][9][0] == "raw8"]
+            if mj:
+                mj = np.array(mj)
+                mS = np.array([rp[j][9][1] for j in mj], np.int64)
+                moff = np.array([rp[j][9][2] for j in mj], np.int64)
+                mlen = np.array([rp[j][9][3] for j in mj], np.int64)
+                if ((mS < 4) | (mS > UNFILTER_MAX_ROWS) | (mlen != 7 * mS * (1 + mS)) | (moff < 0) | (moff + mlen > cap)).any():
+                    raise ValueError("prep blob: a ring item's filtered masks do not fit its slot")
+                area = (7 * mS * mS + 7) & ~7
+                mout = off + np.cumsum(area) - area
+                off += int(area.sum())
+                seven = np.arange(7, dtype=np.int64)[None, :]
+                sl = slice(ni, ni + 7 * len(mj))
+                unf["raw_off"][sl] = (bases[mj][:, None] + moff[:, None] + seven * (mS * (1 + mS))[:, None]).reshape(-1)
+                unf["out_off"][sl] = (mout[:, None] + seven * (mS * mS)[:, None]).reshape(-1)
+                unf["h"][sl] = unf["w"][sl] = np.repeat(mS, 7)
+                unf["c"][sl], unf["grey_out"][sl] = 1, 1
+                mask_out = {ring_idx[int(j)]: (int(o), int(S_)) for j, o, S_ in zip(mj, mout, mS)}
         rows["img_off"][sel] = img_at
         rows["gt_off"][sel] = gt_at
         rows["box"][sel] = np.stack([np.asarray(p[7], np.int32).reshape(4) for p in rp])
@@ -373,7 +433,7 @@ def _layout_ex(parts, size: int, cap: int):
     bad = (lows < 0) | (ends > off) | (rows["ntri"].max(axis=1) > MAX_TRI) | (rows["ntri"].min(axis=1) < 0) | (h64 < 0) | (w64 < 0)
     if bad.any():
         raise ValueError("prep blob: row %d points outside the %d-byte blob" % (int(np.argmax(bad)), off))
-    return off, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf)
+    return off, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf, mask_out)
 
 
 def pack_into(buf: np.ndarray, pieces) -> None:
@@ -420,7 +480,7 @@ class DevicePrep:
         B, S = len(parts), self.size
         ring = getattr(self, "ring", None)
         cap = ring.cap if ring is not None else RING_CAP
-        total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf) = _layout_ex(parts, S, cap)
+        total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf, mask_out) = _layout_ex(parts, S, cap)
         if cells and ring is None:
             raise RuntimeError("DevicePrep.rows_ex: ring records without a ring")
         dev = "cuda:%d" % self.device
@@ -486,6 +546,10 @@ class DevicePrep:
             m = parts[i][9]
             if m is not None:
                 kind, ms, moff, nbytes = m
+                if kind == "raw8":                 # reconstructed by bsr_png_unfilter into their own area: grey levels [7,S,S]
+                    o = mask_out[i][0]
+                    masks[i] = ("dev_u8", d_blob[o:o + 7 * ms * ms].view(7, ms, ms), ms)
+                    continue
                 v = d_blob[base + moff:base + moff + nbytes]
                 masks[i] = ("dev_" + kind, v.view(7, -1) if kind == "bits" else v.view(7, ms, ms), ms)
         return out, boxes, masks, names

@@ -132,9 +132,9 @@ int bsr_prep_rows(int device, const void* d_blob, size_t blob_bytes, size_t rows
 /* PNG scanline reconstruction (RFC 2083 section 6) of n images on the device — what cv2.imread / PIL do after inflating a file
  * (/root/reference/dataset.py:151,622: the images parse_fn_test / parse_fn_test_FFHQ read), moved behind the copy to the device so that a
  * loader's worker stops at the inflated stream.  d_blob (device, blob_bytes): at items_off (8-byte aligned) n records
- * { int64 raw_off, out_off; int32 h, w, c, pad } — raw_off: h x (1 + w c) bytes of FILTERED scanlines (filter-type byte first; c = 1
+ * { int64 raw_off, out_off; int32 h, w, c, grey_out } — raw_off: h x (1 + w c) bytes of FILTERED scanlines (filter-type byte first; c = 1
  * grey, 3 RGB, 4 RGBA of an 8-bit non-interlaced file), out_off: where the RGB8 image [h][w][3] is written (grey replicated, alpha
- * dropped — PIL's convert("RGB")); both inside the blob, validated by the caller like bsr_prep_rows' records: h <= 256 (one workgroup
+ * dropped — PIL's convert("RGB"); grey_out != 0 with c = 1: one byte per pixel, [h][w] — the UCB masks); both inside the blob, validated by the caller like bsr_prep_rows' records: h <= 256 (one workgroup
  * per image, one thread per row, pixels on the anti-diagonal), w c >= 4, and 16 readable bytes of the blob in front of and behind every
  * filtered image (a thread reads its row four pixels at a time).  ABI 8. */
 int bsr_png_unfilter(int device, void* d_blob, size_t blob_bytes, size_t items_off, int n, void* stream);

@@ -1,6 +1,6 @@
 set -x
 python -m pytest tests/test_unfilter_gpu.py -x -q -m gpu 2>&1 | tail -8
-python -m pytest tests/test_dataset.py tests/test_prep_gpu.py -x -q -m gpu 2>&1 | tail -3
+python -m pytest tests/test_dataset.py tests/test_prep_gpu.py tests/test_fsrnet.py -x -q -m gpu 2>&1 | tail -3
 for i in 1 2; do
 python bench.py --steps 5 --no-cpu-baseline --no-secondary --loop ucb > gpurun_out/r6v_loop_ucb_$i.json 2>/dev/null
 python bench.py --steps 5 --no-cpu-baseline --no-secondary --loop ffhq > gpurun_out/r6v_loop_ffhq_$i.json 2>/dev/null

@@ -358,22 +358,29 @@ def test_loader_ring_slot_holds_what_the_pipe_would_carry(tmp_path, golden_dir):
     # round 6: the images lie in the slot as inflated, still FILTERED scanlines; the blob gets an unfilter table (where the filtered bytes
     # are, where the RGB image goes) and the row records point at the output areas behind the cells
     recs = [D.build_element(j + ((path, s, cap, True),)) for j, s in zip(jobs, slots)]
-    assert all(r[11] == (3, 3) for r in recs)
+    assert all(r[11] == (3, 3) and r[9][0] == "raw8" and r[10] <= cap for r in recs)
     ring = np.fromfile(path, np.uint8)
-    total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf) = prep._layout_ex(recs, 256, cap)
-    assert n_unf == 6 and unf_off + 6 * prep.UNFILTER_DTYPE.itemsize <= head and total == head + 3 * cap + 6 * ((256 * 256 * 3 + 7) & ~7)
+    total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf, mask_out) = prep._layout_ex(recs, 256, cap)
+    assert n_unf == 6 + 21 and unf_off + n_unf * prep.UNFILTER_DTYPE.itemsize <= head
+    assert total == head + 3 * cap + 6 * 256 * 256 * 3 + 3 * 7 * 256 * 256 and sorted(mask_out) == [0, 1, 2]
     blob = np.zeros(total, np.uint8)
     prep.pack_into(blob, pieces)
     for i, slot, base in cells:
         blob[base:base + cap] = ring[slot * cap:(slot + 1) * cap]
-    unf = blob[unf_off:unf_off + 6 * prep.UNFILTER_DTYPE.itemsize].view(prep.UNFILTER_DTYPE)
+    unf = blob[unf_off:unf_off + n_unf * prep.UNFILTER_DTYPE.itemsize].view(prep.UNFILTER_DTYPE)
     rows = blob[rows_off:rows_off + 3 * prep.ROW_DTYPE.itemsize].view(prep.ROW_DTYPE)
     from blindshadowremoval_amd import pngio
-    for k, u in enumerate(unf):
-        assert (u["h"], u["w"], u["c"]) == (256, 256, 3) and head + 3 * cap <= u["out_off"] and u["out_off"] + 256 * 256 * 3 <= total
+    for k, u in enumerate(unf[:6]):
+        assert (u["h"], u["w"], u["c"], u["grey_out"]) == (256, 256, 3, 0) and head + 3 * cap <= u["out_off"] and u["out_off"] + 256 * 256 * 3 <= total
         img = pngio.unfilter_host(blob[u["raw_off"]:u["raw_off"] + 256 * 769], 256, 256, 3)
         assert np.array_equal(img, pipe[k // 2][k % 2]) and u["out_off"] == rows[k // 2][("img_off", "gt_off")[k % 2]]
-    assert len(set(int(u["out_off"]) for u in unf)) == 6
+    for k, u in enumerate(unf[6:]):                                        # the masks: seven grey images per item, one output area per item
+        i, m = divmod(k, 7)
+        assert (u["h"], u["w"], u["c"], u["grey_out"]) == (256, 256, 1, 1) and u["out_off"] == mask_out[i][0] + m * 65536 and u["out_off"] + 65536 <= total
+        lv = pngio.unfilter_host(blob[u["raw_off"]:u["raw_off"] + 256 * 257], 256, 256, 1)[:, :, 0]
+        assert np.array_equal(np.packbits(lv != 0), pipe[i][5][1][m]) and set(np.unique(lv)) <= {0, 255}
+    assert len(set(int(u["out_off"]) for u in unf)) == n_unf
+    assert prep.masks_from_raw(("raw8", blob[unf[6]["raw_off"]:unf[6]["raw_off"] + 7 * 256 * 257], 256))[0] == "bits"
     bad = list(recs[0]); bad[11] = (2, 3)
     with pytest.raises(ValueError, match="channels per filtered pixel"):
         prep._layout_ex([tuple(bad)], 256, cap)
@@ -382,7 +389,7 @@ def test_loader_ring_slot_holds_what_the_pipe_would_carry(tmp_path, golden_dir):
     assert all(r[0] == "ring" and r[1] == s and r[10] <= cap and r[11] == (0, 0) for r, s in zip(recs, slots))
     assert all(len(pickle_bytes(r)) < 1000 for r in recs) and all(len(pickle_bytes(p)) > 400000 for p in pipe)
     ring = np.fromfile(path, np.uint8)
-    total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf) = prep._layout_ex(recs, 256, cap)
+    total, rows_off, grid_off, pieces, head, cells, (unf_off, n_unf, _) = prep._layout_ex(recs, 256, cap)
     assert [c[:2] for c in cells] == [(0, 2), (1, 3), (2, 0)] and total == head + 3 * cap and n_unf == 0
     blob = np.zeros(total, np.uint8)
     prep.pack_into(blob, pieces)
@@ -457,7 +464,7 @@ def test_loader_ring_and_pipe_give_identical_rows(golden_dir, monkeypatch):
         for el in ds.feed:
             sums.append(el[0].double().sum(dim=(0, 1, 2, 3)).cpu())
             boxes.append(el[1]); names.append(el[2][0])
-            assert el[3][0] == ("dev_bits" if ring else "bits")
+            assert el[3][0] == (("dev_bits" if unfilter is False else "dev_u8") if ring else "bits")
             msum.append(prep.unpack_masks([el[3]], torch.device("cuda", 0)).double().sum(dim=(2, 3)).cpu())
         ds.close()
         return torch.stack(sums), np.concatenate(boxes), names, torch.cat(msum)
