@@ -66,7 +66,8 @@ def _host_lib():
 
 def _parse_8bit(b: bytes):
     """-> (w, h, channels, inflated scanlines) of a non-interlaced 8-bit grey / RGB / RGBA file without palette, transparency or gamma
-    chunks; ValueError for anything else (PIL's business)."""
+    chunks; ValueError for anything else (PIL's business).  The chunks' CRC-32 fields are NOT verified (PIL would reject a file whose
+    chunk CRC is wrong; here the zlib stream's Adler-32 and its exact length h * (1 + w c) are what vouch for the pixels)."""
     if b[:8] != _SIGNATURE:
         raise ValueError
     o, idat, hdr = 8, [], None
