@@ -122,7 +122,7 @@ def test_run_loop_refuses_to_run_without_a_gpu():
 
 
 def test_kernel_group_traffic_from_the_committed_counter_passes(monkeypatch):
-    """bench.attach_group_traffic: every kernel group gets its HBM rate from the committed counter passes (profiles/r5_pmc_traffic*.json)
+    """bench.attach_group_traffic: every kernel group gets its HBM rate from the committed counter passes (profiles/r6_pmc_traffic*.json)
     beside the algorithmic one — but only while the kernel sources hash to what the passes ran on (a stale figure is never quoted)."""
     import importlib.util
     import json
@@ -131,8 +131,8 @@ def test_kernel_group_traffic_from_the_committed_counter_passes(monkeypatch):
     spec.loader.exec_module(bench)
     from blindshadowremoval_amd import build
     for dtype, sfx in (("f32", ""), ("f16", "_f16")):
-        line = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_n1%s.json" % sfx)))
-        passes = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic%s.json" % sfx)))
+        line = json.load(open(os.path.join(ROOT, "profiles", "r6_bench_n1%s.json" % sfx)))
+        passes = json.load(open(os.path.join(ROOT, "profiles", "r6_pmc_traffic%s.json" % sfx)))
         rf = json.loads(json.dumps(line["roofline"]))
         for g in rf["kernel_groups"].values():
             g.pop("counter_GBps", None); g.pop("hbm_frac_counters", None); g.pop("traffic_ratio", None)
