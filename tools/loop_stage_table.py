@@ -83,6 +83,20 @@ def main():
         res["stages"]["loader_host_half_with_masks"] = {"items_per_sec": round(n / dt, 1), "driver_cpu_ms_per_item": round(cpu / n * 1e3, 3),
                                                         "job_cpu_ms_alone": alone_ms(build_element, jobs_m),
                                                         "what": "prep.host_part per item incl. the seven UCB masks (C scanline reconstruction, bit-packed)"}
+        # ---- stage 1b (round 6): the UCB loop's job as it runs now — the worker stops after the inflate and writes the item's filtered scanlines
+        # (two photographs, seven masks) + triangle tables into its slot of the ring (a plain file here); reconstruction happens on the device
+        from blindshadowremoval_amd.prep import RING_CAP
+        ring_path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else out_dir, "bsr_stage_ring_%d.bin" % os.getpid())      # (the loops' ring lives in /dev/shm)
+        nslots = 64
+        with open(ring_path, "wb") as fh:
+            fh.truncate(nslots * RING_CAP)
+        jobs_r = [j + ((ring_path, i % nslots, RING_CAP, True),) for i, j in enumerate(jobs_m)]
+        run_stage(pool, jobs_r[:nw])
+        dt, cpu = run_stage(pool, jobs_r)
+        res["stages"]["loader_host_half_with_masks_device_unfilter"] = {
+            "items_per_sec": round(n / dt, 1), "driver_cpu_ms_per_item": round(cpu / n * 1e3, 3), "job_cpu_ms_alone": alone_ms(build_element, jobs_r),
+            "what": "prep.host_part_ring per item with the scanline reconstruction left to the device (inflate only; filtered scanlines of image, ground truth and the seven masks into the ring slot)"}
+        os.remove(ring_path)
         # ---- stage 1c (round 5): writing the PNG files the DEVICE built (gpu_png): four writer threads in the loop's process, 256x768 and 256x1792 strips
         from concurrent.futures import ThreadPoolExecutor
         from blindshadowremoval_amd.pngio import stored_layout
@@ -153,9 +167,11 @@ def main():
         "testFFHQ": "round 5 (PNG files built on the device): host stages = loader_host_half + file_write_ffhq (+ the driving thread); slowest stage alone: %.0f /s.  "
                     "Rounds 3-4 (host encoder): loader_host_half + png_strip, slowest %.0f /s"
                     % (min(st["loader_host_half"]["items_per_sec"], st["file_write_ffhq"]["items_per_sec"]), min(st["loader_host_half"]["items_per_sec"], st["png_strip"]["items_per_sec"])),
-        "test (UCB)": "round 5 (post-processing + PNG on the device): host stages = loader_host_half_with_masks + file_write_ucb; slowest stage alone: %.0f /s.  "
+        "test (UCB)": "round 6 (scanline reconstruction on the device too): host stages = loader_host_half_with_masks_device_unfilter + file_write_ucb; slowest stage "
+                      "alone: %.0f /s.  Round 5 (post-processing + PNG on the device): loader_host_half_with_masks + file_write_ucb, slowest %.0f /s.  "
                       "Rounds 2-4 (host post-processing): loader_host_half + ucb_post (its PNG strip included), slowest %.0f /s"
-                      % (min(st["loader_host_half_with_masks"]["items_per_sec"], st["file_write_ucb"]["items_per_sec"]), st["ucb_post"]["items_per_sec"]),
+                      % (min(st["loader_host_half_with_masks_device_unfilter"]["items_per_sec"], st["file_write_ucb"]["items_per_sec"]),
+                         min(st["loader_host_half_with_masks"]["items_per_sec"], st["file_write_ucb"]["items_per_sec"]), st["ucb_post"]["items_per_sec"]),
         "cpu_sum_ms_per_item_uncontended": {"testFFHQ": round(st["loader_host_half"]["job_cpu_ms_alone"] + st["png_strip"]["job_cpu_ms_alone"], 2),
                                             "test (UCB)": round(st["loader_host_half"]["job_cpu_ms_alone"] + st["ucb_post"]["job_cpu_ms_alone"], 2)},
         "note": "items_per_sec = the stage ALONE through a pool of %d worker processes on %d usable CPUs; job_cpu_ms_alone = the same job run once in one "
