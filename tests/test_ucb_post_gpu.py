@@ -73,6 +73,36 @@ def test_other_crop_sizes_and_rule_branches():
             assert abs(float(losses[j, 0]) - l_ref["ssim"]) < 1e-4 and abs(float(losses[j, 1]) - l_ref["psnr"]) < 1e-3, (key, losses[j], l_ref)
 
 
+@pytest.mark.parametrize("step", [2, 4])
+def test_smaller_images(step):
+    """S = 128 and 64 (bsr_ucb_post takes 32 .. 256): the same items subsampled — the stage chain's grids, the run labelling (at S = 64 a
+    wave spans a whole image row), leaf counts and the sum tree are functions of S; still bit-identical to the host statement."""
+    from blindshadowremoval_amd.ucb_post import ucb_postprocess
+    batch = []
+    for i, (key, row, box, masks, con, dif) in enumerate(cases()):
+        S = row.shape[0] // step
+        b = np.asarray(box, np.float32).reshape(4).copy()
+        b[3] = b[1] + (S if i % 2 == 0 else S - 1 - 3 * i)
+        sub = lambda a: np.ascontiguousarray(a[::step, ::step])
+        batch.append(("%s_S%d" % (key, S), sub(row), b, {k: sub(v) for k, v in masks.items()}, sub(con), sub(dif)))
+    losses, strips, figs, status = _run(batch)
+    done = 0
+    for j, (key, row, box, masks, con, dif) in enumerate(batch):
+        try:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                l_ref, f_ref = ucb_postprocess(row[..., 0:3], row[..., 3:6], con, dif, box, masks)
+        except ValueError:
+            assert status[j] == 1, key
+            continue
+        assert status[j] == 0, key
+        done += 1
+        for k in range(7):
+            np.testing.assert_array_equal(figs[j, k], f_ref[k][0], err_msg="%s fig %d" % (key, k))
+        if np.isfinite(l_ref["psnr"]):
+            assert abs(float(losses[j, 0]) - l_ref["ssim"]) < 1e-4 and abs(float(losses[j, 1]) - l_ref["psnr"]) < 1e-3, (key, losses[j], l_ref)
+    assert done >= len(batch) // 2
+
+
 def test_empty_mask_and_bad_box_are_reported():
     import torch
     from blindshadowremoval_amd.ucb_post_gpu import UcbPostDevice, raise_for_status
