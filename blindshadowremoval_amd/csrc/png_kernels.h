@@ -15,9 +15,13 @@
 // head in front of it where one starts there) in LDS, copies them out, and reduces its part of the two checksums:
 //   * CRC-32 (reflected, poly 0xEDB88320): the register after a message is linear in (initial register, message), so
 //     crc(A | B) = shift(crc(A), |B|) ^ crc_0(B) with shift(c, n) = c * x^(8n) mod P — zlib's crc32_combine, restated: multmodp / x2nmodp
-//     below.  Every lane runs the table-driven byte loop over its piece (the stream's first piece starts from 0xFFFFFFFF, all others
+//     below.  Every lane runs the table-driven loop over its piece (the stream's first piece starts from 0xFFFFFFFF, all others
 //     from 0), shifts the result to the END of the checksummed stream and the pieces are XORed together: a wave reduction, then one
-//     atomicXor per scanline — XOR is order-independent, so the result is deterministic.
+//     atomicXor per scanline — XOR is order-independent, so the result is deterministic.  Round 6 (rocprofv3: 106 -> 26-30 us per 16 strips, the
+//     files byte for byte the same): the shift is TWO tabulated multiplications (lane: to the end of the scanline; row: to the end of the stream;
+//     tables of the host in the kernel arguments) instead of ~20 bit-serial ones per lane — 70 of the 106 us by knock-out builds; the loop takes
+//     four bytes per step (slice-by-4 tables, a lane's piece = whole dwords of LDS); the scanline's pixels sit on a 16-byte boundary of LDS, are
+//     filled and copied out 16 bytes per lane (unaligned global stores); LDS is sized by the scanline (one round of workgroups).
 //   * Adler-32 over the n raw bytes d_0 .. d_{n-1}: A = 1 + sum d_j, B = n + sum (n - j) d_j (mod 65521): two integer sums, 64-bit atomics.
 // Round 6: ONE launch.  The workgroup whose arrival ticket says it is the file's LAST folds the accumulators, runs the 4 Adler bytes through the
 // CRC, writes the fixed bytes — and clears accumulators and ticket again: the scratch is zero before and after every call (the caller
@@ -26,6 +30,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+// Diagnostic builds (scratch/png_knock.sh; wrong files, timing only): bit 0 = no CRC / Adler byte loop, 1 = no copy-out, 2 = no pixel fill,
+// 3 = no shift to the end of the stream, 4 = no atomics / ticket / finish
+#ifndef BSR_PNG_KNOCK
+#define BSR_PNG_KNOCK 0
+#endif
 
 namespace bsr {
 
@@ -54,7 +64,15 @@ struct PngGeom {
   unsigned file_bytes;
   unsigned ihdr_crc;
   unsigned x2n[32];         // x^(2^k) mod P
+  // round 6: the shift of a lane's piece of a scanline to the end of the stream as TWO tabulated multiplications — x^(8 (bytes of the
+  // scanline behind the piece)), a function of the lane, times x^(8 (bytes of the stream behind the scanline)), a function of the row —
+  // instead of ~20 bit-serial ones per lane (rocprof + knock-out builds: 70 of the kernel's 110 us).  Tables of the host, in the kernel
+  // arguments; rows beyond kPngRowTable use the bit-serial shift.
+  int cb;                   // pixel bytes of a scanline per lane: 4 ceil(3 W / 256)
+  unsigned lane_shift[64];
+  unsigned row_shift[512];
 };
+constexpr int kPngRowTable = 512;
 
 __host__ __device__ inline unsigned crc_update_byte(unsigned c, unsigned byte) {     // bitwise form (host, and the finish kernel's few bytes)
   c ^= byte;
@@ -78,6 +96,39 @@ inline bool png_geometry(int H, int W, PngGeom* g) {
   unsigned p = 1u << 30;                                     // x^1
   g->x2n[0] = p;
   for (int k = 1; k < 32; ++k) g->x2n[k] = p = crc_multmodp(p, p);
+  // x^(8 n) mod P on the host (crc_shift_bytes of the device, applied to x^0)
+  auto x8n = [&](unsigned n) {
+    unsigned c = 1u << 31, k = 3;
+    while (n) {
+      if (n & 1u) c = crc_multmodp(g->x2n[k & 31], c);
+      n >>= 1;
+      ++k;
+    }
+    return c;
+  };
+  const int nbp = 3 * W;                                     // pixel bytes of a scanline
+  g->cb = 4 * ((nbp + 255) / 256);
+  {
+    // lane l covers PIXEL bytes [l cb, min((l + 1) cb, 3 W)) of its scanline (cb a multiple of 4: whole dwords of LDS, four bytes per CRC
+    // step): behind it lie 3 W - min((l + 1) cb, 3 W) bytes of the scanline
+    const unsigned step = x8n((unsigned)g->cb);
+    int last = (nbp - 1) / g->cb;                            // the last lane with bytes; its piece may be short
+    for (int l = 63; l >= 0; --l) {
+      if (l >= last) g->lane_shift[l] = 1u << 31;            // nothing behind it: x^0
+      else if (l == last - 1) g->lane_shift[l] = x8n((unsigned)(nbp - last * g->cb));
+      else g->lane_shift[l] = crc_multmodp(g->lane_shift[l + 1], step);
+    }
+    // scanline y: the stream ("IDAT" + zlib stream without its Adler-32) continues for dist(y) bytes behind it; dist(H - 1) = 0 and one
+    // scanline up adds RB bytes, plus the 5-byte header where a stored block starts in between
+    const unsigned xa = x8n((unsigned)g->RB), xb = x8n((unsigned)g->RB + 5u);
+    const int rows = H < kPngRowTable ? H : kPngRowTable;
+    unsigned cur = 1u << 31;
+    for (int y = H - 1; y >= 0; --y) {
+      if (y < H - 1) cur = crc_multmodp(cur, ((y + 1) % g->R == 0) ? xb : xa);
+      if (y < rows) g->row_shift[y] = cur;
+    }
+    for (int y = rows; y < kPngRowTable; ++y) g->row_shift[y] = 0u;
+  }
   return true;
 }
 
@@ -92,8 +143,10 @@ __device__ inline unsigned crc_shift_bytes(const PngGeom& g, unsigned c, unsigne
   return c;
 }
 
-constexpr int kPngSegMax = 16384 + 16;                        // LDS bytes per wave: a scanline + the headers that may precede it
+constexpr int kPngSegMax = 16384 + 16;                        // LDS bytes per wave at most: a scanline + the headers that may precede it
+__host__ __device__ inline int png_seg_bytes(int RB) { return (RB + 11 + 15 + 15) & ~15; }     // LDS bytes per wave for this geometry: headers + scanline + the pad that aligns its pixels
 constexpr int kPngWaves = 4;
+constexpr int kPngTabBytes = 4096;
 constexpr int kPngSub = 8;                                    // checksum sub-accumulators per file (workgroup b adds into b % 8: at most H / 32 atomics per address)
 constexpr int kPngMaxFigs = 8;
 
@@ -148,13 +201,20 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
   extern __shared__ __attribute__((aligned(16))) unsigned char png_smem[];
   __shared__ unsigned long long s_red[kPngWaves][3];
   __shared__ int s_last;
-  unsigned* s_tab = reinterpret_cast<unsigned*>(png_smem);                       // 256-entry CRC table
+  unsigned* s_tab = reinterpret_cast<unsigned*>(png_smem);                       // 4 x 256-entry CRC tables (slice by 4)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned char* seg = png_smem + 1024 + (size_t)wave * kPngSegMax;
+  unsigned char* seg = png_smem + kPngTabBytes + (size_t)wave * (size_t)png_seg_bytes(g.RB);      // (sized by the scanline: a 768-pixel strip leaves room for ~14 workgroups per CU, the maximum for 2)
   {
+    // slice-by-4 tables: T0 = the byte table; T_{k+1}[i] = T_k[i] moved past one more zero byte — four bytes per step instead of one, the
+    // step's four look-ups independent of each other (the byte loop was a chain of 37-84 dependent LDS round trips per lane)
     unsigned c = (unsigned)tid;
     for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
     s_tab[tid] = c;
+    __syncthreads();
+    for (int k = 1; k < 4; ++k) {
+      c = s_tab[c & 0xFFu] ^ (c >> 8);
+      s_tab[256 * k + tid] = c;
+    }
   }
   const int item = blockIdx.y;
   const int y = blockIdx.x * kPngWaves + wave;
@@ -168,6 +228,7 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
     if (y % g.R == 0) hdr = 5;
     if (y == 0) hdr = 5 + 2 + 4;                             // "IDAT" | 78 01 | block header
     file_off = row_off - (unsigned)hdr;
+    seg += (16 - ((hdr + 1) & 15)) & 15;                     // the scanline's first PIXEL byte (segment byte hdr + 1) on a 16-byte boundary of LDS
     if (lane == 0) {
       int o = 0;
       if (y == 0) {
@@ -185,7 +246,8 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
     }
     const unsigned char* src = pixels + ((size_t)item * g.H + y) * (size_t)(3 * g.W);
     const int nb = 3 * g.W;
-    if (figs.n > 0) {
+    if (BSR_PNG_KNOCK & 4) {
+    } else if (figs.n > 0) {
       unsigned char* d = seg + hdr + 1;
       const size_t rowpix = ((size_t)item * g.H + y) * (size_t)figs.Wf;
       for (int k = 0; k < figs.n; ++k) {
@@ -193,24 +255,34 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
         const float* mp = figs.mul[k];
         const float sc = figs.scale[k];
         const int ch3 = figs.ch[k] == 3;
+        const bool wide = ch3 && (reinterpret_cast<uintptr_t>(fp) & 15) == 0 && (figs.ps[k] & 3) == 0;      // a channel slice of an NHWC tensor: one 16-byte load per pixel
         for (int x = lane; x < figs.Wf; x += 64) {
 #pragma clang fp contract(off)
           const float* px = fp + (rowpix + x) * (size_t)figs.ps[k];
           const float m = mp != nullptr ? mp[(rowpix + x) * (size_t)figs.mps[k]] : 1.f;
-          float v0 = px[0], v1 = ch3 ? px[1] : v0, v2 = ch3 ? px[2] : v0;
+          float v0, v1, v2;
+          if (wide) {
+            typedef float png_f4 __attribute__((ext_vector_type(4)));
+            const png_f4 q = *reinterpret_cast<const png_f4*>(px);
+            v0 = q[0]; v1 = q[1]; v2 = q[2];
+          } else {
+            v0 = px[0]; v1 = ch3 ? px[1] : v0; v2 = ch3 ? px[2] : v0;
+          }
           if (mp != nullptr) { v0 = v0 * m; v1 = v1 * m; v2 = v2 * m; }
           if (sc != 1.f) { v0 = v0 * sc; v1 = v1 * sc; v2 = v2 * sc; }
           unsigned char* o = d + 3 * (k * figs.Wf + x);
           o[0] = png_quantise(v0); o[1] = png_quantise(v1); o[2] = png_quantise(v2);
         }
       }
+    } else if (((3 * g.W) & 15) == 0 && (reinterpret_cast<uintptr_t>(pixels) & 15) == 0) {
+      typedef unsigned png_u4 __attribute__((ext_vector_type(4)));
+      const png_u4* src16 = reinterpret_cast<const png_u4*>(src);
+      png_u4* d16 = reinterpret_cast<png_u4*>(seg + hdr + 1);
+      for (int i = lane; i < nb / 16; i += 64) d16[i] = src16[i];
     } else if (((3 * g.W) & 3) == 0 && (reinterpret_cast<uintptr_t>(pixels) & 3) == 0) {
       const unsigned* src4 = reinterpret_cast<const unsigned*>(src);
-      for (int i = lane; i < nb / 4; i += 64) {
-        const unsigned v = src4[i];
-        unsigned char* d = seg + hdr + 1 + 4 * i;
-        d[0] = (unsigned char)v; d[1] = (unsigned char)(v >> 8); d[2] = (unsigned char)(v >> 16); d[3] = (unsigned char)(v >> 24);
-      }
+      unsigned* d4 = reinterpret_cast<unsigned*>(seg + hdr + 1);
+      for (int i = lane; i < nb / 4; i += 64) d4[i] = src4[i];
     } else {
       for (int i = lane; i < nb; i += 64) seg[hdr + 1 + i] = src[i];
     }
@@ -221,35 +293,71 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
   const int seg_len = hdr + g.RB;
   // copy the segment to the file image
   unsigned char* dst = out + (size_t)item * stride + file_off;
-  for (int i = lane; i < seg_len; i += 64) dst[i] = seg[i];
-  // checksums: lane l owns bytes [l * chunk, (l + 1) * chunk) of the segment
-  const int chunk = (seg_len + 63) / 64;
-  const int b0 = min(lane * chunk, seg_len), b1 = min(b0 + chunk, seg_len);
+  if (!(BSR_PNG_KNOCK & 2)) {
+    // 16-byte pieces on LDS's boundaries (the pixels' alignment), stored to whatever byte address of the file they belong to (global memory takes
+    // unaligned stores on gfx950); the bytes in front of the first and behind the last whole piece go one per lane
+    typedef unsigned png_u4 __attribute__((ext_vector_type(4)));
+    const int head = min((hdr + 1) & 15, seg_len);          // segment bytes in front of the first 16-byte boundary
+    const int npiece = (seg_len - head) / 16, tail0 = head + 16 * npiece;
+    if (lane < head) dst[lane] = seg[lane];
+    if (lane < seg_len - tail0) dst[tail0 + lane] = seg[tail0 + lane];
+    for (int i = lane; i < npiece; i += 64) {
+      const png_u4 v = *reinterpret_cast<const png_u4*>(seg + head + 16 * i);
+      __builtin_memcpy(dst + head + 16 * i, &v, 16);
+    }
+  }
+  // checksums: lane l owns PIXEL bytes [l cb, (l + 1) cb) of the scanline — whole dwords of LDS — and lane 0 also what stands in front of them
+  // in the segment (headers, filter byte), so that the bytes of the scanline behind a lane's piece depend on the lane only
+  const int nbp = 3 * g.W, px0 = hdr + 1;                      // segment byte of the first pixel byte
+  const int p0 = min(lane * g.cb, nbp), p1 = min((lane + 1) * g.cb, nbp);
+  const int b0 = lane == 0 ? 0 : px0 + p0, b1 = px0 + p1;
   unsigned c = (y == 0 && lane == 0) ? 0xFFFFFFFFu : 0u;     // the checksummed stream starts with "IDAT"
   unsigned long long sa = 0, sb = 0;
   const unsigned long long n_raw = (unsigned long long)g.H * (unsigned long long)g.RB;
   const long long raw0 = (long long)y * g.RB - hdr;         // raw index of segment byte 0 (header bytes are not raw data)
-  for (int i = b0; i < b1; ++i) {
+  auto byte_step = [&](int i) {
     const unsigned d = seg[i];
     c = s_tab[(c ^ d) & 0xFFu] ^ (c >> 8);
     if (i >= hdr) {
       sa += d;
       sb += (n_raw - (unsigned long long)(raw0 + i)) * d;
     }
+  };
+  if (!(BSR_PNG_KNOCK & 1)) {
+    if (lane == 0)
+      for (int i = 0; i < px0; ++i) byte_step(i);
+    int i = px0 + p0;
+    for (; i + 4 <= b1; i += 4) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(seg + i);      // (px0 is on a 16-byte boundary of LDS, p0 a multiple of 4)
+      c ^= w;
+      c = s_tab[768 + (c & 0xFFu)] ^ s_tab[512 + ((c >> 8) & 0xFFu)] ^ s_tab[256 + ((c >> 16) & 0xFFu)] ^ s_tab[c >> 24];
+      const unsigned d0 = w & 0xFFu, d1 = (w >> 8) & 0xFFu, d2 = (w >> 16) & 0xFFu, d3 = w >> 24;
+      const unsigned long long wt = n_raw - (unsigned long long)(raw0 + i);      // weight of the dword's first byte; the next ones weigh one less each
+      sa += d0 + d1 + d2 + d3;
+      sb += wt * (d0 + d1 + d2 + d3) - (unsigned long long)(d1 + 2u * d2 + 3u * d3);
+    }
+    for (; i < b1; ++i) byte_step(i);
   }
   // shift this piece to the end of the checksummed stream (just before the Adler bytes): stream = "IDAT" + zlib stream - adler
   const unsigned stream_pos = file_off - 37u + (unsigned)b1;                     // bytes of the stream up to and including this piece ("IDAT" sits at file offset 37)
   const unsigned stream_end = 4u + g.zlen - 4u;
-  unsigned contrib = (b1 > b0) ? crc_shift_bytes(g, c, stream_end - stream_pos) : 0u;
+  const bool tabled = g.H <= kPngRowTable;                    // (uniform)
+  unsigned contrib = 0u;
+  if (b1 > b0) {
+    if (BSR_PNG_KNOCK & 8) contrib = c + stream_end - stream_pos;
+    else if (tabled) contrib = crc_multmodp(g.lane_shift[lane], c);                 // to the end of the scanline ...
+    else contrib = crc_shift_bytes(g, c, stream_end - stream_pos);
+  }
   for (int o = 32; o >= 1; o >>= 1) {
     contrib ^= __shfl_xor(contrib, o);
     sa += __shfl_xor(sa, o);
     sb += __shfl_xor(sb, o);
   }
+  if (tabled && lane == 0 && !(BSR_PNG_KNOCK & 8)) contrib = crc_multmodp(g.row_shift[y], contrib);      // ... and the scanline to the end of the stream
   if (lane == 0) { s_red[wave][0] = sa; s_red[wave][1] = sb; s_red[wave][2] = contrib; }
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && !(BSR_PNG_KNOCK & 16)) {
     unsigned long long ra = 0, rb = 0;
     unsigned rc = 0;
 #pragma unroll
@@ -271,7 +379,7 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
     s_last = ticket == (unsigned long long)gridDim.x - 1ull ? 1 : 0;
   }
   __syncthreads();
-  if (s_last && wave == 0) {
+  if (!(BSR_PNG_KNOCK & 16) && s_last && wave == 0) {
     // fold the 8 x {sum, sum, xor} sub-accumulators and clear them (and the ticket) for the next call: 32 lanes, one atomic exchange each —
     // as a chain in one thread the 25 round trips were 0.03 ms of the call
     unsigned long long* base = acc + (size_t)item * kPngSub * 4;
@@ -290,11 +398,11 @@ __global__ __launch_bounds__(256) void png_rows_kernel(const unsigned char* __re
 
 inline hipError_t launch_png_encode(const unsigned char* pixels, const PngFigs& figs, int B, const PngGeom& g, unsigned char* out, size_t stride,
                                     unsigned long long* acc, hipStream_t stream) {
-  const int smem = 1024 + kPngWaves * kPngSegMax;
+  const int smem_max = kPngTabBytes + kPngWaves * kPngSegMax, smem = kPngTabBytes + kPngWaves * png_seg_bytes(g.RB);
   static PerDeviceOnce once;
   const int dev = PerDeviceOnce::current();
   if (dev < 0 || !once.done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
     if (e != hipSuccess) return e;
     if (dev >= 0) once.done[dev] = true;
   }
