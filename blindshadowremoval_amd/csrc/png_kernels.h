@@ -82,6 +82,11 @@ __host__ __device__ inline unsigned crc_update_byte(unsigned c, unsigned byte) {
 
 inline bool png_geometry(int H, int W, PngGeom* g) {
   if (H <= 0 || W <= 0 || (long long)3 * W + 1 > 16384 || H > 65535) return false;      // a scanline must fit the per-wave LDS segment
+  // a loop encodes the same geometry thousands of times: the last one is kept per thread (the shift tables are ~330 polynomial multiplications)
+  static thread_local PngGeom last;
+  static thread_local bool have = false;
+  if (have && last.H == H && last.W == W) { *g = last; return true; }
+  struct Keep { PngGeom* g; ~Keep() { last = *g; have = true; } } keep{g};
   g->H = H; g->W = W;
   g->RB = 1 + 3 * W;
   g->R = 65535 / g->RB;
