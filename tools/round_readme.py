@@ -75,6 +75,20 @@ for kind in ("ffhq", "ucb"):
         keys = [k for k in ls[0] if isinstance(ls[0][k], dict) and "images_per_sec" in ls[0][k]]
         side.append("* `%s_loop_%s_{1,2}.json` — `FSRNet.%s` end to end: %s." % (tag, kind, "testFFHQ" if kind == "ffhq" else "test", "; ".join(
             "%s %s images/s" % (k, " / ".join("%.0f" % x[k]["images_per_sec"] for x in ls if k in x)) for k in keys)))
+stg = J("%s_loop_stage_table.json" % tag)
+if stg and "stages" in stg:
+    st = stg["stages"]
+    side.append("* `%s_loop_stage_table.json` — the loops' host stages, each ALONE through %s worker processes (`tools/loop_stage_table.py`): %s." % (
+        tag, stg.get("worker_processes", "?"), "; ".join("%s %.0f items/s (%.2f ms of CPU per item alone)" % (k, v["items_per_sec"], v["job_cpu_ms_alone"])
+                                                       for k, v in st.items() if k.startswith("loader_host_half"))))
+for extra, what in (("%s_nsplit_f32.txt" % tag, "the fp32 c3q GEMM under finer N splits (`-DBSR_NL_NSPLIT`; HISTORY: bounded attempt 2)"),
+                    ("%s_batch_sweep.json" % tag, "`tools/batch_sweep.py`: images/s against the batch per forward"),
+                    ("%s_lane_overlap.txt" % tag, "`tools/lane_overlap.py`: the two-forwards-in-flight mode in the profiler's view"),
+                    ("%s_pmc_mfma.json" % tag, "(+ `_f32x3`, `_f16`) matrix-pipe utilisation and clock per kernel from the counter passes (`tools/pmc_mfma.py`)"),
+                    ("%s_pmc_traffic.json" % tag, "(+ `_f32x3`, `_f16`) HBM bytes per kernel from the counter passes (`tools/pmc_traffic.py`), the source of `traffic` and `hbm frac (counters)`"),
+                    ("%s_kernel_stats_tsm512.csv" % tag, "(+ `_b16`) rocprofv3 kernel-trace summaries of configs[4]'s per-rank shape and of B = 16")):
+    if os.path.isfile(os.path.join(ROOT, "profiles", extra)):
+        side.append("* `%s` — %s." % (extra, what))
 mg = os.path.join(ROOT, "profiles", "%s_f16_margins.txt" % tag)
 if os.path.isfile(mg):
     side.append("* `%s_f16_margins.txt` — what the f16-mode tests measured against F16_TOL = 2e-3: %s." % (
