@@ -94,6 +94,26 @@ def test_every_filter_type_and_channel_count(h, w, c):
         np.testing.assert_array_equal(o, want)
 
 
+def test_random_geometries_in_one_batch():
+    """Forty images of random size (1-256 rows, 2-300 pixels wide with w c >= 4), channel count and per-row filter types in ONE launch — the
+    items of a batch need not look alike."""
+    from blindshadowremoval_amd import pngio
+    rng = np.random.RandomState(2026)
+    items, want = [], []
+    while len(items) < 40:
+        h, w, c = int(rng.randint(1, 257)), int(rng.randint(2, 301)), int(rng.choice([1, 3, 4]))
+        if w * c < 4:
+            continue
+        img = rng.randint(0, 256, (h, w, c)).astype(np.uint8)
+        if rng.rand() < 0.5:
+            img[:, : w // 2] = img[:1, :1]                    # flat areas: predictor ties
+        raw = _filter_rows(img, rng.randint(0, 5, h))
+        items.append((raw, h, w, c))
+        want.append(img if c == 3 else (np.repeat(img, 3, axis=2) if c == 1 else img[:, :, :3]))
+    for o, wv in zip(_run(items), want):
+        np.testing.assert_array_equal(o, wv)
+
+
 def test_the_ucb_masks_as_grey_levels():
     """The seven segmentation masks of an item the way the UCB loop sends them (prep._masks_raw): filtered grey scanlines in, one byte per
     pixel out — the grey levels pngio.read_grey_u8 reads from the files."""
