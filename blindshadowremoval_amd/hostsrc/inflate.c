@@ -140,8 +140,48 @@ static inline void refill(Bits* b)
 /* bytes of input really consumed so far (bits still in the buffer do not count) */
 static inline size_t consumed(const Bits* b) { return b->pos - (size_t)(b->cnt >> 3); }
 
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+/* the same two sums 32 bytes per step (round 6: the scalar form was 14 % of a photograph's inflate): a += sum b_i; s += 32 a_before +
+ * sum (32 - i) b_i, kept unreduced for a run of at most 5 536 bytes.  Compiled for AVX2 whatever the build's -march; used when the CPU has it. */
+__attribute__((target("avx2"))) static uint32_t adler32_avx2(const uint8_t* p, size_t n)
+{
+    uint32_t a = 1, s = 0;
+    const __m256i weights = _mm256_setr_epi8(32, 31, 30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1);
+    const __m256i ones = _mm256_set1_epi16(1), zero = _mm256_setzero_si256();
+    while (n >= 32) {
+        size_t k = (n < 5536 ? n : 5536) & ~(size_t)31;        /* 173 steps: every 32-bit lane stays far below 2^31 */
+        n -= k;
+        __m256i vs1 = zero, vs2 = zero, vs3 = zero;            /* byte sums (4 x 64 bit), weighted sums (8 x 32 bit), sum of the byte sums BEFORE each step */
+        const uint32_t steps = (uint32_t)(k / 32);
+        for (uint32_t i = 0; i < steps; ++i, p += 32) {
+            const __m256i b = _mm256_loadu_si256((const __m256i*)p);
+            vs3 = _mm256_add_epi64(vs3, vs1);
+            vs1 = _mm256_add_epi64(vs1, _mm256_sad_epu8(b, zero));
+            vs2 = _mm256_add_epi32(vs2, _mm256_madd_epi16(_mm256_maddubs_epi16(b, weights), ones));
+        }
+        uint64_t t1[4], t3[4];
+        uint32_t t2[8];
+        _mm256_storeu_si256((__m256i*)t1, vs1);
+        _mm256_storeu_si256((__m256i*)t3, vs3);
+        _mm256_storeu_si256((__m256i*)t2, vs2);
+        const uint64_t s1 = t1[0] + t1[1] + t1[2] + t1[3], s3 = t3[0] + t3[1] + t3[2] + t3[3];
+        uint64_t s2 = 0;
+        for (int i = 0; i < 8; ++i) s2 += t2[i];
+        s = (uint32_t)(((uint64_t)s + (uint64_t)k * a + 32u * s3 + s2) % 65521u);
+        a = (uint32_t)(((uint64_t)a + s1) % 65521u);
+    }
+    while (n--) { a += *p++; s += a; }                         /* fewer than 32 bytes: no overflow */
+    return ((s % 65521u) << 16) | (a % 65521u);
+}
+#define BSR_HAVE_ADLER_AVX2 1
+#endif
+
 static uint32_t adler32(const uint8_t* p, size_t n)
 {
+#ifdef BSR_HAVE_ADLER_AVX2
+    if (__builtin_cpu_supports("avx2")) return adler32_avx2(p, n);
+#endif
     uint32_t a = 1, s = 0;
     while (n) {
         size_t k = n < 5552 ? n : 5552;                /* the largest run before a 32-bit sum can overflow */

@@ -230,3 +230,22 @@ def test_host_inflate_on_the_reference_files_and_on_damaged_streams(golden_dir):
         assert rc <= 0 and (rc != 0 or got == want)
         refused += rc != 0
     assert refused > 550
+
+
+def test_inflate_adler32_over_lengths_and_extreme_bytes():
+    """The Adler-32 that vouches for the inflate's output (hostsrc/inflate.c: 32 bytes per step on AVX2 since round 6, scalar elsewhere) must
+    ACCEPT every valid stream — a wrong sum would only show as a silent fallback to zlib: lengths around the 32-byte step and the 5 536-byte
+    run, all-0xFF data (the largest sums), random data."""
+    import zlib
+    from blindshadowremoval_amd import pngio
+    lib = pngio._host_lib()
+    if lib is None:
+        pytest.skip("no C compiler: libbsr_host.so unavailable")
+    rng = np.random.RandomState(7)
+    for n in list(range(0, 70)) + [5535, 5536, 5537, 5567, 5568, 11071, 11072, 11073, 65521, 200000]:
+        for data in (bytes([255]) * n, rng.randint(0, 256, n).astype(np.uint8).tobytes()):
+            for level in (0, 6):
+                z = zlib.compress(data, level) + bytes(16)
+                out = np.empty(n + 16, np.uint8)
+                assert lib.bsr_inflate_zlib(z, len(z) - 16, out.ctypes.data, n) == 0, (n, level)
+                assert out[:n].tobytes() == data
