@@ -26,7 +26,7 @@ real.name_list = (base * 16)[:16]
 if ucb:
     real.ucb_mask_files = (masks * 16)[:16]
 elems = [tuple(e) for e in real.feed]
-elems = [(e[0].clone(), e[1], e[2]) + ((("dev_bits", e[3][1].clone(), e[3][2]),) if len(e) > 3 else ()) for e in elems]
+elems = [(e[0].clone(), e[1], e[2]) + (((e[3][0], e[3][1].clone(), e[3][2]),) if len(e) > 3 else ()) for e in elems]
 real.close()
 
 
