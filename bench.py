@@ -1044,7 +1044,7 @@ def run_rank(args):
                                                   with_parity=(world == 1 and not args.no_cpu_baseline), lanes=lanes)
             if args.loop and world == 1:
                 from blindshadowremoval_amd.loop_bench import loop_bench
-                result["loop"] = loop_bench(args.loop, os.path.join(ROOT, "tests", "golden"), gen, dtype=args.dtype)      # (--dtype f32x3: the loops on the split-precision generator)
+                result["loop"] = loop_bench(args.loop, os.path.join(ROOT, "tests", "golden"), gen)
         line = json.dumps(result) + "\n"
         if real_stdout is not None:
             sys.stdout.flush()
