@@ -428,6 +428,35 @@ def test_loader_ring_slot_holds_what_the_pipe_would_carry(tmp_path, golden_dir):
         prep._layout(recs, 256)
 
 
+def test_device_unfilter_is_decided_per_loop(golden_dir, monkeypatch):
+    """Dataset.device_unfilter (round 6): None = the UCB loop with its masks reconstructs PNG scanlines on the device, the FFHQ loop does not;
+    True / False force it; BSR_DEVICE_UNFILTER=0 / 1 overrides both.  The decision travels as the 4th element of the job's ring tuple."""
+    from types import SimpleNamespace
+    from blindshadowremoval_amd.fsrnet import Config, FSRNet
+    cfg = Config(0)
+    cfg.DATA_DIR_TEST = [os.path.join(golden_dir, "UCB", "train", "input", "*")]
+    cfg.UCB_MASK_ROOT = os.path.join(golden_dir, "UCB_masks")
+    fsr = FSRNet.__new__(FSRNet)
+    fsr.config = cfg
+    mf = fsr._ucb_masks()
+    monkeypatch.delenv("BSR_DEVICE_UNFILTER", raising=False)
+
+    def flag(ucb, masks, setting=None):
+        ds = D.Dataset(cfg, "test", ucb=ucb)
+        ds.device_prep, ds.device_unfilter = 0, setting
+        ds.ucb_mask_files = mf if masks else None
+        ds._ring, ds._ring_seq, ds._ring_copies = SimpleNamespace(nslots=64, cap=1 << 20, path_for_workers="/dev/null"), 0, []
+        job = next(iter(ds._jobs()))
+        assert len(job) == 5 and job[4][:3] == ("/dev/null", 0, 1 << 20)
+        return job[4][3]
+    assert flag(True, True) is True and flag(True, False) is False and flag(False, False) is False
+    assert flag(False, False, True) is True and flag(True, True, False) is False
+    monkeypatch.setenv("BSR_DEVICE_UNFILTER", "0")
+    assert flag(True, True) is False and flag(False, False, True) is False
+    monkeypatch.setenv("BSR_DEVICE_UNFILTER", "1")
+    assert flag(False, False) is True and flag(True, True, False) is True
+
+
 def pickle_bytes(x) -> bytes:
     import pickle
     return pickle.dumps(x, protocol=pickle.HIGHEST_PROTOCOL)
