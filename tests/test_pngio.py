@@ -249,3 +249,29 @@ def test_inflate_adler32_over_lengths_and_extreme_bytes():
                 out = np.empty(n + 16, np.uint8)
                 assert lib.bsr_inflate_zlib(z, len(z) - 16, out.ctypes.data, n) == 0, (n, level)
                 assert out[:n].tobytes() == data
+
+
+def test_raw_scanlines_and_the_host_reconstruction_without_the_c_library(tmp_path, monkeypatch):
+    """pngio.read_rgb_raw hands back the inflated, still filtered scanlines of a plain 8-bit PNG (what the UCB loop's workers put into
+    their ring slot since round 6) and everything else decoded; RawScanlines.decode / unfilter_host give PIL's pixels — through
+    libbsr_host.so and through the plain numpy statement used where no C compiler exists."""
+    from blindshadowremoval_amd import pngio
+    rng = np.random.RandomState(11)
+    for mode, c in (("RGB", 3), ("L", 1), ("RGBA", 4)):
+        a = rng.randint(0, 256, (23, 31, c)).astype(np.uint8)
+        a[5:9] = a[5]
+        f = str(tmp_path / ("x_%s.png" % mode))
+        Image.fromarray(a[:, :, 0] if c == 1 else a, mode).save(f)
+        r = pngio.read_rgb_raw(f)
+        assert isinstance(r, pngio.RawScanlines) and (r.h, r.w, r.c) == (23, 31, c) and r.raw.size == 23 * (1 + 31 * c) and r.shape == (23, 31, 3)
+        want = np.asarray(Image.open(f).convert("RGB"))
+        assert np.array_equal(r.decode(), want) and np.array_equal(pngio.read_rgb_u8(f), want)
+        monkeypatch.setattr(pngio, "_HOST", [None, True])                  # no C library: the numpy statement
+        assert np.array_equal(pngio._to_rgb(pngio.unfilter_host(r.raw, r.h, r.w, r.c)), want)
+        monkeypatch.undo()
+    pal = str(tmp_path / "p.png")
+    Image.fromarray(rng.randint(0, 4, (9, 9)).astype(np.uint8), "P").save(pal)      # a palette file is PIL's: decoded, not raw
+    d = pngio.read_rgb_raw(pal)
+    assert isinstance(d, np.ndarray) and d.shape == (9, 9, 3)
+    with pytest.raises(ValueError):
+        pngio.unfilter_host(np.zeros(10, np.uint8), 2, 2, 3)
