@@ -86,7 +86,9 @@ for extra, what in (("%s_nsplit_f32.txt" % tag, "the fp32 c3q GEMM under finer N
                     ("%s_lane_overlap.txt" % tag, "`tools/lane_overlap.py`: the two-forwards-in-flight mode in the profiler's view"),
                     ("%s_pmc_mfma.json" % tag, "(+ `_f32x3`, `_f16`) matrix-pipe utilisation and clock per kernel from the counter passes (`tools/pmc_mfma.py`)"),
                     ("%s_pmc_traffic.json" % tag, "(+ `_f32x3`, `_f16`) HBM bytes per kernel from the counter passes (`tools/pmc_traffic.py`), the source of `traffic` and `hbm frac (counters)`"),
-                    ("%s_kernel_stats_tsm512.csv" % tag, "(+ `_b16`) rocprofv3 kernel-trace summaries of configs[4]'s per-rank shape and of B = 16")):
+                    ("%s_kernel_stats_tsm512.csv" % tag, "(+ `_b16`) rocprofv3 kernel-trace summaries of configs[4]'s per-rank shape and of B = 16"),
+                    ("%s_kernel_stats_ucb_post.csv" % tag, "(+ `_png`, `_unfilter`) rocprofv3 kernel-trace summaries of the loops' device stages alone: `bsr_ucb_post` on 16 UCB items "
+                     "(`scratch/ucb_time.py`: the stage chain), `bsr_png_encode` / `_figs` on 16 strips (`scratch/png_time.py`), `bsr_png_unfilter` on 16 / 32 photographs (`scratch/unf_time.py`)")):
     if os.path.isfile(os.path.join(ROOT, "profiles", extra)):
         side.append("* `%s` — %s." % (extra, what))
 mg = os.path.join(ROOT, "profiles", "%s_f16_margins.txt" % tag)
